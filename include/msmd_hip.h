@@ -1,0 +1,283 @@
+/*
+ * msmd_hip.h -- C ABI of libmsmd_hip.so: the MI355X (gfx950) implementation of
+ * MSMDFusion's sparse-voxel fusion hot path.
+ *
+ * The reference has no C ABI for this path; its boundary is pybind11 torch
+ * extensions plus the spconv-2.x Python package.  Every entry point below
+ * names the reference interface it replaces (paths relative to the reference
+ * checkout).  INTEGRATION.md shows the binding a reference maintainer adds.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless the
+ *     parameter is documented "host";
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it,
+ *     nothing synchronises the device, nothing allocates;
+ *   - outputs and scratch are caller-allocated; scratch sizes come from the
+ *     matching *_workspace_bytes() query; workspace base must be 256-B aligned;
+ *   - the return value is an msmd_status (0 = ok, <0 = error, nothing was
+ *     enqueued on error); msmd_status_string() names it;
+ *   - re-entrant: no global mutable state; two streams may call concurrently
+ *     with distinct workspaces.
+ *   - tensors are dense row-major; `indices` rows are (batch, z, y, x) int32.
+ */
+#ifndef MSMD_HIP_H_
+#define MSMD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* msmd_stream_t; /* hipStream_t */
+
+enum msmd_status {
+  MSMD_OK = 0,
+  MSMD_ERR_INVALID_ARG = -1,
+  MSMD_ERR_WORKSPACE = -2,   /* workspace too small or misaligned            */
+  MSMD_ERR_UNSUPPORTED = -3, /* shape / parameter outside the built kernels  */
+  MSMD_ERR_LAUNCH = -4,      /* hipGetLastError() != hipSuccess after launch */
+  MSMD_ERR_RANGE = -5        /* linear voxel id would not fit 32 bits        */
+};
+
+const char* msmd_status_string(int status);
+/* ABI version: bumped whenever a signature below changes. */
+int msmd_abi_version(void);
+/* 1 when a gfx950 device is visible to this process, else 0 (host call). */
+int msmd_device_ok(void);
+
+/* ------------------------------------------------------------------------ *
+ * a1/a3  Hard voxelization (+ fused mean VFE)
+ * replaces: voxel_layer.hard_voxelize  mmdet3d/ops/voxel/src/voxelization.h:51-69
+ *           (CPU mmdet3d/ops/voxel/src/voxelization_cpu.cpp:44-142,
+ *            CUDA mmdet3d/ops/voxel/src/voxelization_cuda.cu:184-326)
+ *           HardSimpleVFE.forward  mmdet3d/models/voxel_encoders/voxel_encoder.py:29-46
+ * Semantics kept bit-for-bit: float32 floor((p-min)/size) coordinates, grid =
+ * round((max-min)/size), voxel id = rank of the voxel's first point in input
+ * order, slot = number of earlier same-voxel points (< max_points kept), the
+ * `break` at the point that would open voxel number max_voxels.
+ * Only rows [0, *voxel_num) of voxels/coors/num_points_per_voxel are written
+ * (padding slots inside a written voxel row are zero-filled); the caller
+ * reads *voxel_num (device int32) after the stream reaches this point.
+ * ------------------------------------------------------------------------ */
+size_t msmd_voxelize_workspace_bytes(int num_points, int max_voxels,
+                                     int max_points);
+
+int msmd_hard_voxelize(const float* points, int num_points, int num_features,
+                       const float* voxel_size /* host[3] x,y,z */,
+                       const float* coors_range /* host[6] xyzxyz min,max */,
+                       int max_points, int max_voxels,
+                       float* voxels /* [max_voxels,max_points,C] or NULL */,
+                       int32_t* coors /* [max_voxels,3] (z,y,x) */,
+                       int32_t* num_points_per_voxel /* [max_voxels] */,
+                       float* voxel_mean /* [max_voxels,C] or NULL: fused VFE */,
+                       int32_t* voxel_num /* [1] */, void* workspace,
+                       size_t workspace_bytes, msmd_stream_t stream);
+
+/* HardSimpleVFE on an already materialised voxel tensor (unfused form). */
+int msmd_voxel_mean(const float* voxels /* [M,max_points,C] */,
+                    const int32_t* num_points_per_voxel, int num_voxels,
+                    int max_points, int num_features, int out_features,
+                    float* out /* [M,out_features] */, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * a5  Submanifold rulebook (hash-based voxel index)
+ * replaces: sparse_conv_ext.get_indice_pairs_3d(..., subM=1)
+ *           mmdet3d/ops/spconv/src/all.cc:21-27,
+ *           mmdet3d/ops/spconv/include/spconv/spconv_ops.h:28-107,
+ *           algorithm geometry.h:247-297 (getIndicePairsSubM), CUDA
+ *           indice.cu.h:148-203; spconv-2.x ops.get_indice_pairs_implicit_gemm
+ *           (bug_fix/conv.py:382-396).
+ * Output is output-stationary: nbr[k*n + o] = input row feeding output row o
+ * through kernel offset k ((kz*KH+ky)*KW+kx, geometry.h:62-73), or -1.
+ * msmd_rulebook_pairs() converts it to the reference's indicePairs/indiceNum.
+ * ------------------------------------------------------------------------ */
+size_t msmd_rulebook_subm_workspace_bytes(int n);
+
+int msmd_rulebook_subm3d(const int32_t* indices /* [n,4] */, int n,
+                         int batch_size, const int* spatial_shape /* host[3] */,
+                         const int* ksize /* host[3] */,
+                         int32_t* nbr /* [K,n] */, void* workspace,
+                         size_t workspace_bytes, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * a6  Strided (regular) sparse conv rulebook, two phases with one host read
+ * replaces: sparse_conv_ext.get_indice_pairs_3d(..., subM=0)
+ *           spconv_ops.h:108-137, geometry.h:144-194 (getIndicePairsConv),
+ *           CUDA indice.cu.h:22-65,112-145 + torch::_unique.
+ * Output rows are in ascending linear (b,z,y,x) id, the order of the
+ * reference's CUDA path (spconv_ops.h:130).  Phase 1 marks the occupied
+ * output cells and counts them (*n_out, device); the caller reads it,
+ * allocates, then phase 2 fills out_indices / nbr_fwd / nbr_bwd.  The same
+ * workspace must be passed, untouched, to both phases.
+ * ------------------------------------------------------------------------ */
+size_t msmd_rulebook_conv_workspace_bytes(int batch_size,
+                                          const int* out_shape /* host[3] */);
+
+int msmd_rulebook_conv3d_count(const int32_t* indices /* [n,4] */, int n,
+                               int batch_size, const int* out_shape,
+                               const int* ksize, const int* stride,
+                               const int* padding, int32_t* n_out /* [1] */,
+                               void* workspace, size_t workspace_bytes,
+                               msmd_stream_t stream);
+
+int msmd_rulebook_conv3d_fill(const int32_t* indices, int n, int batch_size,
+                              const int* out_shape, const int* ksize,
+                              const int* stride, const int* padding, int n_out,
+                              int32_t* out_indices /* [n_out,4] */,
+                              int32_t* nbr_fwd /* [K,n_out] in-row or -1 */,
+                              int32_t* nbr_bwd /* [K,n]    out-row or -1 */,
+                              void* workspace, size_t workspace_bytes,
+                              msmd_stream_t stream);
+
+/* nbr table -> reference rulebook format: indice_pairs[K,2,ld] (-1 padded,
+ * pairs of one offset sorted by output row) and indice_num[K]
+ * (spconv_ops.h:55-59).  n_rows = number of output rows of `nbr`. */
+size_t msmd_rulebook_pairs_workspace_bytes(int kernel_volume, int n_rows);
+
+int msmd_rulebook_pairs(const int32_t* nbr /* [K,n_rows] */, int kernel_volume,
+                        int n_rows, int32_t* indice_pairs /* [K,2,ld] */,
+                        int ld, int32_t* indice_num /* [K] */, void* workspace,
+                        size_t workspace_bytes, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * a7/a8  Sparse convolution arithmetic (implicit GEMM on MFMA)
+ * replaces: sparse_conv_ext.indice_conv_fp32 / indice_conv_backward_fp32
+ *           all.cc:28-51, spconv_ops.h:260-456 (+ reordering.cc:20-50);
+ *           spconv-2.x Fsp.implicit_gemm (bug_fix/conv.py:441-447).
+ *   out[o,:] = sum_k in[nbr[k,o],:] @ W[k]          (W[k] is [c_in,c_out])
+ * `weight` is plain [K,c_in,c_out] fp32; msmd_spconv_pack_weight() converts
+ * it (optionally transposing each W[k]) to the MFMA fragment order the
+ * kernels read; packed size is K*round16(c_in)*round16(c_out) floats.
+ * dgrad = the same kernel on the backward table with transposed weights.
+ * `weight_flip` != 0 pairs table row k with weight K-1-k: a SubM (odd kernel)
+ * forward table read that way IS its backward table, so SubM dgrad needs no
+ * second rulebook.
+ * ------------------------------------------------------------------------ */
+size_t msmd_spconv_packed_weight_elems(int kernel_volume, int c_in, int c_out);
+
+int msmd_spconv_pack_weight(const float* weight /* [K,c_in,c_out] */,
+                            int kernel_volume, int c_in, int c_out,
+                            int transpose /* pack W[k]^T: [c_out,c_in] */,
+                            float* packed, msmd_stream_t stream);
+
+int msmd_spconv_fwd_f32(const float* in_feat /* [n_in,c_in] */, int n_in,
+                        int c_in, const float* packed_weight,
+                        const int32_t* nbr /* [K,ld] */, int ld, int n_out,
+                        int kernel_volume, int weight_flip,
+                        float* out_feat /* [n_out,c_out] */, int c_out,
+                        msmd_stream_t stream);
+
+/* dW[k] = sum over pairs p of offset k: in[pairs[k,0,p],:]^T (x) dout[pairs[k,1,p],:]
+ * (spconv_ops.h:399,438).  Deterministic two-pass reduction. */
+size_t msmd_spconv_wgrad_workspace_bytes(int kernel_volume, int ld, int c_in,
+                                         int c_out);
+
+int msmd_spconv_wgrad_f32(const float* in_feat, int c_in, const float* d_out,
+                          int c_out, const int32_t* indice_pairs /* [K,2,ld] */,
+                          const int32_t* indice_num /* [K] device */, int ld,
+                          int kernel_volume, float* d_weight /* [K,c_in,c_out] */,
+                          void* workspace, size_t workspace_bytes,
+                          msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * a12  SparseConvTensor.dense(): BEV scatter
+ * replaces: scatter_nd + permute + contiguous
+ *           mmdet3d/ops/spconv/structure.py:5-18,55-64
+ * out is [B,C,D,H,W] contiguous (channels-first) and is fully written
+ * (zero-filled then scattered) by this call.  The backward gathers.
+ * ------------------------------------------------------------------------ */
+int msmd_dense_scatter_f32(const float* feat /* [n,c] */,
+                           const int32_t* indices /* [n,4] */, int n, int c,
+                           int batch_size, const int* spatial_shape,
+                           float* out, msmd_stream_t stream);
+int msmd_dense_gather_f32(const float* dense /* [B,C,D,H,W] */,
+                          const int32_t* indices, int n, int c, int batch_size,
+                          const int* spatial_shape, float* feat /* [n,c] */,
+                          msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * a17  spconv.pytorch.functional.sparse_add(a, b)
+ * call site: mmdet3d/models/middle_encoders/sparse_multimodal_encoder_painting.py:455
+ * Union of two coordinate sets on one grid, rows in ascending linear id,
+ * features summed where both are present.  Two phases like the strided
+ * rulebook; map_a/map_b give each input row's output row (for autograd).
+ * ------------------------------------------------------------------------ */
+size_t msmd_sparse_add_workspace_bytes(int batch_size, const int* spatial_shape);
+
+int msmd_sparse_add_count(const int32_t* idx_a, int n_a, const int32_t* idx_b,
+                          int n_b, int batch_size, const int* spatial_shape,
+                          int32_t* n_out /* [1] */, void* workspace,
+                          size_t workspace_bytes, msmd_stream_t stream);
+
+int msmd_sparse_add_fill(const float* feat_a, const int32_t* idx_a, int n_a,
+                         const float* feat_b, const int32_t* idx_b, int n_b,
+                         int c, int batch_size, const int* spatial_shape,
+                         int n_out, int32_t* out_indices /* [n_out,4] */,
+                         float* out_feat /* [n_out,c] */,
+                         int32_t* map_a /* [n_a] */, int32_t* map_b /* [n_b] */,
+                         void* workspace, size_t workspace_bytes,
+                         msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * a14  voxel_modality_split: LiDAR voxels vs virtual-point voxels
+ * replaces: MSMDFusionDetector.voxel_modality_split + numba type_assign
+ *           mmdet3d/models/detectors/MSMDFusion.py:27-45,251-325
+ * mix3d[i]/mix2d[j] = 1 when the voxel exists in both sets (same b,z,y,x).
+ * pair_3d/pair_2d list the matched rows, aligned, in ascending linear id;
+ * *n_mixed (device) is their count.  Keys are exact integers (the reference's
+ * float32 keys alias, SURVEY Appendix B.3 -- deliberate, documented fix).
+ * ------------------------------------------------------------------------ */
+size_t msmd_modality_split_workspace_bytes(int batch_size,
+                                           const int* spatial_shape);
+
+int msmd_modality_split(const int32_t* idx_3d /* [n3,4] */, int n3,
+                        const int32_t* idx_2d /* [n2,4] */, int n2,
+                        int batch_size, const int* spatial_shape,
+                        int32_t* mix3d /* [n3] */, int32_t* mix2d /* [n2] */,
+                        int32_t* pair_3d /* [min(n3,n2)] */,
+                        int32_t* pair_2d /* [min(n3,n2)] */,
+                        int32_t* n_mixed /* [1] */, void* workspace,
+                        size_t workspace_bytes, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * a15  GMA-Conv neighbour search helpers
+ * replaces: furthest_point_sample_ext.furthest_point_sampling_wrapper
+ *           mmdet3d/ops/furthest_point_sample/src/furthest_point_sample_cuda.cu:25-141
+ *           ball_query_ext.ball_query_wrapper
+ *           mmdet3d/ops/ball_query/src/ball_query_cuda.cu:11-54
+ *           and the dense torch.norm/min/index_put_ glue of fps_NN_fast
+ *           sparse_multimodal_encoder_painting.py:276-323
+ * FPS reproduces the reference block reduction's tie order exactly.
+ * ------------------------------------------------------------------------ */
+int msmd_furthest_point_sample(const float* xyz /* [b,n,3] */, int b, int n,
+                               int m, float* temp /* [b,n] scratch */,
+                               int32_t* idx /* [b,m] */, msmd_stream_t stream);
+
+int msmd_ball_query(const float* center_xyz /* [b,m,3] */,
+                    const float* xyz /* [b,n,3] */, int b, int n, int m,
+                    float min_radius, float max_radius, int nsample,
+                    int32_t* idx /* [b,m,nsample] */, msmd_stream_t stream);
+
+/* nearest key per query: out_idx[q] = argmin_k |query_q - key_k| (lowest k on
+ * ties) when sqrt(d2) < dist_thresh, else -1.  Integer voxel coordinates.
+ * scratch: nq * 8 bytes. */
+int msmd_nn_search(const int32_t* query_zyx /* [nq,3] */, int nq,
+                   const int32_t* key_zyx /* [nk,3] */, int nk,
+                   float dist_thresh, int32_t* out_idx /* [nq] */,
+                   void* scratch, msmd_stream_t stream);
+
+/* fps_NN_fast's last step: every query inside the ball of a valid
+ * representative inherits that representative's nearest key; when several
+ * balls cover a query the highest representative index wins (the order a
+ * sequential index_put_ leaves, sparse_multimodal_encoder_painting.py:321). */
+int msmd_nn_assign(const int32_t* group_idx /* [m,nsample] ball-query out */,
+                   const int32_t* rep_nn /* [m] nearest key or -1 */, int m,
+                   int nsample, int nq, int32_t* query_nn /* [nq], -1 init by callee */,
+                   int32_t* scratch /* [nq] */, msmd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSMD_HIP_H_ */

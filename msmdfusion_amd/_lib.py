@@ -1,0 +1,86 @@
+"""ctypes binding of libmsmd_hip.so (C ABI: include/msmd_hip.h).
+
+The library is the product: if it has not been built this module raises at
+import -- there is no CPU or PyTorch fallback anywhere in msmdfusion_amd.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C msmdfusion_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsmd_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        f"{LIB_PATH} is missing: the HIP library is not built. Run "
+        "`make -C msmdfusion_amd/csrc` (hipcc, --offload-arch=gfx950). "
+        "msmdfusion_amd has no fallback path.")
+
+lib = C.CDLL(LIB_PATH)
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_ip = C.POINTER(C.c_int)
+_fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes).  Mirrors include/msmd_hip.h one to one;
+# tests/test_boundary.py checks the two stay in sync.
+SIGNATURES = {
+    "msmd_status_string": (C.c_char_p, [_i]),
+    "msmd_abi_version": (_i, []),
+    "msmd_device_ok": (_i, []),
+    "msmd_voxelize_workspace_bytes": (_sz, [_i, _i, _i]),
+    "msmd_hard_voxelize": (_i, [_vp, _i, _i, _fp, _fp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "msmd_voxel_mean": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "msmd_rulebook_subm_workspace_bytes": (_sz, [_i]),
+    "msmd_rulebook_subm3d": (_i, [_vp, _i, _i, _ip, _ip, _vp, _vp, _sz, _vp]),
+    "msmd_rulebook_conv_workspace_bytes": (_sz, [_i, _ip]),
+    "msmd_rulebook_conv3d_count": (_i, [_vp, _i, _i, _ip, _ip, _ip, _ip, _vp, _vp, _sz, _vp]),
+    "msmd_rulebook_conv3d_fill": (_i, [_vp, _i, _i, _ip, _ip, _ip, _ip, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "msmd_rulebook_pairs_workspace_bytes": (_sz, [_i, _i]),
+    "msmd_rulebook_pairs": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "msmd_spconv_packed_weight_elems": (_sz, [_i, _i, _i]),
+    "msmd_spconv_pack_weight": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "msmd_spconv_fwd_f32": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "msmd_spconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "msmd_spconv_wgrad_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "msmd_dense_scatter_f32": (_i, [_vp, _vp, _i, _i, _i, _ip, _vp, _vp]),
+    "msmd_dense_gather_f32": (_i, [_vp, _vp, _i, _i, _i, _ip, _vp, _vp]),
+    "msmd_sparse_add_workspace_bytes": (_sz, [_i, _ip]),
+    "msmd_sparse_add_count": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _sz, _vp]),
+    "msmd_sparse_add_fill": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _ip, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "msmd_modality_split_workspace_bytes": (_sz, [_i, _ip]),
+    "msmd_modality_split": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "msmd_furthest_point_sample": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "msmd_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp]),
+    "msmd_nn_search": (_i, [_vp, _i, _vp, _i, _f, _vp, _vp, _vp]),
+    "msmd_nn_assign": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == the library is stale
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+ABI_VERSION = 1
+if lib.msmd_abi_version() != ABI_VERSION:
+    raise RuntimeError("libmsmd_hip.so ABI version mismatch: rebuild msmdfusion_amd/csrc")
+
+
+class MsmdError(RuntimeError):
+    """A C-ABI call returned a non-zero msmd_status (the reference raises
+    RuntimeError from TV_ASSERT_RT_ERR / TORCH_CHECK the same way)."""
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib.msmd_status_string(status).decode()
+        raise MsmdError(f"{what}: {msg} (msmd_status {status})")
+
+
+def int3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+def float_arr(v):
+    return (C.c_float * len(v))(*[float(x) for x in v])

@@ -1,0 +1,126 @@
+// common.hpp -- shared helpers of libmsmd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/msmd_hip.h"
+
+#define MSMD_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace msmd {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+inline int launch_status() {
+  return hipGetLastError() == hipSuccess ? MSMD_OK : MSMD_ERR_LAUNCH;
+}
+
+// Bump allocator over the caller's workspace (256-B aligned slices).
+struct Arena {
+  char* base;
+  size_t off = 0, cap;
+  Arena(void* p, size_t bytes) : base((char*)p), cap(bytes) {}
+  template <typename T>
+  T* take(size_t n) {
+    size_t o = off;
+    off = align_up(off + n * sizeof(T));
+    return (T*)(base + o);
+  }
+  bool ok() const { return off <= cap && ((uintptr_t)base & 255) == 0; }
+};
+// Same arithmetic without memory, for the *_workspace_bytes() queries.
+struct ArenaSize {
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t n) { off = align_up(off + n * sizeof(T)); return nullptr; }
+};
+
+inline int next_pow2_bits(long v) {  // smallest b with (1<<b) >= v
+  int b = 0;
+  while ((1L << b) < v) ++b;
+  return b;
+}
+
+// ---- 32-bit key -> slot hash (multiplicative, table size 2^bits) ----------
+__device__ __forceinline__ uint32_t hash_slot(uint32_t key, int bits) {
+  return (key * 0x9E3779B1u) >> (32 - bits);
+}
+constexpr uint64_t kEmptySlot = 0xFFFFFFFFFFFFFFFFull;
+
+// Insert (key -> val) keeping, for equal keys, min(val) (KeepMax=false) or
+// max(val).  Slot = key<<32 | val in one 64-bit word: one CAS claims it, one
+// atomicMin/Max merges duplicates.  Returns the slot index.
+template <bool KeepMax>
+__device__ __forceinline__ uint32_t hash_insert(unsigned long long* table, int bits,
+                                                uint32_t key, uint32_t val) {
+  const uint32_t mask = (1u << bits) - 1;
+  uint32_t h = hash_slot(key, bits);
+  const unsigned long long packed = ((unsigned long long)key << 32) | val;
+  while (true) {
+    unsigned long long cur = table[h];
+    if (cur == kEmptySlot) {
+      cur = atomicCAS(&table[h], (unsigned long long)kEmptySlot, packed);
+      if (cur == kEmptySlot) return h;
+    }
+    if ((uint32_t)(cur >> 32) == key) {
+      if (KeepMax) atomicMax(&table[h], packed); else atomicMin(&table[h], packed);
+      return h;
+    }
+    h = (h + 1) & mask;
+  }
+}
+
+// Lookup: value stored for key, or -1.
+__device__ __forceinline__ int hash_find(const unsigned long long* __restrict__ table,
+                                         int bits, uint32_t key) {
+  const uint32_t mask = (1u << bits) - 1;
+  uint32_t h = hash_slot(key, bits);
+  while (true) {
+    unsigned long long cur = table[h];
+    if (cur == kEmptySlot) return -1;
+    if ((uint32_t)(cur >> 32) == key) return (int)(uint32_t)cur;
+    h = (h + 1) & mask;
+  }
+}
+
+// ---- wave / block reductions ---------------------------------------------
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// exclusive prefix of v over the 64 lanes of a wave
+__device__ __forceinline__ int wave_excl_scan(int v, int lane) {
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  return x - v;
+}
+
+// Exclusive scan of one int per thread across a block of BLOCK threads.
+// smem needs BLOCK/64 ints.  Returns the exclusive prefix; *total = block sum.
+template <int BLOCK>
+__device__ __forceinline__ int block_excl_scan(int v, int* smem, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int ex = wave_excl_scan(v, lane);
+  if (lane == 63) smem[w] = ex + v;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < BLOCK / 64; ++i) {
+    int s = smem[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return ex + base;
+}
+
+}  // namespace msmd

@@ -1,0 +1,287 @@
+// dense.hip -- SparseConvTensor.dense() (BEV scatter), sparse_add and the
+// LiDAR / virtual-point modality split.  HBM-bound permutation / set kernels.
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace msmd {
+namespace {
+
+__device__ __forceinline__ uint32_t cell_of(int4 r, const int* s) {
+  return (((uint32_t)r.x * s[0] + r.y) * s[1] + r.z) * s[2] + r.w;
+}
+struct Shape3 {
+  int s[3];
+};
+
+// ---------------------------------------------------------------- dense ----
+// structure.py:55-64 does zero-fill + scatter to [B,D,H,W,C] + a full permute
+// copy to [B,C,D,H,W].  Here: one memset + one kernel that writes channels-first
+// directly.  A block stages 64 rows x C through LDS (row reads are coalesced
+// 16-B loads) and writes with the ROW index fastest: rows are in ascending
+// linear id after a strided conv, so neighbouring rows are neighbouring x and
+// the stores of one channel coalesce.
+constexpr int kDenseRows = 64;
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void dense_kernel(float* __restrict__ feat,
+                                                    const int32_t* __restrict__ idx, int n, int c,
+                                                    Shape3 sh, float* __restrict__ dense) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* tile = (float*)smem_raw;                       // [64][c+1]
+  long* cells = (long*)(tile + kDenseRows * (c + 1) + ((kDenseRows * (c + 1)) & 1));
+  const int r0 = blockIdx.x * kDenseRows;
+  const int nr = (n - r0) < kDenseRows ? (n - r0) : kDenseRows;
+  const long vol = (long)sh.s[0] * sh.s[1] * sh.s[2];
+  if (threadIdx.x < nr) {
+    int4 r = ((const int4*)idx)[r0 + threadIdx.x];
+    long cell = ((long)r.y * sh.s[1] + r.z) * sh.s[2] + r.w;
+    cells[threadIdx.x] = (long)r.x * c * vol + cell;    // offset of channel 0
+  }
+  if (SCATTER) {
+    for (int e = threadIdx.x; e < nr * c; e += 256) {
+      int rr = e / c, cc = e - rr * c;
+      tile[rr * (c + 1) + cc] = feat[(size_t)(r0 + rr) * c + cc];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kDenseRows * c; e += 256) {
+    int cc = e / kDenseRows, rr = e - cc * kDenseRows;   // row fastest
+    if (rr < nr) {
+      float* p = dense + cells[rr] + (long)cc * vol;
+      if (SCATTER) *p = tile[rr * (c + 1) + cc]; else tile[rr * (c + 1) + cc] = *p;
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < nr * c; e += 256) {
+      int rr = e / c, cc = e - rr * c;
+      feat[(size_t)(r0 + rr) * c + cc] = tile[rr * (c + 1) + cc];
+    }
+  }
+}
+
+size_t dense_smem(int c) {
+  size_t fl = (size_t)kDenseRows * (c + 1);
+  fl += fl & 1;
+  return fl * sizeof(float) + kDenseRows * sizeof(long);
+}
+
+// ----------------------------------------------------------- sparse_add ----
+__global__ __launch_bounds__(256) void mark_rows(const int32_t* __restrict__ idx, int n, Shape3 sh,
+                                                 uint32_t* bits) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) bitmap_set(bits, cell_of(((const int4*)idx)[i], sh.s));
+}
+
+__global__ __launch_bounds__(256) void add_rows(const float* __restrict__ feat,
+                                                const int32_t* __restrict__ idx, int n, int c,
+                                                Shape3 sh, const uint32_t* __restrict__ bits,
+                                                const int* __restrict__ prefix, int n_out,
+                                                int32_t* __restrict__ out_idx,
+                                                float* __restrict__ out_feat,
+                                                int32_t* __restrict__ map) {
+  // one wave-quarter (16 lanes) per row: coalesced feature reads
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int i = (int)(t >> 4), sub = (int)(t & 15);
+  if (i >= n) return;
+  int4 r = ((const int4*)idx)[i];
+  int o = bitmap_rank(bits, prefix, cell_of(r, sh.s));
+  if (o >= n_out) return;
+  if (sub == 0) {
+    ((int4*)out_idx)[o] = r;
+    if (map) map[i] = o;
+  }
+  for (int ch = sub; ch < c; ch += 16)
+    unsafeAtomicAdd(&out_feat[(size_t)o * c + ch], feat[(size_t)i * c + ch]);
+}
+
+// ------------------------------------------------------- modality split ----
+__global__ __launch_bounds__(256) void and_words(uint32_t* a, const uint32_t* __restrict__ b,
+                                                 size_t words) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < words) a[i] &= b[i];
+}
+__global__ __launch_bounds__(256) void split_rows(const int32_t* __restrict__ idx, int n,
+                                                  Shape3 sh, const uint32_t* __restrict__ both,
+                                                  const int* __restrict__ prefix, int cap,
+                                                  int32_t* __restrict__ mix,
+                                                  int32_t* __restrict__ pair) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t cell = cell_of(((const int4*)idx)[i], sh.s);
+  int m = bitmap_test(both, cell);
+  mix[i] = m;
+  if (m) {
+    int r = bitmap_rank(both, prefix, cell);
+    if (r < cap) pair[r] = i;
+  }
+}
+
+struct SetWs {
+  uint32_t *bits, *bits2;
+  int *prefix, *tiles;
+  size_t words;
+};
+template <typename A>
+void carve_set(A& a, SetWs* w, int batch, const int* shape, bool two) {
+  size_t cells = (size_t)batch * shape[0] * shape[1] * shape[2];
+  size_t words = (cells + 31) / 32;
+  uint32_t* b0 = a.template take<uint32_t>(words);
+  uint32_t* b1 = two ? a.template take<uint32_t>(words) : nullptr;
+  int* pf = a.template take<int>(words);
+  int* tl = a.template take<int>(scan_num_tiles((long)words) + 1);
+  if (w) *w = SetWs{b0, b1, pf, tl, words};
+}
+
+int check_grid(int batch, const int* shape, Shape3* sh) {
+  if (batch < 1 || !shape) return MSMD_ERR_INVALID_ARG;
+  double cells = batch;
+  for (int i = 0; i < 3; ++i) {
+    if (shape[i] < 1) return MSMD_ERR_INVALID_ARG;
+    sh->s[i] = shape[i];
+    cells *= shape[i];
+  }
+  return cells >= 4294967295.0 ? MSMD_ERR_RANGE : MSMD_OK;
+}
+
+}  // namespace
+}  // namespace msmd
+
+using namespace msmd;
+
+MSMD_EXPORT int msmd_dense_scatter_f32(const float* feat, const int32_t* indices, int n, int c,
+                                       int batch_size, const int* spatial_shape, float* out,
+                                       msmd_stream_t stream) {
+  Shape3 sh;
+  int rc = check_grid(batch_size, spatial_shape, &sh);
+  if (rc) return rc;
+  if (n < 0 || c < 1 || !out || (n > 0 && (!feat || !indices))) return MSMD_ERR_INVALID_ARG;
+  size_t smem = dense_smem(c);
+  if (smem > 160 * 1024) return MSMD_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  size_t bytes = sizeof(float) * (size_t)batch_size * c * sh.s[0] * sh.s[1] * sh.s[2];
+  hipMemsetAsync(out, 0, bytes, st);
+  if (n > 0) {
+    if (smem > 64 * 1024)
+      hipFuncSetAttribute((const void*)dense_kernel<true>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(dense_kernel<true>, dim3(ceil_div(n, kDenseRows)), dim3(256), smem, st,
+                       const_cast<float*>(feat), indices, n, c, sh, out);
+  }
+  return launch_status();
+}
+
+MSMD_EXPORT int msmd_dense_gather_f32(const float* dense, const int32_t* indices, int n, int c,
+                                      int batch_size, const int* spatial_shape, float* feat,
+                                      msmd_stream_t stream) {
+  Shape3 sh;
+  int rc = check_grid(batch_size, spatial_shape, &sh);
+  if (rc) return rc;
+  if (n < 0 || c < 1 || (n > 0 && (!feat || !indices || !dense))) return MSMD_ERR_INVALID_ARG;
+  if (n == 0) return MSMD_OK;
+  size_t smem = dense_smem(c);
+  if (smem > 160 * 1024) return MSMD_ERR_UNSUPPORTED;
+  if (smem > 64 * 1024)
+    hipFuncSetAttribute((const void*)dense_kernel<false>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(dense_kernel<false>, dim3(ceil_div(n, kDenseRows)), dim3(256), smem,
+                     (hipStream_t)stream, feat, indices, n, c, sh, const_cast<float*>(dense));
+  return launch_status();
+}
+
+MSMD_EXPORT size_t msmd_sparse_add_workspace_bytes(int batch_size, const int* spatial_shape) {
+  ArenaSize a;
+  carve_set(a, (SetWs*)nullptr, batch_size, spatial_shape, false);
+  return a.off;
+}
+
+MSMD_EXPORT int msmd_sparse_add_count(const int32_t* idx_a, int n_a, const int32_t* idx_b,
+                                      int n_b, int batch_size, const int* spatial_shape,
+                                      int32_t* n_out, void* workspace, size_t workspace_bytes,
+                                      msmd_stream_t stream) {
+  Shape3 sh;
+  int rc = check_grid(batch_size, spatial_shape, &sh);
+  if (rc) return rc;
+  if (n_a < 0 || n_b < 0 || !n_out) return MSMD_ERR_INVALID_ARG;
+  Arena a(workspace, workspace_bytes);
+  SetWs w;
+  carve_set(a, &w, batch_size, spatial_shape, false);
+  if (!a.ok()) return MSMD_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(w.bits, 0, sizeof(uint32_t) * w.words, st);
+  if (n_a > 0)
+    hipLaunchKernelGGL(mark_rows, dim3(ceil_div(n_a, 256)), dim3(256), 0, st, idx_a, n_a, sh,
+                       w.bits);
+  if (n_b > 0)
+    hipLaunchKernelGGL(mark_rows, dim3(ceil_div(n_b, 256)), dim3(256), 0, st, idx_b, n_b, sh,
+                       w.bits);
+  device_scan(PopcCount{w.bits}, StorePrefix{w.prefix}, (int)w.words, w.tiles, n_out, -1, st);
+  return launch_status();
+}
+
+MSMD_EXPORT int msmd_sparse_add_fill(const float* feat_a, const int32_t* idx_a, int n_a,
+                                     const float* feat_b, const int32_t* idx_b, int n_b, int c,
+                                     int batch_size, const int* spatial_shape, int n_out,
+                                     int32_t* out_indices, float* out_feat, int32_t* map_a,
+                                     int32_t* map_b, void* workspace, size_t workspace_bytes,
+                                     msmd_stream_t stream) {
+  Shape3 sh;
+  int rc = check_grid(batch_size, spatial_shape, &sh);
+  if (rc) return rc;
+  if (n_a < 0 || n_b < 0 || c < 1 || n_out < 0 || (n_out > 0 && (!out_indices || !out_feat)))
+    return MSMD_ERR_INVALID_ARG;
+  Arena a(workspace, workspace_bytes);
+  SetWs w;
+  carve_set(a, &w, batch_size, spatial_shape, false);
+  if (!a.ok()) return MSMD_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_out > 0) hipMemsetAsync(out_feat, 0, sizeof(float) * (size_t)n_out * c, st);
+  if (n_a > 0)
+    hipLaunchKernelGGL(add_rows, dim3(ceil_div((long)n_a * 16, 256)), dim3(256), 0, st, feat_a,
+                       idx_a, n_a, c, sh, w.bits, w.prefix, n_out, out_indices, out_feat, map_a);
+  if (n_b > 0)
+    hipLaunchKernelGGL(add_rows, dim3(ceil_div((long)n_b * 16, 256)), dim3(256), 0, st, feat_b,
+                       idx_b, n_b, c, sh, w.bits, w.prefix, n_out, out_indices, out_feat, map_b);
+  return launch_status();
+}
+
+MSMD_EXPORT size_t msmd_modality_split_workspace_bytes(int batch_size, const int* spatial_shape) {
+  ArenaSize a;
+  carve_set(a, (SetWs*)nullptr, batch_size, spatial_shape, true);
+  return a.off;
+}
+
+MSMD_EXPORT int msmd_modality_split(const int32_t* idx_3d, int n3, const int32_t* idx_2d, int n2,
+                                    int batch_size, const int* spatial_shape, int32_t* mix3d,
+                                    int32_t* mix2d, int32_t* pair_3d, int32_t* pair_2d,
+                                    int32_t* n_mixed, void* workspace, size_t workspace_bytes,
+                                    msmd_stream_t stream) {
+  Shape3 sh;
+  int rc = check_grid(batch_size, spatial_shape, &sh);
+  if (rc) return rc;
+  if (n3 < 0 || n2 < 0 || !n_mixed) return MSMD_ERR_INVALID_ARG;
+  Arena a(workspace, workspace_bytes);
+  SetWs w;
+  carve_set(a, &w, batch_size, spatial_shape, true);
+  if (!a.ok()) return MSMD_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(w.bits, 0, sizeof(uint32_t) * w.words, st);
+  hipMemsetAsync(w.bits2, 0, sizeof(uint32_t) * w.words, st);
+  if (n3 > 0)
+    hipLaunchKernelGGL(mark_rows, dim3(ceil_div(n3, 256)), dim3(256), 0, st, idx_3d, n3, sh,
+                       w.bits);
+  if (n2 > 0)
+    hipLaunchKernelGGL(mark_rows, dim3(ceil_div(n2, 256)), dim3(256), 0, st, idx_2d, n2, sh,
+                       w.bits2);
+  hipLaunchKernelGGL(and_words, dim3(ceil_div((long)w.words, 256)), dim3(256), 0, st, w.bits,
+                     w.bits2, w.words);
+  device_scan(PopcCount{w.bits}, StorePrefix{w.prefix}, (int)w.words, w.tiles, n_mixed, -1, st);
+  const int cap = n3 < n2 ? n3 : n2;
+  if (n3 > 0)
+    hipLaunchKernelGGL(split_rows, dim3(ceil_div(n3, 256)), dim3(256), 0, st, idx_3d, n3, sh,
+                       w.bits, w.prefix, cap, mix3d, pair_3d);
+  if (n2 > 0)
+    hipLaunchKernelGGL(split_rows, dim3(ceil_div(n2, 256)), dim3(256), 0, st, idx_2d, n2, sh,
+                       w.bits, w.prefix, cap, mix2d, pair_2d);
+  return launch_status();
+}

@@ -1,0 +1,303 @@
+// points.hip -- GMA-Conv neighbour-search helpers: furthest point sampling,
+// ball query, brute-force nearest key and the cluster -> member assignment.
+//
+// FPS: one 1024-thread workgroup per batch element (the m-1 rounds are serial
+// by definition); every thread keeps its points AND their running distances
+// in registers (no per-round HBM/LDS traffic at all), the per-round argmax is
+// a 64-bit (distance, tie-order) max reduced with wave shuffles + one LDS hop.
+// The tie order reproduces the reference kernel's block reduction exactly
+// (furthest_point_sample_cuda.cu:17-23,55-137): among equal distances the
+// point with the smallest (k mod block, k) wins, block = opt_n_threads(n).
+#include "common.hpp"
+
+#include <math.h>
+
+namespace msmd {
+namespace {
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int o) {
+  int lo = __shfl_xor((int)(uint32_t)v, o, 64), hi = __shfl_xor((int)(v >> 32), o, 64);
+  return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+// PPT > 0: points per thread held in registers (n <= 1024*PPT).
+// PPT == 0: any n, coordinates and distances streamed from memory each round.
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz, int n, int m,
+                                                   int bs_ref, float* __restrict__ temp,
+                                                   int32_t* __restrict__ idx) {
+  __shared__ unsigned long long red[16];
+  __shared__ int s_old;
+  if (m <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  xyz += (size_t)blockIdx.x * n * 3;
+  temp += (size_t)blockIdx.x * n;
+  idx += (size_t)blockIdx.x * m;
+  constexpr int P = PPT > 0 ? PPT : 1;
+  float px[P], py[P], pz[P], pd[P];
+  if (PPT > 0) {
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+      int k = tid + 1024 * s;
+      bool ok = k < n;
+      px[s] = ok ? xyz[k * 3 + 0] : 0.f;
+      py[s] = ok ? xyz[k * 3 + 1] : 0.f;
+      pz[s] = ok ? xyz[k * 3 + 2] : 0.f;
+      pd[s] = 1e10f;
+    }
+  } else {
+    for (int k = tid; k < n; k += 1024) temp[k] = 1e10f;
+  }
+  int old = 0;
+  if (tid == 0) idx[0] = 0;
+  const int bs_shift = 31 - __clz(bs_ref);  // bs_ref is a power of two
+  for (int j = 1; j < m; ++j) {
+    const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
+    unsigned long long best = 0;
+    auto visit = [&](int k, float d2) {
+      // larger distance first; ties: smaller (k mod bs, k div bs) first
+      uint32_t tb = ((uint32_t)(k & (bs_ref - 1)) << 21) | (uint32_t)(k >> bs_shift);
+      unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (uint32_t)~tb;
+      best = key > best ? key : best;
+    };
+    if (PPT > 0) {
+#pragma unroll
+      for (int s = 0; s < P; ++s) {
+        int k = tid + 1024 * s;
+        if (k < n) {
+          float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
+          float d = dx * dx + dy * dy + dz * dz;
+          float d2 = fminf(d, pd[s]);
+          pd[s] = d2;
+          visit(k, d2);
+        }
+      }
+    } else {
+      for (int k = tid; k < n; k += 1024) {
+        float dx = xyz[k * 3] - x1, dy = xyz[k * 3 + 1] - y1, dz = xyz[k * 3 + 2] - z1;
+        float d = dx * dx + dy * dy + dz * dz;
+        float d2 = fminf(d, temp[k]);
+        temp[k] = d2;
+        visit(k, d2);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long other = shfl_xor_u64(best, o);
+      best = other > best ? other : best;
+    }
+    if (lane == 0) red[wave] = best;
+    __syncthreads();
+    if (wave == 0) {
+      unsigned long long v = lane < 16 ? red[lane] : 0;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        unsigned long long other = shfl_xor_u64(v, o);
+        v = other > v ? other : v;
+      }
+      if (lane == 0) {
+        uint32_t tb = ~(uint32_t)v;
+        int k = (int)((tb & 0x1FFFFFu) << bs_shift) | (int)(tb >> 21);
+        s_old = k;
+        idx[j] = k;
+      }
+    }
+    __syncthreads();
+    old = s_old;
+  }
+}
+
+// One wave per centre; points visited 64 at a time in index order, hits
+// compacted with a ballot so the first `nsample` hits keep their order
+// (ball_query_cuda.cu:33-53).
+__global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ centers,
+                                                         const float* __restrict__ xyz, int n,
+                                                         int m, float min_r2, float max_r2,
+                                                         int nsample, int32_t* __restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (c >= m) return;
+  centers += ((size_t)b * m + c) * 3;
+  xyz += (size_t)b * n * 3;
+  int32_t* out = idx + ((size_t)b * m + c) * nsample;
+  const float cx = centers[0], cy = centers[1], cz = centers[2];
+  int cnt = 0;
+  for (int base = 0; base < n && cnt < nsample; base += 64) {
+    int k = base + lane;
+    bool hit = false;
+    if (k < n) {
+      float x = xyz[k * 3], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
+      float d2 = (cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z);
+      hit = d2 == 0.f || (d2 >= min_r2 && d2 < max_r2);
+    }
+    unsigned long long mask = __ballot(hit);
+    if (mask == 0) continue;
+    if (cnt == 0) {  // first hit pre-fills every slot
+      int first = base + __ffsll((long long)mask) - 1;
+      for (int l = lane; l < nsample; l += 64) out[l] = first;
+    }
+    int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+    if (hit && pos < nsample) out[pos] = k;
+    cnt += __popcll(mask);
+  }
+  if (cnt == 0)  // no hit at all: reference leaves the zero-initialised row
+    for (int l = lane; l < nsample; l += 64) out[l] = 0;
+}
+
+// nearest key: grid (query blocks, key chunks); packed (dist bits, key) min.
+constexpr int kNnChunk = 4096;
+__global__ __launch_bounds__(256) void nn_partial(const int32_t* __restrict__ q, int nq,
+                                                  const int32_t* __restrict__ key, int nk,
+                                                  unsigned long long* best) {
+  __shared__ int ks[1024 * 3];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int k0 = blockIdx.y * kNnChunk;
+  const int k1 = (k0 + kNnChunk) < nk ? (k0 + kNnChunk) : nk;
+  float qz = 0, qy = 0, qx = 0;
+  if (i < nq) {
+    qz = (float)q[i * 3];
+    qy = (float)q[i * 3 + 1];
+    qx = (float)q[i * 3 + 2];
+  }
+  unsigned long long b = kEmptySlot;
+  for (int base = k0; base < k1; base += 1024) {
+    int cnt = (k1 - base) < 1024 ? (k1 - base) : 1024;
+    __syncthreads();
+    for (int e = threadIdx.x; e < cnt * 3; e += 256) ks[e] = key[(size_t)base * 3 + e];
+    __syncthreads();
+    for (int k = 0; k < cnt; ++k) {
+      float dz = qz - (float)ks[k * 3], dy = qy - (float)ks[k * 3 + 1],
+            dx = qx - (float)ks[k * 3 + 2];
+      float d = sqrtf(dz * dz + dy * dy + dx * dx);
+      unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | (uint32_t)(base + k);
+      b = v < b ? v : b;
+    }
+  }
+  if (i < nq) atomicMin(&best[i], b);
+}
+__global__ __launch_bounds__(256) void nn_final(const unsigned long long* __restrict__ best,
+                                                int nq, float thresh, int32_t* __restrict__ out) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nq) return;
+  unsigned long long b = best[i];
+  float d = __uint_as_float((uint32_t)(b >> 32));
+  out[i] = (b != kEmptySlot && d < thresh) ? (int)(uint32_t)b : -1;
+}
+
+__global__ __launch_bounds__(256) void assign_max(const int32_t* __restrict__ group_idx,
+                                                  const int32_t* __restrict__ rep_nn, int m,
+                                                  int nsample, int nq, int32_t* winner) {
+  long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)m * nsample) return;
+  int r = (int)(t / nsample);
+  if (rep_nn[r] < 0) return;
+  int g = group_idx[t];
+  if (g >= 0 && g < nq) atomicMax(&winner[g], r);
+}
+__global__ __launch_bounds__(256) void assign_final(const int32_t* __restrict__ winner,
+                                                    const int32_t* __restrict__ rep_nn, int nq,
+                                                    int32_t* __restrict__ out) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nq) return;
+  int w = winner[i];
+  out[i] = w >= 0 ? rep_nn[w] : -1;
+}
+
+int fps_block_size(int n) {  // opt_n_threads, furthest_point_sample_cuda.cu:11-15
+  int pow_2 = (int)(log((double)n) / log(2.0));
+  int t = 1 << pow_2;
+  if (t > 1024) t = 1024;
+  return t < 1 ? 1 : t;
+}
+
+}  // namespace
+}  // namespace msmd
+
+using namespace msmd;
+
+MSMD_EXPORT int msmd_furthest_point_sample(const float* xyz, int b, int n, int m, float* temp,
+                                           int32_t* idx, msmd_stream_t stream) {
+  if (b < 1 || n < 1 || m < 0 || !xyz || !idx || !temp) return MSMD_ERR_INVALID_ARG;
+  if (m == 0) return MSMD_OK;
+  if (n >= (1 << 21) * 1) return MSMD_ERR_RANGE;
+  hipStream_t st = (hipStream_t)stream;
+  const int bs = fps_block_size(n);
+  const int ppt = ceil_div(n, 1024);
+#define FPS(P) hipLaunchKernelGGL(fps_kernel<P>, dim3(b), dim3(1024), 0, st, xyz, n, m, bs, temp, idx)
+  if (ppt <= 2) FPS(2);
+  else if (ppt <= 4) FPS(4);
+  else if (ppt <= 8) FPS(8);
+  else if (ppt <= 16) FPS(16);
+  else if (ppt <= 24) FPS(24);
+  else FPS(0);
+#undef FPS
+  return launch_status();
+}
+
+MSMD_EXPORT int msmd_ball_query(const float* center_xyz, const float* xyz, int b, int n, int m,
+                                float min_radius, float max_radius, int nsample, int32_t* idx,
+                                msmd_stream_t stream) {
+  if (b < 1 || n < 1 || m < 0 || nsample < 1 || !center_xyz || !xyz || !idx)
+    return MSMD_ERR_INVALID_ARG;
+  if (m == 0) return MSMD_OK;
+  hipLaunchKernelGGL(ball_query_kernel, dim3(ceil_div(m, 4), b), dim3(256), 0,
+                     (hipStream_t)stream, center_xyz, xyz, n, m, min_radius * min_radius,
+                     max_radius * max_radius, nsample, idx);
+  return launch_status();
+}
+
+MSMD_EXPORT int msmd_nn_search(const int32_t* query_zyx, int nq, const int32_t* key_zyx, int nk,
+                               float dist_thresh, int32_t* out_idx, void* scratch,
+                               msmd_stream_t stream) {
+  if (nq < 0 || nk < 0 || (nq > 0 && (!query_zyx || !out_idx || !scratch)))
+    return MSMD_ERR_INVALID_ARG;
+  if (nq == 0) return MSMD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  auto* best = (unsigned long long*)scratch;
+  hipMemsetAsync(best, 0xFF, sizeof(unsigned long long) * nq, st);
+  if (nk > 0)
+    hipLaunchKernelGGL(nn_partial, dim3(ceil_div(nq, 256), ceil_div(nk, kNnChunk)), dim3(256), 0,
+                       st, query_zyx, nq, key_zyx, nk, best);
+  hipLaunchKernelGGL(nn_final, dim3(ceil_div(nq, 256)), dim3(256), 0, st, best, nq, dist_thresh,
+                     out_idx);
+  return launch_status();
+}
+
+MSMD_EXPORT int msmd_nn_assign(const int32_t* group_idx, const int32_t* rep_nn, int m,
+                               int nsample, int nq, int32_t* query_nn, int32_t* scratch,
+                               msmd_stream_t stream) {
+  if (m < 0 || nsample < 1 || nq < 0 || (nq > 0 && (!query_nn || !scratch)))
+    return MSMD_ERR_INVALID_ARG;
+  if (nq == 0) return MSMD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(scratch, 0xFF, sizeof(int32_t) * nq, st);
+  if (m > 0)
+    hipLaunchKernelGGL(assign_max, dim3(ceil_div((long)m * nsample, 256)), dim3(256), 0, st,
+                       group_idx, rep_nn, m, nsample, nq, scratch);
+  hipLaunchKernelGGL(assign_final, dim3(ceil_div(nq, 256)), dim3(256), 0, st, scratch, rep_nn, nq,
+                     query_nn);
+  return launch_status();
+}
+
+// ------------------------------------------------------------- misc API ----
+MSMD_EXPORT const char* msmd_status_string(int status) {
+  switch (status) {
+    case MSMD_OK: return "ok";
+    case MSMD_ERR_INVALID_ARG: return "invalid argument";
+    case MSMD_ERR_WORKSPACE: return "workspace too small or misaligned";
+    case MSMD_ERR_UNSUPPORTED: return "unsupported shape or parameter";
+    case MSMD_ERR_LAUNCH: return "kernel launch failed";
+    case MSMD_ERR_RANGE: return "linear voxel id does not fit 32 bits";
+    default: return "unknown status";
+  }
+}
+MSMD_EXPORT int msmd_abi_version(void) { return 1; }
+MSMD_EXPORT int msmd_device_ok(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return 0;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 0;
+  const char* a = p.gcnArchName;
+  return a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0';
+}

@@ -1,0 +1,324 @@
+// rulebook.hip -- voxel index + rulebook builders for gfx950.
+//
+// Native product: an OUTPUT-STATIONARY neighbour table nbr[K, n_out]
+// (nbr[k][o] = input row that reaches output row o through kernel offset k,
+// or -1).  That is the layout the implicit-GEMM kernels (spconv.hip) consume:
+// one coalesced int32 load per (tile row, offset), no atomics, no scatter.
+// msmd_rulebook_pairs() compacts it to the reference's indicePairs/indiceNum
+// (spconv_ops.h:55-59) for the weight-gradient kernel and for parity checks.
+//
+// SubM (geometry.h:247-297; CUDA indice.cu.h:148-203 uses a dense int32 grid
+// of B*D*H*W cells = 340 MB/sample at 41x1440x1440): a 64-bit-slot hash table
+// of 2N slots (key = linear cell id, value = row), one probe sequence per
+// (output row, offset), writes coalesced along the row axis.
+//
+// Strided (geometry.h:144-194; CUDA indice.cu.h:22-65,112-145 + torch::_unique
+// sort): an occupancy bitmap of the OUTPUT grid (1 bit/cell: 1.4 MB/sample at
+// 21x720x720) + popcount prefix scan.  The rank of a set bit IS the output row
+// in ascending linear id -- the order the reference's CUDA path gets from its
+// sort -- so no sort, no hash and no dedup pass are needed.
+//
+// Everything here is HBM/L2-bound integer work; only dilation 1 is built (all
+// the reference configs use it), anything else returns MSMD_ERR_UNSUPPORTED.
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace msmd {
+namespace {
+
+struct Geom {
+  int shape[3];   // grid the table/bitmap indexes (z,y,x)
+  int ks[3], st[3], pd[3];
+  int kvol;
+};
+
+__device__ __forceinline__ uint32_t cell_id(int b, int z, int y, int x, const int* s) {
+  return (((uint32_t)b * s[0] + z) * s[1] + y) * s[2] + x;
+}
+
+// ---------------------------------------------------------------- SubM ----
+__global__ __launch_bounds__(256) void subm_insert(const int32_t* __restrict__ idx, int n,
+                                                   Geom g, unsigned long long* table, int bits) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  int4 r = ((const int4*)idx)[j];
+  // duplicate coordinates: the CPU reference's grid keeps the LAST row
+  // (geometry.h:277-282) -> keep max(row)
+  hash_insert<true>(table, bits, cell_id(r.x, r.y, r.z, r.w, g.shape), (uint32_t)j);
+}
+
+// thread (o, k): blockIdx.y = kernel offset -> stores of one block are
+// contiguous in nbr[k][*]; the 16-B index row load is coalesced.
+__global__ __launch_bounds__(256) void subm_lookup(const int32_t* __restrict__ idx, int n, Geom g,
+                                                   const unsigned long long* __restrict__ table,
+                                                   int bits, int32_t* __restrict__ nbr) {
+  int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= n) return;
+  const int k = blockIdx.y;
+  const int kx = k % g.ks[2], ky = (k / g.ks[2]) % g.ks[1], kz = k / (g.ks[2] * g.ks[1]);
+  int4 r = ((const int4*)idx)[o];
+  // pair (in, out) sits under offset k when out = in + pad - k (stride 1,
+  // geometry.h:40-44,69): the input of output o is at o - pad + k.
+  int z = r.y - g.pd[0] + kz, y = r.z - g.pd[1] + ky, x = r.w - g.pd[2] + kx;
+  int v = -1;
+  if (z >= 0 && z < g.shape[0] && y >= 0 && y < g.shape[1] && x >= 0 && x < g.shape[2])
+    v = hash_find(table, bits, cell_id(r.x, z, y, x, g.shape));
+  nbr[(size_t)k * n + o] = v;
+}
+
+// ------------------------------------------------------------- strided ----
+// Output position reached from input coordinate c through offset component kc
+// (dilation 1): val = (c + pad - kc) / stride when divisible and in range.
+__device__ __forceinline__ bool out_coord(int c, int kc, int pad, int stride, int lim, int* val) {
+  int t = c + pad - kc;
+  if (t < 0) return false;
+  int q = t / stride;
+  if (q * stride != t || q >= lim) return false;
+  *val = q;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void conv_mark(const int32_t* __restrict__ idx, int n, Geom g,
+                                                 uint32_t* bits) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k = blockIdx.y;
+  const int kx = k % g.ks[2], ky = (k / g.ks[2]) % g.ks[1], kz = k / (g.ks[2] * g.ks[1]);
+  int4 r = ((const int4*)idx)[i];
+  int z, y, x;
+  if (out_coord(r.y, kz, g.pd[0], g.st[0], g.shape[0], &z) &&
+      out_coord(r.z, ky, g.pd[1], g.st[1], g.shape[1], &y) &&
+      out_coord(r.w, kx, g.pd[2], g.st[2], g.shape[2], &x))
+    bitmap_set(bits, cell_id(r.x, z, y, x, g.shape));
+}
+
+__global__ __launch_bounds__(256) void conv_fill(const int32_t* __restrict__ idx, int n, Geom g,
+                                                 const uint32_t* __restrict__ bits,
+                                                 const int* __restrict__ prefix, int n_out,
+                                                 int32_t* __restrict__ out_idx,
+                                                 int32_t* __restrict__ nbr_fwd,
+                                                 int32_t* __restrict__ nbr_bwd) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k = blockIdx.y;
+  const int kx = k % g.ks[2], ky = (k / g.ks[2]) % g.ks[1], kz = k / (g.ks[2] * g.ks[1]);
+  int4 r = ((const int4*)idx)[i];
+  int z, y, x, o = -1;
+  if (out_coord(r.y, kz, g.pd[0], g.st[0], g.shape[0], &z) &&
+      out_coord(r.z, ky, g.pd[1], g.st[1], g.shape[1], &y) &&
+      out_coord(r.w, kx, g.pd[2], g.st[2], g.shape[2], &x)) {
+    o = bitmap_rank(bits, prefix, cell_id(r.x, z, y, x, g.shape));
+    if (o < n_out) {
+      nbr_fwd[(size_t)k * n_out + o] = i;  // (k,o) has exactly one source row
+      ((int4*)out_idx)[o] = make_int4(r.x, z, y, x);  // same value from every writer
+    } else {
+      o = -1;
+    }
+  }
+  if (nbr_bwd) nbr_bwd[(size_t)k * n + i] = o;
+}
+
+// ------------------------------------------------- nbr table -> pair list --
+struct NbrValid {
+  const int32_t* nbr;  // one offset's row
+  __device__ int operator()(int i) const { return nbr[i] >= 0; }
+};
+// Compaction of all K offsets in one launch set: element e = k*n_rows + o.
+// Count/Emit see flat element ids; tiles never straddle offsets because each
+// offset is padded to whole tiles (rows_pad).
+struct PairCount {
+  const int32_t* nbr;
+  int n_rows, rows_pad;
+  __device__ int operator()(int e) const {
+    int k = e / rows_pad, o = e - k * rows_pad;
+    return o < n_rows && nbr[(size_t)k * n_rows + o] >= 0;
+  }
+};
+struct PairEmit {
+  const int32_t* nbr;
+  int n_rows, rows_pad, ld;
+  int32_t* pairs;
+  int* tile_offs;  // exclusive prefix over all (offset,tile) tiles
+  __device__ void operator()(int e, int p, int v) const {
+    if (!v) return;
+    int k = e / rows_pad, o = e - k * rows_pad;
+    int base = tile_offs[k * (rows_pad / kScanTile)];  // first tile of offset k
+    int pos = p - base;
+    if (pos >= ld) return;
+    pairs[((size_t)k * 2 + 0) * ld + pos] = nbr[(size_t)k * n_rows + o];
+    pairs[((size_t)k * 2 + 1) * ld + pos] = o;
+  }
+};
+__global__ void pair_counts(const int* __restrict__ tile_offs, const int* __restrict__ total,
+                            int tiles_per_k, int kvol, int32_t* __restrict__ num) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= kvol) return;
+  int lo = tile_offs[k * tiles_per_k];
+  int hi = k + 1 < kvol ? tile_offs[(k + 1) * tiles_per_k] : *total;
+  num[k] = hi - lo;
+}
+
+int check_geom(const int* shape, const int* ks, const int* st, const int* pd, int batch,
+               Geom* g) {
+  if (!shape || !ks || batch < 1) return MSMD_ERR_INVALID_ARG;
+  double cells = batch;
+  g->kvol = 1;
+  for (int i = 0; i < 3; ++i) {
+    g->shape[i] = shape[i];
+    g->ks[i] = ks[i];
+    g->st[i] = st ? st[i] : 1;
+    g->pd[i] = pd ? pd[i] : ks[i] / 2;  // SubM: spconv_ops.h:76-79
+    if (shape[i] < 1 || ks[i] < 1 || g->st[i] < 1 || g->pd[i] < 0) return MSMD_ERR_INVALID_ARG;
+    cells *= shape[i];
+    g->kvol *= ks[i];
+  }
+  if (g->kvol > 4096) return MSMD_ERR_UNSUPPORTED;  // spconv_ops.h:51
+  if (cells >= 4294967295.0) return MSMD_ERR_RANGE;
+  return MSMD_OK;
+}
+
+}  // namespace
+}  // namespace msmd
+
+using namespace msmd;
+
+// ------------------------------------------------------------------ SubM ---
+MSMD_EXPORT size_t msmd_rulebook_subm_workspace_bytes(int n) {
+  int bits = next_pow2_bits(2L * (n > 0 ? n : 1));
+  if (bits < 6) bits = 6;
+  return align_up(sizeof(unsigned long long) << bits);
+}
+
+MSMD_EXPORT int msmd_rulebook_subm3d(const int32_t* indices, int n, int batch_size,
+                                     const int* spatial_shape, const int* ksize, int32_t* nbr,
+                                     void* workspace, size_t workspace_bytes,
+                                     msmd_stream_t stream) {
+  Geom g;
+  int rc = check_geom(spatial_shape, ksize, nullptr, nullptr, batch_size, &g);
+  if (rc) return rc;
+  if (n < 0 || (n > 0 && (!indices || !nbr))) return MSMD_ERR_INVALID_ARG;
+  if (n == 0) return MSMD_OK;
+  int bits = next_pow2_bits(2L * n);
+  if (bits < 6) bits = 6;
+  if (workspace_bytes < (sizeof(unsigned long long) << bits) || ((uintptr_t)workspace & 255))
+    return MSMD_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  auto* table = (unsigned long long*)workspace;
+  hipMemsetAsync(table, 0xFF, sizeof(unsigned long long) << bits, st);
+  const int nb = ceil_div(n, 256);
+  hipLaunchKernelGGL(subm_insert, dim3(nb), dim3(256), 0, st, indices, n, g, table, bits);
+  hipLaunchKernelGGL(subm_lookup, dim3(nb, g.kvol), dim3(256), 0, st, indices, n, g, table, bits,
+                     nbr);
+  return launch_status();
+}
+
+// --------------------------------------------------------------- strided ---
+namespace {
+struct ConvWs {
+  uint32_t* bits;
+  int* prefix;
+  int* tiles;
+  size_t words;
+};
+template <typename A>
+void carve_conv(A& a, ConvWs* w, int batch, const int* out_shape) {
+  size_t cells = (size_t)batch * out_shape[0] * out_shape[1] * out_shape[2];
+  size_t words = (cells + 31) / 32;
+  uint32_t* b = a.template take<uint32_t>(words);
+  int* p = a.template take<int>(words);
+  int* t = a.template take<int>(scan_num_tiles((long)words) + 1);
+  if (w) *w = ConvWs{b, p, t, words};
+}
+}  // namespace
+
+MSMD_EXPORT size_t msmd_rulebook_conv_workspace_bytes(int batch_size, const int* out_shape) {
+  ArenaSize a;
+  carve_conv(a, (ConvWs*)nullptr, batch_size, out_shape);
+  return a.off;
+}
+
+MSMD_EXPORT int msmd_rulebook_conv3d_count(const int32_t* indices, int n, int batch_size,
+                                           const int* out_shape, const int* ksize,
+                                           const int* stride, const int* padding,
+                                           int32_t* n_out, void* workspace,
+                                           size_t workspace_bytes, msmd_stream_t stream) {
+  Geom g;
+  if (!stride || !padding || !n_out) return MSMD_ERR_INVALID_ARG;
+  int rc = check_geom(out_shape, ksize, stride, padding, batch_size, &g);
+  if (rc) return rc;
+  if (n < 0 || (n > 0 && !indices)) return MSMD_ERR_INVALID_ARG;
+  Arena a(workspace, workspace_bytes);
+  ConvWs w;
+  carve_conv(a, &w, batch_size, out_shape);
+  if (!a.ok()) return MSMD_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(w.bits, 0, sizeof(uint32_t) * w.words, st);
+  if (n > 0)
+    hipLaunchKernelGGL(conv_mark, dim3(ceil_div(n, 256), g.kvol), dim3(256), 0, st, indices, n, g,
+                       w.bits);
+  device_scan(PopcCount{w.bits}, StorePrefix{w.prefix}, (int)w.words, w.tiles, n_out, -1, st);
+  return launch_status();
+}
+
+MSMD_EXPORT int msmd_rulebook_conv3d_fill(const int32_t* indices, int n, int batch_size,
+                                          const int* out_shape, const int* ksize,
+                                          const int* stride, const int* padding, int n_out,
+                                          int32_t* out_indices, int32_t* nbr_fwd,
+                                          int32_t* nbr_bwd, void* workspace,
+                                          size_t workspace_bytes, msmd_stream_t stream) {
+  Geom g;
+  if (!stride || !padding) return MSMD_ERR_INVALID_ARG;
+  int rc = check_geom(out_shape, ksize, stride, padding, batch_size, &g);
+  if (rc) return rc;
+  if (n < 0 || n_out < 0 || (n_out > 0 && (!out_indices || !nbr_fwd)))
+    return MSMD_ERR_INVALID_ARG;
+  Arena a(workspace, workspace_bytes);
+  ConvWs w;
+  carve_conv(a, &w, batch_size, out_shape);
+  if (!a.ok()) return MSMD_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_out > 0) hipMemsetAsync(nbr_fwd, 0xFF, sizeof(int32_t) * (size_t)g.kvol * n_out, st);
+  if (n > 0)
+    hipLaunchKernelGGL(conv_fill, dim3(ceil_div(n, 256), g.kvol), dim3(256), 0, st, indices, n, g,
+                       w.bits, w.prefix, n_out, out_indices, nbr_fwd, nbr_bwd);
+  return launch_status();
+}
+
+// ------------------------------------------------------------ pair lists ---
+namespace {
+inline int rows_padded(int n_rows) { return scan_num_tiles(n_rows > 0 ? n_rows : 1) * kScanTile; }
+}
+
+MSMD_EXPORT size_t msmd_rulebook_pairs_workspace_bytes(int kernel_volume, int n_rows) {
+  ArenaSize a;
+  a.take<int>((size_t)kernel_volume * (rows_padded(n_rows) / kScanTile) + 1);
+  a.take<int>(64);
+  return a.off;
+}
+
+MSMD_EXPORT int msmd_rulebook_pairs(const int32_t* nbr, int kernel_volume, int n_rows,
+                                    int32_t* indice_pairs, int ld, int32_t* indice_num,
+                                    void* workspace, size_t workspace_bytes,
+                                    msmd_stream_t stream) {
+  if (kernel_volume < 1 || n_rows < 0 || ld < 0 || !indice_num ||
+      (n_rows > 0 && (!nbr || !indice_pairs)))
+    return MSMD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int rp = rows_padded(n_rows), tpk = rp / kScanTile;
+  if ((double)kernel_volume * rp >= 2147483647.0) return MSMD_ERR_RANGE;
+  Arena a(workspace, workspace_bytes);
+  int* tiles = a.take<int>((size_t)kernel_volume * tpk + 1);
+  int* total = a.take<int>(64);
+  if (!a.ok()) return MSMD_ERR_WORKSPACE;
+  if (ld > 0)
+    hipMemsetAsync(indice_pairs, 0xFF, sizeof(int32_t) * (size_t)kernel_volume * 2 * ld, st);
+  if (n_rows == 0) {
+    hipMemsetAsync(indice_num, 0, sizeof(int32_t) * kernel_volume, st);
+    return launch_status();
+  }
+  device_scan(PairCount{nbr, n_rows, rp}, PairEmit{nbr, n_rows, rp, ld, indice_pairs, tiles},
+              kernel_volume * rp, tiles, total, -1, st);
+  hipLaunchKernelGGL(pair_counts, dim3(ceil_div(kernel_volume, 64)), dim3(64), 0, st, tiles, total,
+                     tpk, kernel_volume, indice_num);
+  return launch_status();
+}

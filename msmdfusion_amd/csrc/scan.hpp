@@ -1,0 +1,114 @@
+// scan.hpp -- device-wide exclusive prefix sum in three small kernels
+// (tile sums -> single-block scan of tile sums -> apply), generic over where
+// the per-element count comes from and what is done with the prefix.
+//   Count: int operator()(int i) const          -- value of element i
+//   Emit : void operator()(int i, int prefix, int value) const
+// Used for: popcount ranks of occupancy bitmaps (strided rulebook,
+// sparse_add, modality split), first-point flags (voxelization) and per-offset
+// pair compaction.  All HBM-bound streaming passes with coalesced access.
+#pragma once
+#include "common.hpp"
+
+namespace msmd {
+
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanBlock * kScanItems;
+
+inline int scan_num_tiles(long n) { return ceil_div(n, kScanTile); }
+
+template <typename Count>
+__global__ __launch_bounds__(kScanBlock) void scan_tile_sums(Count count, int n,
+                                                             int* __restrict__ tile_sums) {
+  __shared__ int smem[kScanBlock / 64];
+  const int base = blockIdx.x * kScanTile;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    int i = base + j * kScanBlock + threadIdx.x;  // coalesced
+    if (i < n) s += count(i);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int i = 0; i < kScanBlock / 64; ++i) t += smem[i];
+    tile_sums[blockIdx.x] = t;
+  }
+}
+
+// One block: in-place exclusive scan of tile_sums[0..ntiles), total -> *total
+// (optionally clamped to `clamp` when clamp >= 0).
+static __global__ __launch_bounds__(1024) void scan_tiles_top(int* __restrict__ tile_sums, int ntiles,
+                                                       int* __restrict__ total, int clamp) {
+  __shared__ int smem[1024 / 64];
+  int carry = 0;
+  for (int base = 0; base < ntiles; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = i < ntiles ? tile_sums[i] : 0;
+    int tot;
+    int ex = block_excl_scan<1024>(v, smem, &tot);
+    if (i < ntiles) tile_sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total) *total = (clamp >= 0 && carry > clamp) ? clamp : carry;
+}
+
+template <typename Count, typename Emit>
+__global__ __launch_bounds__(kScanBlock) void scan_apply(Count count, Emit emit, int n,
+                                                         const int* __restrict__ tile_offs) {
+  __shared__ int smem[kScanBlock / 64];
+  const int base = blockIdx.x * kScanTile;
+  int carry = tile_offs[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    int i = base + j * kScanBlock + threadIdx.x;
+    int v = i < n ? count(i) : 0;
+    int tot;
+    int ex = block_excl_scan<kScanBlock>(v, smem, &tot);
+    if (i < n) emit(i, carry + ex, v);
+    carry += tot;
+  }
+}
+
+// Host driver.  tile_sums: scratch of scan_num_tiles(n) ints.
+template <typename Count, typename Emit>
+inline void device_scan(Count count, Emit emit, int n, int* tile_sums, int* total, int clamp,
+                        hipStream_t st) {
+  const int nt = scan_num_tiles(n);
+  if (nt == 0) {
+    hipLaunchKernelGGL(scan_tiles_top, dim3(1), dim3(1024), 0, st, tile_sums, 0, total, clamp);
+    return;
+  }
+  hipLaunchKernelGGL(scan_tile_sums<Count>, dim3(nt), dim3(kScanBlock), 0, st, count, n,
+                     tile_sums);
+  hipLaunchKernelGGL(scan_tiles_top, dim3(1), dim3(1024), 0, st, tile_sums, nt, total, clamp);
+  hipLaunchKernelGGL((scan_apply<Count, Emit>), dim3(nt), dim3(kScanBlock), 0, st, count, emit, n,
+                     tile_sums);
+}
+
+// ---- occupancy bitmap + popcount rank ---------------------------------------
+// A set of 32-bit cell ids in [0, cells) is a bitmap of ceil(cells/32) words;
+// after device_scan(PopcCount, StorePrefix) the row of a present cell, in
+// ascending cell order, is prefix[cell>>5] + popc(bits[cell>>5] & low mask).
+struct PopcCount {
+  const uint32_t* bits;
+  __device__ int operator()(int i) const { return __popc(bits[i]); }
+};
+struct StorePrefix {
+  int* prefix;
+  __device__ void operator()(int i, int p, int) const { prefix[i] = p; }
+};
+__device__ __forceinline__ void bitmap_set(uint32_t* bits, uint32_t cell) {
+  atomicOr(&bits[cell >> 5], 1u << (cell & 31));
+}
+__device__ __forceinline__ bool bitmap_test(const uint32_t* __restrict__ bits, uint32_t cell) {
+  return (bits[cell >> 5] >> (cell & 31)) & 1u;
+}
+__device__ __forceinline__ int bitmap_rank(const uint32_t* __restrict__ bits,
+                                           const int* __restrict__ prefix, uint32_t cell) {
+  return prefix[cell >> 5] + __popc(bits[cell >> 5] & ((1u << (cell & 31)) - 1u));
+}
+
+}  // namespace msmd

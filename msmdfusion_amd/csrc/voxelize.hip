@@ -1,0 +1,266 @@
+// voxelize.hip -- hard voxelization (+ fused mean VFE) for gfx950.
+//
+// Replaces hard_voxelize_gpu (mmdet3d/ops/voxel/src/voxelization_cuda.cu:184-326:
+// an O(N^2) predecessor scan, a <<<1,1>>> serial loop and four device syncs)
+// with an order-exact parallel formulation of hard_voxelize_cpu's loop
+// (mmdet3d/ops/voxel/src/voxelization_cpu.cpp:68-96):
+//
+//   1. key[i]   = linear cell of point i (float32 floor((p-min)/size), same
+//                 operation order as voxelization_cpu.cpp:23), inserted into a
+//                 64-bit-slot hash table keeping min(point index) per cell
+//                 -> the voxel's first point.
+//   2. flag[i]  = point i is the first point of its voxel; an exclusive scan
+//                 of the flags in point order is the first-appearance voxel id.
+//   3. i*       = the first point whose voxel id == max_voxels: the reference
+//                 loop breaks there, so every point >= i* is dropped.
+//   4. slot of a point = number of earlier same-voxel points: slot 0 is the
+//                 first point; slot r is found by round r of "smallest point
+//                 index above the previous winner" (atomicMin per voxel),
+//                 max_points-1 rounds of a streaming pass.
+//   5. gather: voxel-stationary, writes rows [0, voxel_num) only, padding
+//                 slots zero-filled in the same pass (the reference memsets
+//                 max_voxels*max_points*C floats per call, voxelize.py:46-50),
+//                 optionally reducing straight to the mean (HardSimpleVFE).
+//
+// All passes are HBM-bound integer work with coalesced reads; no host sync.
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace msmd {
+namespace {
+
+constexpr uint32_t kNoCell = 0xFFFFFFFFu;
+constexpr int kNoPoint = 0x7F7F7F7F;  // hipMemsetAsync(0x7F) pattern
+
+struct VoxGeom {
+  float vs[3], lo[3];
+  int grid[3];  // x,y,z
+};
+
+__global__ __launch_bounds__(256) void vox_insert(const float* __restrict__ points, int n, int c,
+                                                  VoxGeom g, uint32_t* __restrict__ key,
+                                                  uint32_t* __restrict__ slot,
+                                                  unsigned long long* table, int bits) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* p = points + (size_t)i * c;
+  int q[3];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    int v = (int)floorf((p[j] - g.lo[j]) / g.vs[j]);
+    if (v < 0 || v >= g.grid[j]) ok = false;
+    q[j] = v;
+  }
+  uint32_t k = kNoCell, s = 0;
+  if (ok) {
+    k = ((uint32_t)q[2] * g.grid[1] + q[1]) * g.grid[0] + q[0];
+    s = hash_insert<false>(table, bits, k, (uint32_t)i);
+  }
+  key[i] = k;
+  slot[i] = s;
+}
+
+struct FirstFlag {  // 1 when point i is the first point of its cell
+  const uint32_t* key;
+  const uint32_t* slot;
+  const unsigned long long* table;
+  __device__ int operator()(int i) const {
+    return key[i] != kNoCell && (uint32_t)table[slot[i]] == (uint32_t)i;
+  }
+};
+struct RankEmit {  // rank[i] = voxel id if first point; records i* (step 3)
+  int* rank;
+  int* istar;
+  int max_voxels;
+  __device__ void operator()(int i, int p, int v) const {
+    rank[i] = p;
+    if (v && p == max_voxels) *istar = i;
+  }
+};
+
+// step 4, round 0 + coordinates: every kept point learns its voxel id.
+__global__ __launch_bounds__(256) void vox_assign(int n, VoxGeom g,
+                                                  const uint32_t* __restrict__ key,
+                                                  const uint32_t* __restrict__ slot,
+                                                  const unsigned long long* __restrict__ table,
+                                                  const int* __restrict__ rank,
+                                                  const int* __restrict__ istar,
+                                                  int* __restrict__ pv, int* __restrict__ win,
+                                                  int max_points, int32_t* __restrict__ coors) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k = key[i];
+  int v = -1;
+  if (k != kNoCell && i < *istar) {
+    int first = (int)(uint32_t)table[slot[i]];
+    v = rank[first];
+    if (first == i) {
+      win[(size_t)v * max_points] = i;
+      int x = k % g.grid[0];
+      int y = (k / g.grid[0]) % g.grid[1];
+      int z = k / (g.grid[0] * g.grid[1]);
+      coors[(size_t)v * 3 + 0] = z;
+      coors[(size_t)v * 3 + 1] = y;
+      coors[(size_t)v * 3 + 2] = x;
+    }
+  }
+  pv[i] = v;
+}
+
+// step 4, round r >= 1.
+__global__ __launch_bounds__(256) void vox_round(int n, const int* __restrict__ pv, int* win,
+                                                 int max_points, int r) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int v = pv[i];
+  if (v < 0) return;
+  int* w = win + (size_t)v * max_points;
+  if (i > w[r - 1]) atomicMin(&w[r], i);
+}
+
+// step 5: one thread per (voxel, channel); slots walked in order.
+__global__ __launch_bounds__(256) void vox_gather(const float* __restrict__ points, int c,
+                                                  const int* __restrict__ win, int max_points,
+                                                  const int* __restrict__ voxel_num,
+                                                  float* __restrict__ voxels,
+                                                  int32_t* __restrict__ num_points,
+                                                  float* __restrict__ mean) {
+  const long total = (long)(*voxel_num) * c;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    int v = (int)(t / c), ch = (int)(t % c);
+    const int* w = win + (size_t)v * max_points;
+    float sum = 0.f;
+    int cnt = 0;
+    for (int s = 0; s < max_points; ++s) {
+      int src = w[s];
+      float val = 0.f;
+      if (src != kNoPoint) {
+        val = points[(size_t)src * c + ch];
+        ++cnt;
+      }
+      if (voxels) voxels[((size_t)v * max_points + s) * c + ch] = val;
+      sum += val;
+    }
+    if (mean) mean[(size_t)v * c + ch] = sum / (float)cnt;
+    if (ch == 0) num_points[v] = cnt;
+  }
+}
+
+__global__ void vox_init_scalars(int* istar, int n) { *istar = n; }
+
+struct VoxWs {
+  uint32_t *key, *slot;
+  int *rank, *pv, *win, *tiles, *istar;
+  unsigned long long* table;
+  int bits;
+};
+
+template <typename A>
+void carve(A& a, VoxWs* w, int n, int max_voxels, int max_points) {
+  int bits = next_pow2_bits(2L * (n > 0 ? n : 1));
+  if (bits < 6) bits = 6;
+  if (w) w->bits = bits;
+#define TAKE(field, T, cnt)              \
+  {                                      \
+    T* p_ = a.template take<T>(cnt);     \
+    if (w) w->field = p_;                \
+  }
+  TAKE(key, uint32_t, n);
+  TAKE(slot, uint32_t, n);
+  TAKE(rank, int, n);
+  TAKE(pv, int, n);
+  TAKE(win, int, (size_t)max_voxels * max_points);
+  TAKE(tiles, int, scan_num_tiles(n) + 1);
+  TAKE(istar, int, 64);
+  TAKE(table, unsigned long long, (size_t)1 << bits);
+#undef TAKE
+}
+
+}  // namespace
+}  // namespace msmd
+
+using namespace msmd;
+
+MSMD_EXPORT size_t msmd_voxelize_workspace_bytes(int num_points, int max_voxels, int max_points) {
+  ArenaSize a;
+  carve(a, (VoxWs*)nullptr, num_points, max_voxels, max_points);
+  return a.off;
+}
+
+MSMD_EXPORT int msmd_hard_voxelize(const float* points, int num_points, int num_features,
+                                   const float* voxel_size, const float* coors_range,
+                                   int max_points, int max_voxels, float* voxels,
+                                   int32_t* coors, int32_t* num_points_per_voxel,
+                                   float* voxel_mean, int32_t* voxel_num, void* workspace,
+                                   size_t workspace_bytes, msmd_stream_t stream) {
+  if (num_points < 0 || num_features < 3 || max_points < 1 || max_voxels < 1 || !coors ||
+      !num_points_per_voxel || !voxel_num || !voxel_size || !coors_range ||
+      (num_points > 0 && !points))
+    return MSMD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  VoxGeom g;
+  double cells = 1;
+  for (int i = 0; i < 3; ++i) {
+    g.vs[i] = voxel_size[i];
+    g.lo[i] = coors_range[i];
+    // voxelization_cpu.cpp:119-122 -- round() of the float quotient
+    g.grid[i] = (int)roundf((coors_range[3 + i] - coors_range[i]) / voxel_size[i]);
+    if (g.grid[i] < 1) return MSMD_ERR_INVALID_ARG;
+    cells *= g.grid[i];
+  }
+  if (cells >= 4294967295.0) return MSMD_ERR_RANGE;
+  Arena a(workspace, workspace_bytes);
+  VoxWs w;
+  carve(a, &w, num_points, max_voxels, max_points);
+  if (!a.ok()) return MSMD_ERR_WORKSPACE;
+
+  const int n = num_points;
+  hipMemsetAsync(w.table, 0xFF, sizeof(unsigned long long) << w.bits, st);
+  hipMemsetAsync(w.win, 0x7F, sizeof(int) * (size_t)max_voxels * max_points, st);
+  hipLaunchKernelGGL(vox_init_scalars, dim3(1), dim3(1), 0, st, w.istar, n);
+  const int nb = ceil_div(n, 256);
+  if (n > 0)
+    hipLaunchKernelGGL(vox_insert, dim3(nb), dim3(256), 0, st, points, n, num_features, g, w.key,
+                       w.slot, w.table, w.bits);
+  device_scan(FirstFlag{w.key, w.slot, w.table}, RankEmit{w.rank, w.istar, max_voxels}, n,
+              w.tiles, voxel_num, max_voxels, st);
+  if (n > 0) {
+    hipLaunchKernelGGL(vox_assign, dim3(nb), dim3(256), 0, st, n, g, w.key, w.slot, w.table,
+                       w.rank, w.istar, w.pv, w.win, max_points, coors);
+    for (int r = 1; r < max_points; ++r)
+      hipLaunchKernelGGL(vox_round, dim3(nb), dim3(256), 0, st, n, w.pv, w.win, max_points, r);
+  }
+  long work = (long)max_voxels * num_features;
+  int gb = ceil_div(work, 256);
+  if (gb > 4096) gb = 4096;
+  hipLaunchKernelGGL(vox_gather, dim3(gb), dim3(256), 0, st, points, num_features, w.win,
+                     max_points, voxel_num, voxels, num_points_per_voxel, voxel_mean);
+  return launch_status();
+}
+
+namespace {
+__global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict__ voxels,
+                                                         const int32_t* __restrict__ npv, int m,
+                                                         int mp, int c, int oc,
+                                                         float* __restrict__ out) {
+  long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)m * oc) return;
+  int v = (int)(t / oc), ch = (int)(t % oc);
+  float s = 0.f;
+  for (int p = 0; p < mp; ++p) s += voxels[((size_t)v * mp + p) * c + ch];
+  out[t] = s / (float)npv[v];
+}
+}  // namespace
+
+MSMD_EXPORT int msmd_voxel_mean(const float* voxels, const int32_t* num_points_per_voxel,
+                                int num_voxels, int max_points, int num_features,
+                                int out_features, float* out, msmd_stream_t stream) {
+  if (num_voxels < 0 || out_features > num_features || out_features < 1)
+    return MSMD_ERR_INVALID_ARG;
+  if (num_voxels == 0) return MSMD_OK;
+  hipLaunchKernelGGL(voxel_mean_kernel, dim3(ceil_div((long)num_voxels * out_features, 256)),
+                     dim3(256), 0, (hipStream_t)stream, voxels, num_points_per_voxel, num_voxels,
+                     max_points, num_features, out_features, out);
+  return launch_status();
+}

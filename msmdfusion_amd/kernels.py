@@ -1,0 +1,299 @@
+"""Tensor-level wrappers over the C ABI (include/msmd_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every
+computation is a call into libmsmd_hip.so on torch's current stream.  All
+functions require CUDA (ROCm) tensors and raise otherwise -- no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import check, float_arr, int3, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("msmdfusion_amd kernels need CUDA/ROCm tensors "
+                               "(there is no CPU fallback)")
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _expand3(v):
+    return [int(v)] * 3 if isinstance(v, int) else [int(x) for x in v]
+
+
+def kernel_volume(ksize):
+    k = _expand3(ksize)
+    return k[0] * k[1] * k[2]
+
+
+# ------------------------------------------------------------------ voxelization
+def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels,
+                  want_voxels=True, want_mean=False):
+    """voxel_layer.hard_voxelize (mmdet3d/ops/voxel/src/voxelization.h:51-69).
+
+    Returns (voxels[M,max_points,C] | None, coors[M,3], num_points[M],
+    mean[M,C] | None).  One host read (the voxel count), like the reference.
+    """
+    _need_cuda(points)
+    pts = points.contiguous().float()
+    n, c = pts.shape
+    dev = pts.device
+    voxels = torch.empty((max_voxels, max_points, c), dtype=torch.float32, device=dev) \
+        if want_voxels else None
+    mean = torch.empty((max_voxels, c), dtype=torch.float32, device=dev) if want_mean else None
+    coors = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
+    npv = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    nbytes = lib.msmd_voxelize_workspace_bytes(n, max_voxels, max_points)
+    ws = _ws(nbytes, dev)
+    check(lib.msmd_hard_voxelize(_p(pts), n, c, float_arr(voxel_size), float_arr(coors_range),
+                                 int(max_points), int(max_voxels), _p(voxels), _p(coors), _p(npv),
+                                 _p(mean), _p(count), _p(ws), nbytes, _stream()),
+          "msmd_hard_voxelize")
+    m = int(count.item())
+    return (voxels[:m] if want_voxels else None, coors[:m], npv[:m],
+            mean[:m] if want_mean else None)
+
+
+def voxel_mean(voxels, num_points, out_features=None):
+    _need_cuda(voxels, num_points)
+    v = voxels.contiguous().float()
+    m, mp, c = v.shape
+    of = c if out_features is None else int(out_features)
+    out = torch.empty((m, of), dtype=torch.float32, device=v.device)
+    check(lib.msmd_voxel_mean(_p(v), _p(num_points.contiguous().int()), m, mp, c, of, _p(out),
+                              _stream()), "msmd_voxel_mean")
+    return out
+
+
+# ------------------------------------------------------------------ rulebooks
+def conv_output_size(in_shape, ksize, stride, padding, dilation=(1, 1, 1)):
+    """mmdet3d/ops/spconv/ops.py:20-30."""
+    return [(in_shape[i] + 2 * padding[i] - dilation[i] * (ksize[i] - 1) - 1) // stride[i] + 1
+            for i in range(3)]
+
+
+def rulebook_subm(indices, batch_size, spatial_shape, ksize):
+    """-> nbr[K,N] int32 (output-stationary neighbour table)."""
+    _need_cuda(indices)
+    idx = indices.contiguous().int()
+    n = idx.shape[0]
+    ks = _expand3(ksize)
+    nbr = torch.empty((kernel_volume(ks), n), dtype=torch.int32, device=idx.device)
+    nbytes = lib.msmd_rulebook_subm_workspace_bytes(n)
+    ws = _ws(nbytes, idx.device)
+    check(lib.msmd_rulebook_subm3d(_p(idx), n, int(batch_size), int3(spatial_shape), int3(ks),
+                                   _p(nbr), _p(ws), nbytes, _stream()), "msmd_rulebook_subm3d")
+    return nbr
+
+
+def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, need_bwd=True):
+    """-> (out_indices[M,4], nbr_fwd[K,M], nbr_bwd[K,N] | None, out_shape)"""
+    _need_cuda(indices)
+    idx = indices.contiguous().int()
+    n = idx.shape[0]
+    dev = idx.device
+    ks, st, pd = _expand3(ksize), _expand3(stride), _expand3(padding)
+    out_shape = conv_output_size(list(spatial_shape), ks, st, pd)
+    kvol = kernel_volume(ks)
+    nbytes = lib.msmd_rulebook_conv_workspace_bytes(int(batch_size), int3(out_shape))
+    ws = _ws(nbytes, dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    check(lib.msmd_rulebook_conv3d_count(_p(idx), n, int(batch_size), int3(out_shape), int3(ks),
+                                         int3(st), int3(pd), _p(count), _p(ws), nbytes, _stream()),
+          "msmd_rulebook_conv3d_count")
+    m = int(count.item())
+    out_idx = torch.empty((m, 4), dtype=torch.int32, device=dev)
+    nbr_fwd = torch.empty((kvol, m), dtype=torch.int32, device=dev)
+    nbr_bwd = torch.empty((kvol, n), dtype=torch.int32, device=dev) if need_bwd else None
+    check(lib.msmd_rulebook_conv3d_fill(_p(idx), n, int(batch_size), int3(out_shape), int3(ks),
+                                        int3(st), int3(pd), m, _p(out_idx), _p(nbr_fwd),
+                                        _p(nbr_bwd), _p(ws), nbytes, _stream()),
+          "msmd_rulebook_conv3d_fill")
+    return out_idx, nbr_fwd, nbr_bwd, out_shape
+
+
+def rulebook_pairs(nbr, ld=None):
+    """nbr[K,M] -> (indice_pairs[K,2,ld], indice_num[K]): the reference's
+    rulebook format (spconv_ops.h:55-59), pairs sorted by output row."""
+    _need_cuda(nbr)
+    kvol, m = nbr.shape
+    ld = m if ld is None else int(ld)
+    dev = nbr.device
+    pairs = torch.empty((kvol, 2, ld), dtype=torch.int32, device=dev)
+    num = torch.empty((kvol,), dtype=torch.int32, device=dev)
+    nbytes = lib.msmd_rulebook_pairs_workspace_bytes(kvol, m)
+    ws = _ws(nbytes, dev)
+    check(lib.msmd_rulebook_pairs(_p(nbr.contiguous()), kvol, m, _p(pairs), ld, _p(num), _p(ws),
+                                  nbytes, _stream()), "msmd_rulebook_pairs")
+    return pairs, num
+
+
+# ------------------------------------------------------------------ convolution
+def pack_weight(weight_kio, transpose=False):
+    """weight [K,Cin,Cout] fp32 -> MFMA-fragment order (see spconv.hip)."""
+    _need_cuda(weight_kio)
+    w = weight_kio.contiguous().float()
+    kvol, cin, cout = w.shape
+    packed = torch.empty((lib.msmd_spconv_packed_weight_elems(kvol, cin, cout),),
+                         dtype=torch.float32, device=w.device)
+    check(lib.msmd_spconv_pack_weight(_p(w), kvol, cin, cout, int(bool(transpose)), _p(packed),
+                                      _stream()), "msmd_spconv_pack_weight")
+    return packed
+
+
+def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False):
+    """out[o] = sum_k feat[nbr[k,o]] @ W[k]  (implicit GEMM on MFMA)."""
+    _need_cuda(feat, packed_weight, nbr)
+    f = feat.contiguous().float()
+    n_in, c_in = f.shape
+    kvol, ld = nbr.shape
+    out = torch.empty((n_out, c_out), dtype=torch.float32, device=f.device)
+    check(lib.msmd_spconv_fwd_f32(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld, int(n_out),
+                                  kvol, int(bool(weight_flip)), _p(out), int(c_out), _stream()),
+          "msmd_spconv_fwd_f32")
+    return out
+
+
+def conv_wgrad(feat, d_out, pairs, num):
+    """dW[K,Cin,Cout] from the compact pair lists."""
+    _need_cuda(feat, d_out, pairs, num)
+    f, g = feat.contiguous().float(), d_out.contiguous().float()
+    kvol, _, ld = pairs.shape
+    c_in, c_out = f.shape[1], g.shape[1]
+    dw = torch.empty((kvol, c_in, c_out), dtype=torch.float32, device=f.device)
+    nbytes = lib.msmd_spconv_wgrad_workspace_bytes(kvol, ld, c_in, c_out)
+    ws = _ws(nbytes, f.device)
+    check(lib.msmd_spconv_wgrad_f32(_p(f), c_in, _p(g), c_out, _p(pairs), _p(num), ld, kvol,
+                                    _p(dw), _p(ws), nbytes, _stream()), "msmd_spconv_wgrad_f32")
+    return dw
+
+
+# ------------------------------------------------------------------ dense / sets
+def dense_scatter(feat, indices, batch_size, spatial_shape):
+    _need_cuda(feat, indices)
+    f = feat.contiguous().float()
+    n, c = f.shape
+    d, h, w = [int(x) for x in spatial_shape]
+    out = torch.empty((int(batch_size), c, d, h, w), dtype=torch.float32, device=f.device)
+    check(lib.msmd_dense_scatter_f32(_p(f), _p(indices.contiguous().int()), n, c, int(batch_size),
+                                     int3(spatial_shape), _p(out), _stream()),
+          "msmd_dense_scatter_f32")
+    return out
+
+
+def dense_gather(dense, indices, spatial_shape):
+    _need_cuda(dense, indices)
+    dn = dense.contiguous().float()
+    b, c = dn.shape[0], dn.shape[1]
+    n = indices.shape[0]
+    feat = torch.empty((n, c), dtype=torch.float32, device=dn.device)
+    check(lib.msmd_dense_gather_f32(_p(dn), _p(indices.contiguous().int()), n, c, b,
+                                    int3(spatial_shape), _p(feat), _stream()),
+          "msmd_dense_gather_f32")
+    return feat
+
+
+def sparse_add(feat_a, idx_a, feat_b, idx_b, batch_size, spatial_shape):
+    """-> (out_indices, out_feat, map_a, map_b)"""
+    _need_cuda(feat_a, idx_a, feat_b, idx_b)
+    fa, fb = feat_a.contiguous().float(), feat_b.contiguous().float()
+    ia, ib = idx_a.contiguous().int(), idx_b.contiguous().int()
+    na, nb, c = fa.shape[0], fb.shape[0], fa.shape[1]
+    dev = fa.device
+    nbytes = lib.msmd_sparse_add_workspace_bytes(int(batch_size), int3(spatial_shape))
+    ws = _ws(nbytes, dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    check(lib.msmd_sparse_add_count(_p(ia), na, _p(ib), nb, int(batch_size), int3(spatial_shape),
+                                    _p(count), _p(ws), nbytes, _stream()), "msmd_sparse_add_count")
+    m = int(count.item())
+    oi = torch.empty((m, 4), dtype=torch.int32, device=dev)
+    of = torch.empty((m, c), dtype=torch.float32, device=dev)
+    ma = torch.empty((na,), dtype=torch.int32, device=dev)
+    mb = torch.empty((nb,), dtype=torch.int32, device=dev)
+    check(lib.msmd_sparse_add_fill(_p(fa), _p(ia), na, _p(fb), _p(ib), nb, c, int(batch_size),
+                                   int3(spatial_shape), m, _p(oi), _p(of), _p(ma), _p(mb), _p(ws),
+                                   nbytes, _stream()), "msmd_sparse_add_fill")
+    return oi, of, ma, mb
+
+
+def modality_split(idx_3d, idx_2d, batch_size, spatial_shape):
+    """-> (mix3d[n3], mix2d[n2], pair_3d[m], pair_2d[m])"""
+    _need_cuda(idx_3d, idx_2d)
+    a, b = idx_3d.contiguous().int(), idx_2d.contiguous().int()
+    n3, n2 = a.shape[0], b.shape[0]
+    dev = a.device
+    cap = max(min(n3, n2), 1)
+    mix3 = torch.empty((n3,), dtype=torch.int32, device=dev)
+    mix2 = torch.empty((n2,), dtype=torch.int32, device=dev)
+    p3 = torch.empty((cap,), dtype=torch.int32, device=dev)
+    p2 = torch.empty((cap,), dtype=torch.int32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    nbytes = lib.msmd_modality_split_workspace_bytes(int(batch_size), int3(spatial_shape))
+    ws = _ws(nbytes, dev)
+    check(lib.msmd_modality_split(_p(a), n3, _p(b), n2, int(batch_size), int3(spatial_shape),
+                                  _p(mix3), _p(mix2), _p(p3), _p(p2), _p(count), _p(ws), nbytes,
+                                  _stream()), "msmd_modality_split")
+    m = int(count.item())
+    return mix3, mix2, p3[:m], p2[:m]
+
+
+# ------------------------------------------------------------------ GMA-Conv helpers
+def furthest_point_sample(points_xyz, num_points):
+    """mmdet3d/ops/furthest_point_sample/furthest_point_sample.py:14-35."""
+    _need_cuda(points_xyz)
+    x = points_xyz.contiguous().float()
+    b, n, _ = x.shape
+    out = torch.empty((b, num_points), dtype=torch.int32, device=x.device)
+    tmp = torch.empty((b, n), dtype=torch.float32, device=x.device)
+    check(lib.msmd_furthest_point_sample(_p(x), b, n, int(num_points), _p(tmp), _p(out),
+                                         _stream()), "msmd_furthest_point_sample")
+    return out
+
+
+def ball_query(min_radius, max_radius, sample_num, xyz, center_xyz):
+    """mmdet3d/ops/ball_query/ball_query.py:14-40 (same argument order)."""
+    _need_cuda(xyz, center_xyz)
+    assert min_radius < max_radius
+    x, cx = xyz.contiguous().float(), center_xyz.contiguous().float()
+    b, n, _ = x.shape
+    m = cx.shape[1]
+    idx = torch.empty((b, m, int(sample_num)), dtype=torch.int32, device=x.device)
+    check(lib.msmd_ball_query(_p(cx), _p(x), b, n, m, float(min_radius), float(max_radius),
+                              int(sample_num), _p(idx), _stream()), "msmd_ball_query")
+    return idx
+
+
+def nn_search(query_zyx, key_zyx, dist_thresh):
+    _need_cuda(query_zyx, key_zyx)
+    q, k = query_zyx.contiguous().int(), key_zyx.contiguous().int()
+    nq, nk = q.shape[0], k.shape[0]
+    out = torch.empty((nq,), dtype=torch.int32, device=q.device)
+    scratch = torch.empty((max(nq, 1),), dtype=torch.int64, device=q.device)
+    check(lib.msmd_nn_search(_p(q), nq, _p(k), nk, float(dist_thresh), _p(out), _p(scratch),
+                             _stream()), "msmd_nn_search")
+    return out
+
+
+def nn_assign(group_idx, rep_nn, nq):
+    _need_cuda(group_idx, rep_nn)
+    g, r = group_idx.contiguous().int(), rep_nn.contiguous().int()
+    m, ns = g.shape
+    out = torch.empty((nq,), dtype=torch.int32, device=g.device)
+    scratch = torch.empty((max(nq, 1),), dtype=torch.int32, device=g.device)
+    check(lib.msmd_nn_assign(_p(g), _p(r), m, ns, int(nq), _p(out), _p(scratch), _stream()),
+          "msmd_nn_assign")
+    return out

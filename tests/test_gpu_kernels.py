@@ -1,0 +1,304 @@
+"""GPU parity tests: every C-ABI entry point (through msmdfusion_amd.kernels)
+against the CPU oracle on the same seeded inputs.  Integer results (voxel
+indices, rulebooks, set operations, FPS / ball query) must match bit for bit;
+fp32 features within 1e-4 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from msmdfusion_amd import synthetic as S
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def t(a, dev, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return x if dtype is None else x.to(dtype)
+
+
+# ------------------------------------------------------------------ voxelization
+@pytest.mark.parametrize("max_points,max_voxels,scale", [(10, 120000, 1), (10, 5000, 1),
+                                                         (3, 120000, 2), (1, 700, 8)])
+def test_hard_voxelize_lidar(dev, max_points, max_voxels, scale):
+    from msmdfusion_amd import kernels as K
+    pts = S.lidar_sweep(1)
+    vs = [v * scale for v in S.VOXEL_SIZE]
+    ev, ec, en = O.hard_voxelize(pts, vs, S.POINT_CLOUD_RANGE, max_points, max_voxels)
+    v, c, n, mean = K.hard_voxelize(t(pts, dev), vs, S.POINT_CLOUD_RANGE, max_points, max_voxels,
+                                    want_voxels=True, want_mean=True)
+    assert c.shape[0] == ec.shape[0]
+    assert np.array_equal(c.cpu().numpy(), ec)
+    assert np.array_equal(n.cpu().numpy(), en)
+    assert np.array_equal(v.cpu().numpy(), ev)          # features are copies: bit exact
+    em = O.voxel_mean(ev, en)
+    np.testing.assert_allclose(mean.cpu().numpy(), em, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(K.voxel_mean(v, n).cpu().numpy(), em, rtol=1e-6, atol=1e-6)
+
+
+def test_hard_voxelize_virtual_64ch(dev):
+    from msmdfusion_amd import kernels as K
+    pts = S.virtual_points(0, n=20000)
+    for f in (1, 4):
+        vs = [v * f for v in S.VOXEL_SIZE]
+        ev, ec, en = O.hard_voxelize(pts, vs, S.POINT_CLOUD_RANGE, 10, 160000)
+        v, c, n, _ = K.hard_voxelize(t(pts, dev), vs, S.POINT_CLOUD_RANGE, 10, 160000)
+        assert np.array_equal(c.cpu().numpy(), ec)
+        assert np.array_equal(n.cpu().numpy(), en)
+        assert np.array_equal(v.cpu().numpy(), ev)
+
+
+def test_hard_voxelize_edge_cases(dev):
+    from msmdfusion_amd import kernels as K
+    rng = np.random.RandomState(0)
+    # all points out of range -> zero voxels
+    far = (rng.rand(100, 5) + 100).astype(np.float32)
+    v, c, n, _ = K.hard_voxelize(t(far, dev), S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 1000)
+    assert c.shape[0] == 0 and v.shape[0] == 0
+    # every point in one voxel, more points than slots
+    one = np.tile(np.array([[0.01, 0.01, 0.01, 0.5, 0]], np.float32), (50, 1))
+    one[:, 3] = np.arange(50)
+    ev, ec, en = O.hard_voxelize(one, S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 1000)
+    v, c, n, _ = K.hard_voxelize(t(one, dev), S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 1000)
+    assert np.array_equal(v.cpu().numpy(), ev) and np.array_equal(n.cpu().numpy(), en)
+    # points exactly on cell / range boundaries (float32 floor semantics)
+    edge = np.array([[-54.0, -54.0, -5.0, 0, 0], [54.0, 0, 0, 0, 0], [53.999996, 0, 0, 0, 0],
+                     [0.075, 0.15, 0.2, 0, 0], [0.0749999, 0.1499999, 0.1999999, 0, 0],
+                     [-0.0, -0.0, -0.0, 0, 0]], np.float32)
+    ev, ec, en = O.hard_voxelize(edge, S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 1000)
+    v, c, n, _ = K.hard_voxelize(t(edge, dev), S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 1000)
+    assert np.array_equal(c.cpu().numpy(), ec) and np.array_equal(n.cpu().numpy(), en)
+
+
+# ------------------------------------------------------------------ rulebooks
+GEOMS = [  # (subm, ksize, stride, padding) : the geometries of SURVEY Appendix A
+    (True, 3, 1, 1),
+    (False, 3, 2, 1),
+    (False, 3, 2, [0, 1, 1]),
+    (False, [3, 1, 1], [2, 1, 1], 0),
+]
+
+
+def _check_rulebook(dev, idx, batch, shape, subm, ks, st, pd):
+    from msmdfusion_amd import kernels as K
+    oi, pr, nm, osz = O.get_indice_pairs(idx, batch, shape, ks, st, pd, 1, subm)
+    d_idx = t(idx, dev)
+    if subm:
+        nbr = K.rulebook_subm(d_idx, batch, shape, ks)
+        # SubM keeps input order: compare raw rows
+        exp = np.full((nm.shape[0], idx.shape[0]), -1, np.int32)
+        for k in range(nm.shape[0]):
+            p = int(nm[k])
+            exp[k, pr[k, 1, :p]] = pr[k, 0, :p]
+        assert np.array_equal(nbr.cpu().numpy(), exp)
+        pairs, num = K.rulebook_pairs(nbr)
+        assert np.array_equal(num.cpu().numpy(), nm)
+        _, can, _ = O.canonical_rulebook(oi, pr, nm, osz)
+        got = pairs.cpu().numpy()
+        for k in range(nm.shape[0]):
+            p = int(nm[k])
+            assert np.array_equal(got[k, :, :p].T, can[k])
+            assert (got[k, :, p:] == -1).all()
+        return
+    out_idx, nbr_fwd, nbr_bwd, out_shape = K.rulebook_conv(d_idx, batch, shape, ks, st, pd)
+    assert list(out_shape) == list(osz)
+    coi, can, perm = O.canonical_rulebook(oi, pr, nm, osz)
+    assert np.array_equal(out_idx.cpu().numpy(), coi)           # ascending linear id
+    exp_fwd = O.nbr_table_from_pairs(can, coi.shape[0])
+    assert np.array_equal(nbr_fwd.cpu().numpy(), exp_fwd)
+    exp_bwd = np.full((nm.shape[0], idx.shape[0]), -1, np.int32)
+    for k, po in enumerate(can):
+        exp_bwd[k, po[:, 0]] = po[:, 1]
+    assert np.array_equal(nbr_bwd.cpu().numpy(), exp_bwd)
+    pairs, num = K.rulebook_pairs(nbr_fwd, ld=max(idx.shape[0], coi.shape[0]))
+    assert np.array_equal(num.cpu().numpy(), nm)
+    got = pairs.cpu().numpy()
+    for k in range(nm.shape[0]):
+        assert np.array_equal(got[k, :, :int(nm[k])].T, can[k])
+
+
+@pytest.mark.parametrize("subm,ks,st,pd", GEOMS)
+def test_rulebook_random(dev, subm, ks, st, pd):
+    idx = S.random_voxel_indices(6000, 2, [21, 200, 200], seed=3)
+    _check_rulebook(dev, idx, 2, [21, 200, 200], subm, ks, st, pd)
+
+
+@pytest.mark.parametrize("subm,ks,st,pd", GEOMS)
+def test_rulebook_lidar_full_grid(dev, subm, ks, st, pd):
+    _, c, _ = O.hard_voxelize(S.lidar_sweep(0), S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 120000)
+    idx = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+    _check_rulebook(dev, idx, 1, S.SPARSE_SHAPE, subm, ks, st, pd)
+
+
+def test_rulebook_edges(dev):
+    from msmdfusion_amd import kernels as K
+    shape = [5, 8, 8]
+    # corners and a full dense block: boundary handling on every side
+    dense_blk = np.array([[0, z, y, x] for z in range(5) for y in range(8) for x in range(8)],
+                         np.int32)
+    for subm, ks, st, pd in GEOMS:
+        _check_rulebook(dev, dense_blk, 1, shape, subm, ks, st, pd)
+    single = np.array([[1, 4, 7, 7]], np.int32)
+    for subm, ks, st, pd in GEOMS:
+        _check_rulebook(dev, single, 2, shape, subm, ks, st, pd)
+    empty = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    assert K.rulebook_subm(empty, 1, shape, 3).shape == (27, 0)
+    oi, f, b, _ = K.rulebook_conv(empty, 1, shape, 3, 2, 1)
+    assert oi.shape[0] == 0 and f.shape == (27, 0)
+
+
+# ------------------------------------------------------------------ convolution
+CHANNELS = [(5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128),
+            (80, 80), (80, 96), (96, 128), (128, 192), (192, 192), (7, 20)]
+
+
+@pytest.mark.parametrize("cin,cout", CHANNELS)
+def test_subm_conv_fwd_bwd(dev, cin, cout):
+    from msmdfusion_amd import kernels as K
+    shape = [11, 64, 64]
+    idx = S.random_voxel_indices(1500, 2, shape, seed=cin + cout)
+    n = idx.shape[0]
+    rng = np.random.RandomState(cin * 1000 + cout)
+    f = rng.randn(n, cin).astype(np.float32)
+    w = (rng.randn(27, cin, cout) / np.sqrt(27 * cin)).astype(np.float32)
+    g = rng.randn(n, cout).astype(np.float32)
+    oi, pr, nm, _ = O.get_indice_pairs(idx, 2, shape, 3, 1, 1, 1, True)
+    exp = O.indice_conv_fwd(f, w, pr, nm, n, subm=True)
+    edin, edw = O.indice_conv_bwd(f, w, g, pr, nm, subm=True)
+
+    nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
+    wd = t(w, dev)
+    out = K.conv_forward(t(f, dev), K.pack_weight(wd), nbr, n, cout)
+    np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=TOL, atol=TOL)
+    # dgrad: forward table read with flipped weights and W^T
+    din = K.conv_forward(t(g, dev), K.pack_weight(wd, transpose=True), nbr, n, cin,
+                         weight_flip=True)
+    np.testing.assert_allclose(din.cpu().numpy(), edin, rtol=TOL, atol=TOL)
+    pairs, num = K.rulebook_pairs(nbr)
+    dw = K.conv_wgrad(t(f, dev), t(g, dev), pairs, num)
+    np.testing.assert_allclose(dw.cpu().numpy(), edw, rtol=TOL, atol=TOL * 5)
+
+
+@pytest.mark.parametrize("ks,st,pd", [(3, 2, 1), (3, 2, [0, 1, 1]), ([3, 1, 1], [2, 1, 1], 0)])
+@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 128), (128, 128), (80, 96)])
+def test_strided_conv_fwd_bwd(dev, ks, st, pd, cin, cout):
+    from msmdfusion_amd import kernels as K
+    shape = [11, 64, 64]
+    idx = S.random_voxel_indices(1500, 2, shape, seed=11)
+    n = idx.shape[0]
+    rng = np.random.RandomState(7)
+    f = rng.randn(n, cin).astype(np.float32)
+    kvol = int(np.prod(O.expand3(ks)))
+    w = (rng.randn(kvol, cin, cout) / np.sqrt(kvol * cin)).astype(np.float32)
+    oi, pr, nm, osz = O.get_indice_pairs(idx, 2, shape, ks, st, pd, 1, False)
+    m = oi.shape[0]
+    g = rng.randn(m, cout).astype(np.float32)
+    exp = O.indice_conv_fwd(f, w, pr, nm, m)
+    edin, edw = O.indice_conv_bwd(f, w, g, pr, nm)
+    _, _, perm = O.canonical_rulebook(oi, pr, nm, osz)   # oracle rows -> sorted rows
+
+    out_idx, nbr_fwd, nbr_bwd, _ = K.rulebook_conv(t(idx, dev), 2, shape, ks, st, pd)
+    wd = t(w, dev)
+    out = K.conv_forward(t(f, dev), K.pack_weight(wd), nbr_fwd, m, cout)
+    np.testing.assert_allclose(out.cpu().numpy(), exp[perm], rtol=TOL, atol=TOL)
+    gs = t(g[perm], dev)
+    din = K.conv_forward(gs, K.pack_weight(wd, transpose=True), nbr_bwd, n, cin)
+    np.testing.assert_allclose(din.cpu().numpy(), edin, rtol=TOL, atol=TOL)
+    pairs, num = K.rulebook_pairs(nbr_fwd, ld=max(n, m))
+    dw = K.conv_wgrad(t(f, dev), gs, pairs, num)
+    np.testing.assert_allclose(dw.cpu().numpy(), edw, rtol=TOL, atol=TOL * 5)
+
+
+# ------------------------------------------------------------------ dense / sets
+@pytest.mark.parametrize("c", [1, 5, 128, 192])
+def test_dense_scatter_gather(dev, c):
+    from msmdfusion_amd import kernels as K
+    shape = [2, 45, 45]
+    idx = S.random_voxel_indices(900, 3, shape, seed=c)
+    f = np.random.RandomState(c).randn(idx.shape[0], c).astype(np.float32)
+    exp = O.dense(f, idx, 3, shape)
+    out = K.dense_scatter(t(f, dev), t(idx, dev), 3, shape)
+    assert np.array_equal(out.cpu().numpy(), exp)
+    back = K.dense_gather(out, t(idx, dev), shape)
+    assert np.array_equal(back.cpu().numpy(), f)
+
+
+def test_sparse_add(dev):
+    from msmdfusion_amd import kernels as K
+    shape = [11, 90, 90]
+    a = S.random_voxel_indices(3000, 2, shape, seed=1)
+    b = np.concatenate([a[::3], S.random_voxel_indices(2000, 2, shape, seed=2)])
+    b = b[np.sort(np.unique(b, axis=0, return_index=True)[1])]
+    rng = np.random.RandomState(0)
+    fa, fb = rng.randn(a.shape[0], 96).astype(np.float32), rng.randn(b.shape[0], 96).astype(np.float32)
+    eoi, eof, ema, emb = O.sparse_add(fa, a, fb, b, shape)
+    oi, of, ma, mb = K.sparse_add(t(fa, dev), t(a, dev), t(fb, dev), t(b, dev), 2, shape)
+    assert np.array_equal(oi.cpu().numpy(), eoi)
+    assert np.array_equal(ma.cpu().numpy(), ema) and np.array_equal(mb.cpu().numpy(), emb)
+    np.testing.assert_allclose(of.cpu().numpy(), eof, rtol=1e-6, atol=1e-6)
+    # empty operand
+    z = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    zf = torch.zeros((0, 96), device=dev)
+    oi2, of2, _, _ = K.sparse_add(t(fa, dev), t(a, dev), zf, z, 2, shape)
+    assert oi2.shape[0] == a.shape[0]
+
+
+def test_modality_split(dev):
+    from msmdfusion_amd import kernels as K
+    shape = [41, 300, 300]
+    a = S.random_voxel_indices(5000, 2, shape, seed=5)
+    b = np.concatenate([a[1::4], S.random_voxel_indices(3000, 2, shape, seed=6)])
+    b = b[np.sort(np.unique(b, axis=0, return_index=True)[1])]
+    m3, m2, p3, p2 = K.modality_split(t(a, dev), t(b, dev), 2, shape)
+    e3, e2, ep3, ep2 = [], [], [], []
+    off3 = off2 = 0
+    for bi in range(2):   # the reference walks sample by sample (MSMDFusion.py:262)
+        sa, sb = a[a[:, 0] == bi], b[b[:, 0] == bi]
+        x3, x2, q3, q2 = O.modality_split(sa[:, 1:], sb[:, 1:], shape)
+        e3.append(x3); e2.append(x2)
+        ep3.append(np.flatnonzero(a[:, 0] == bi)[q3]); ep2.append(np.flatnonzero(b[:, 0] == bi)[q2])
+    assert np.array_equal(m3.cpu().numpy()[np.argsort(a[:, 0], kind="stable")], np.concatenate(e3))
+    assert np.array_equal(m2.cpu().numpy()[np.argsort(b[:, 0], kind="stable")], np.concatenate(e2))
+    assert np.array_equal(p3.cpu().numpy(), np.concatenate(ep3))
+    assert np.array_equal(p2.cpu().numpy(), np.concatenate(ep2))
+
+
+# ------------------------------------------------------------------ GMA-Conv helpers
+@pytest.mark.parametrize("n,m", [(5, 3), (1000, 64), (3000, 512), (20000, 256), (30000, 64)])
+def test_fps(dev, n, m):
+    from msmdfusion_amd import kernels as K
+    rng = np.random.RandomState(n)
+    # integer voxel coordinates: ties are the common case
+    xyz = np.stack([rng.randint(0, 41, (2, n)), rng.randint(0, 200, (2, n)),
+                    rng.randint(0, 200, (2, n))], -1).astype(np.float32)
+    exp = O.furthest_point_sample(xyz, m)
+    got = K.furthest_point_sample(t(xyz, dev), m)
+    assert np.array_equal(got.cpu().numpy(), exp)
+
+
+def test_ball_query_and_assign(dev):
+    from msmdfusion_amd import kernels as K
+    rng = np.random.RandomState(1)
+    n, m, ns = 6000, 300, 50
+    xyz = np.stack([rng.randint(0, 11, (1, n)), rng.randint(0, 120, (1, n)),
+                    rng.randint(0, 120, (1, n))], -1).astype(np.float32)
+    centers = xyz[:, rng.choice(n, m, replace=False)]
+    exp = O.ball_query(0, 6.0, ns, xyz, centers)
+    got = K.ball_query(0, 6.0, ns, t(xyz, dev), t(centers, dev))
+    assert np.array_equal(got.cpu().numpy(), exp)
+    rep_nn = rng.randint(-1, 500, m).astype(np.int32)
+    ea = O.nn_assign(exp[0], rep_nn, n)
+    ga = K.nn_assign(got[0], t(rep_nn, dev), n)
+    assert np.array_equal(ga.cpu().numpy(), ea)
+
+
+def test_nn_search(dev):
+    from msmdfusion_amd import kernels as K
+    rng = np.random.RandomState(2)
+    q = np.stack([rng.randint(0, 41, 700), rng.randint(0, 300, 700), rng.randint(0, 300, 700)], -1)
+    k = np.stack([rng.randint(0, 41, 9000), rng.randint(0, 300, 9000), rng.randint(0, 300, 9000)], -1)
+    exp = O.nn_search(q, k, 13.3)
+    got = K.nn_search(t(q.astype(np.int32), dev), t(k.astype(np.int32), dev), 13.3)
+    assert np.array_equal(got.cpu().numpy(), exp)
