@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""bench.py -- the MSMDFusion sparse-voxel hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): TransFusion-L voxel backbone
+(configs/transfusion_nusc_voxel_L.py: voxelize 0.075 m -> HardSimpleVFE ->
+SparseEncoder 5->16->32->64->128 -> BEV [B,256,180,180]), forward + backward +
+AdamW step, samples_per_gpu = 4, synthetic nuScenes-shaped clouds (seeded,
+resident in HBM before the timed region), fp32 (the reference's precision).
+
+One "step" = voxelize 4 clouds + forward + backward + optimizer step on every
+rank; value = samples/s over all ranks.  Prints ONE JSON line (rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+SAMPLES_PER_GPU = 4            # configs/transfusion_nusc_voxel_L.py:116
+
+ENCODER_CFG = dict(             # configs/transfusion_nusc_voxel_L.py:161-169
+    type="SparseEncoder", in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128,
+    order=("conv", "norm", "act"),
+    encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+    encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
+    block_type="basicblock")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="skip per-launch event timing of the conv kernels")
+    return ap.parse_args()
+
+
+class Backbone(torch.nn.Module):
+    """pts_voxel_layer + pts_voxel_encoder + pts_middle_encoder of
+    TransFusionDetector.extract_pts_feat (mmdet3d/models/detectors/transfusion.py:61-74)."""
+
+    def __init__(self):
+        super().__init__()
+        from msmdfusion_amd import synthetic as S
+        from msmdfusion_amd.registry import build_middle_encoder
+        from msmdfusion_amd.voxelize import Voxelization
+        import msmdfusion_amd.sparse_encoder  # noqa: F401  (registers SparseEncoder)
+        self.voxel_layer = Voxelization(S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, S.MAX_NUM_POINTS,
+                                        S.MAX_VOXELS)
+        self.middle_encoder = build_middle_encoder(ENCODER_CFG)
+
+    @torch.no_grad()
+    def voxelize(self, points):
+        """transfusion.py:76-101 with the VFE fused into the gather."""
+        feats, coors = [], []
+        for b, pts in enumerate(points):
+            mean, c, _ = self.voxel_layer.forward_mean(pts)
+            feats.append(mean)
+            coors.append(F.pad(c, (1, 0), mode="constant", value=b))
+        return torch.cat(feats, 0), torch.cat(coors, 0)
+
+    def forward(self, points):
+        feats, coors = self.voxelize(points)
+        bev, _ = self.middle_encoder(feats, coors, len(points))
+        return bev
+
+
+def cpu_baseline(seed):
+    """Reference algorithm on the host (oracle port, OpenMP): one cloud through
+    voxelization, every rulebook and all 21 sparse convs forward + backward
+    (dgrad + wgrad); BN/ReLU (elementwise, <1 % of the work) are skipped."""
+    from msmdfusion_amd import synthetic as S
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    pts = S.lidar_sweep(seed)
+    t0 = time.perf_counter()
+    v, c, n = O.hard_voxelize(pts, S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 120000)
+    feat = O.voxel_mean(v, n)
+    idx = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+    rng = np.random.RandomState(0)
+    shape = list(S.SPARSE_SHAPE)
+    layers = [("subm", 5, 16)]
+    for i, blocks in enumerate(ENCODER_CFG["encoder_channels"]):
+        cin = layers[-1][2]
+        for j, cout in enumerate(blocks):
+            last = j == len(blocks) - 1 and i != 3
+            if last:
+                layers.append(("down%d" % i, cin, cout))
+            else:
+                layers += [("subm", cout, cout), ("subm", cout, cout)]
+            cin = cout
+    layers.append(("out", 128, 128))
+    pads = {0: 1, 1: 1, 2: [0, 1, 1]}
+    macs = 0
+    cache = {}
+    for kind, cin, cout in layers:
+        if kind == "subm":
+            key = (idx.shape[0], tuple(shape))
+            if key not in cache:
+                cache[key] = O.get_indice_pairs(idx, 1, shape, 3, 1, 1, 1, True)
+            oi, pr, nm, osz = cache[key]
+            w = rng.randn(27, cin, cout).astype(np.float32) * 0.05
+            out = O.indice_conv_fwd(feat, w, pr, nm, oi.shape[0], subm=True)
+            O.indice_conv_bwd(feat, w, out, pr, nm, subm=True)
+        else:
+            ks, st, pd = (3, 2, pads[int(kind[4])]) if kind != "out" else ([3, 1, 1], [2, 1, 1], 0)
+            oi, pr, nm, osz = O.get_indice_pairs(idx, 1, shape, ks, st, pd, 1, False)
+            w = rng.randn(pr.shape[0], cin, cout).astype(np.float32) * 0.05
+            out = O.indice_conv_fwd(feat, w, pr, nm, oi.shape[0])
+            O.indice_conv_bwd(feat, w, out, pr, nm)
+            idx, shape = oi, osz
+        macs += int(nm.sum()) * cin * cout
+        feat = np.maximum(out, 0)
+    dt = time.perf_counter() - t0
+    return dict(value=round(1.0 / dt, 4), unit="samples/s", cores=cores, kind="port",
+                sample="1 synthetic cloud (seed %d, %d pts, %d voxels): voxelize + all rulebooks + "
+                       "21 sparse convs fwd+dgrad+wgrad with oracle/msmd_oracle.c (OpenMP, %d "
+                       "threads), %.1f GMAC fwd, %.1f s" % (seed, pts.shape[0], c.shape[0], cores,
+                                                           macs / 1e9, dt))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    from msmdfusion_amd import kernels as K
+    from msmdfusion_amd import synthetic as S
+
+    torch.manual_seed(0)
+    model = Backbone().to(dev).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank],
+                                                        gradient_as_bucket_view=True)
+    # AdamW lr=1e-4, wd=0.01: configs/transfusion_nusc_voxel_L.py optimizer
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
+
+    clouds = [torch.from_numpy(S.lidar_sweep(rank * SAMPLES_PER_GPU + i)).to(dev)
+              for i in range(SAMPLES_PER_GPU)]
+    target = torch.randn(SAMPLES_PER_GPU, 256, 180, 180, device=dev)
+
+    def step():
+        bev = net(clouds)
+        loss = (bev * target).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 10.0)     # grad_clip max_norm=10 (config)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    prof = None if args.no_profile else []
+    K.PROFILE = prof
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    K.PROFILE = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(loss).item()
+
+    if rank == 0:
+        n_samples = args.steps * SAMPLES_PER_GPU * world
+        out = {
+            "metric": "samples/sec TransFusion-L voxel backbone fwd+bwd (nuScenes 0.075m voxel)",
+            "value": round(n_samples / elapsed, 3), "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: TransFusion-L voxel backbone (voxelize+VFE+"
+                                   "SparseEncoder->BEV), fwd+bwd+AdamW, 4 synthetic ~28.7k-pt "
+                                   "clouds/GPU, 0.075 m voxels, fp32",
+                       "global_batch": SAMPLES_PER_GPU * world, "parallelism": "dp%d" % world},
+        }
+        out["roofline"] = roofline(prof) if prof else None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(0)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline(prof):
+    """Dominant kernel = the conv kernel class with the most accumulated time.
+    achieved = algorithmic flops (2 * pairs * Cin * Cout, the reference's MAC
+    count mmdet3d/apis/flops_counter.py:9-12) / measured launch duration."""
+    pair_cache = {}
+    groups = {}
+    for kind, s, e, meta in prof:
+        ms = s.elapsed_time(e)
+        if kind == "spconv_fwd":
+            nbr = meta["nbr"]
+            key = (nbr.data_ptr(), nbr.shape[1])
+            if key not in pair_cache:
+                pair_cache[key] = int((nbr >= 0).sum().item())
+            pairs = pair_cache[key]
+            name = "spconv_fwd_kernel<NT=%d>" % ((meta["c_out"] + 15) // 16)
+        else:
+            pairs = int(meta["num"].sum().item())
+            name = "spconv_wgrad_kernel"
+        g = groups.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
+        g["ms"] += ms
+        g["flops"] += 2.0 * pairs * meta["c_in"] * meta["c_out"]
+        g["launches"] += 1
+    total_ms = sum(g["ms"] for g in groups.values())
+    name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3),
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2), "launches": g["launches"],
+            "share_of_conv_time": round(g["ms"] / total_ms, 3),
+            "all_conv_kernels": {k: {"ms": round(v["ms"], 3),
+                                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 3),
+                                     "launches": v["launches"]} for k, v in groups.items()}}
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,9 @@ enum msmd_status {
 };
 
 const char* msmd_status_string(int status);
+/* hipGetErrorString() of the launch that made the calling thread's most recent
+ * MSMD_ERR_LAUNCH. */
+const char* msmd_last_launch_error(void);
 /* ABI version: bumped whenever a signature below changes. */
 int msmd_abi_version(void);
 /* 1 when a gfx950 device is visible to this process, else 0 (host call). */

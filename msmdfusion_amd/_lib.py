@@ -8,6 +8,12 @@ Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
 import ctypes as C
 import os
 
+# torch first: its wheel bundles the HIP runtime (torch/lib/libamdhip64.so,
+# SONAME libamdhip64.so.7).  Loading libmsmd_hip.so before torch would pull in
+# /opt/rocm's copy as a second runtime instance that cannot see torch's
+# device context ("no ROCm-capable device is detected" on the first launch).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmsmd_hip.so")
 
@@ -27,6 +33,7 @@ _fp = C.POINTER(C.c_float)
 # tests/test_boundary.py checks the two stay in sync.
 SIGNATURES = {
     "msmd_status_string": (C.c_char_p, [_i]),
+    "msmd_last_launch_error": (C.c_char_p, []),
     "msmd_abi_version": (_i, []),
     "msmd_device_ok": (_i, []),
     "msmd_voxelize_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -75,6 +82,8 @@ class MsmdError(RuntimeError):
 def check(status, what=""):
     if status != 0:
         msg = lib.msmd_status_string(status).decode()
+        if status == -4:
+            msg += " [" + lib.msmd_last_launch_error().decode() + "]"
         raise MsmdError(f"{what}: {msg} (msmd_status {status})")
 
 

@@ -14,8 +14,24 @@ constexpr int kWave = 64;  // CDNA wavefront
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// Launch errors are tracked per call, not through the runtime's sticky "last
+// error": PyTorch's allocator leaves hipErrorNotReady (event polling) behind,
+// which a bare hipGetLastError() after our launches would misreport.
+inline thread_local int g_launch_err = 0;   // first failing hipError_t of this call
+inline thread_local int g_last_detail = 0;  // kept for msmd_last_launch_error()
+#define MSMD_LAUNCH(kernel, grid, block, smem, stream, ...)                       \
+  do {                                                                            \
+    (void)hipGetLastError();                                                      \
+    hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);           \
+    hipError_t e_ = hipGetLastError();                                            \
+    if (e_ != hipSuccess && !::msmd::g_launch_err) ::msmd::g_launch_err = (int)e_; \
+  } while (0)
+
 inline int launch_status() {
-  return hipGetLastError() == hipSuccess ? MSMD_OK : MSMD_ERR_LAUNCH;
+  int e = g_launch_err;
+  g_launch_err = 0;
+  if (e) g_last_detail = e;
+  return e ? MSMD_ERR_LAUNCH : MSMD_OK;
 }
 
 // Bump allocator over the caller's workspace (256-B aligned slices).

@@ -165,7 +165,7 @@ MSMD_EXPORT int msmd_dense_scatter_f32(const float* feat, const int32_t* indices
     if (smem > 64 * 1024)
       hipFuncSetAttribute((const void*)dense_kernel<true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(dense_kernel<true>, dim3(ceil_div(n, kDenseRows)), dim3(256), smem, st,
+    MSMD_LAUNCH(dense_kernel<true>, dim3(ceil_div(n, kDenseRows)), dim3(256), smem, st,
                        const_cast<float*>(feat), indices, n, c, sh, out);
   }
   return launch_status();
@@ -184,7 +184,7 @@ MSMD_EXPORT int msmd_dense_gather_f32(const float* dense, const int32_t* indices
   if (smem > 64 * 1024)
     hipFuncSetAttribute((const void*)dense_kernel<false>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(dense_kernel<false>, dim3(ceil_div(n, kDenseRows)), dim3(256), smem,
+  MSMD_LAUNCH(dense_kernel<false>, dim3(ceil_div(n, kDenseRows)), dim3(256), smem,
                      (hipStream_t)stream, feat, indices, n, c, sh, const_cast<float*>(dense));
   return launch_status();
 }
@@ -210,10 +210,10 @@ MSMD_EXPORT int msmd_sparse_add_count(const int32_t* idx_a, int n_a, const int32
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(w.bits, 0, sizeof(uint32_t) * w.words, st);
   if (n_a > 0)
-    hipLaunchKernelGGL(mark_rows, dim3(ceil_div(n_a, 256)), dim3(256), 0, st, idx_a, n_a, sh,
+    MSMD_LAUNCH(mark_rows, dim3(ceil_div(n_a, 256)), dim3(256), 0, st, idx_a, n_a, sh,
                        w.bits);
   if (n_b > 0)
-    hipLaunchKernelGGL(mark_rows, dim3(ceil_div(n_b, 256)), dim3(256), 0, st, idx_b, n_b, sh,
+    MSMD_LAUNCH(mark_rows, dim3(ceil_div(n_b, 256)), dim3(256), 0, st, idx_b, n_b, sh,
                        w.bits);
   device_scan(PopcCount{w.bits}, StorePrefix{w.prefix}, (int)w.words, w.tiles, n_out, -1, st);
   return launch_status();
@@ -237,10 +237,10 @@ MSMD_EXPORT int msmd_sparse_add_fill(const float* feat_a, const int32_t* idx_a, 
   hipStream_t st = (hipStream_t)stream;
   if (n_out > 0) hipMemsetAsync(out_feat, 0, sizeof(float) * (size_t)n_out * c, st);
   if (n_a > 0)
-    hipLaunchKernelGGL(add_rows, dim3(ceil_div((long)n_a * 16, 256)), dim3(256), 0, st, feat_a,
+    MSMD_LAUNCH(add_rows, dim3(ceil_div((long)n_a * 16, 256)), dim3(256), 0, st, feat_a,
                        idx_a, n_a, c, sh, w.bits, w.prefix, n_out, out_indices, out_feat, map_a);
   if (n_b > 0)
-    hipLaunchKernelGGL(add_rows, dim3(ceil_div((long)n_b * 16, 256)), dim3(256), 0, st, feat_b,
+    MSMD_LAUNCH(add_rows, dim3(ceil_div((long)n_b * 16, 256)), dim3(256), 0, st, feat_b,
                        idx_b, n_b, c, sh, w.bits, w.prefix, n_out, out_indices, out_feat, map_b);
   return launch_status();
 }
@@ -268,20 +268,20 @@ MSMD_EXPORT int msmd_modality_split(const int32_t* idx_3d, int n3, const int32_t
   hipMemsetAsync(w.bits, 0, sizeof(uint32_t) * w.words, st);
   hipMemsetAsync(w.bits2, 0, sizeof(uint32_t) * w.words, st);
   if (n3 > 0)
-    hipLaunchKernelGGL(mark_rows, dim3(ceil_div(n3, 256)), dim3(256), 0, st, idx_3d, n3, sh,
+    MSMD_LAUNCH(mark_rows, dim3(ceil_div(n3, 256)), dim3(256), 0, st, idx_3d, n3, sh,
                        w.bits);
   if (n2 > 0)
-    hipLaunchKernelGGL(mark_rows, dim3(ceil_div(n2, 256)), dim3(256), 0, st, idx_2d, n2, sh,
+    MSMD_LAUNCH(mark_rows, dim3(ceil_div(n2, 256)), dim3(256), 0, st, idx_2d, n2, sh,
                        w.bits2);
-  hipLaunchKernelGGL(and_words, dim3(ceil_div((long)w.words, 256)), dim3(256), 0, st, w.bits,
+  MSMD_LAUNCH(and_words, dim3(ceil_div((long)w.words, 256)), dim3(256), 0, st, w.bits,
                      w.bits2, w.words);
   device_scan(PopcCount{w.bits}, StorePrefix{w.prefix}, (int)w.words, w.tiles, n_mixed, -1, st);
   const int cap = n3 < n2 ? n3 : n2;
   if (n3 > 0)
-    hipLaunchKernelGGL(split_rows, dim3(ceil_div(n3, 256)), dim3(256), 0, st, idx_3d, n3, sh,
+    MSMD_LAUNCH(split_rows, dim3(ceil_div(n3, 256)), dim3(256), 0, st, idx_3d, n3, sh,
                        w.bits, w.prefix, cap, mix3d, pair_3d);
   if (n2 > 0)
-    hipLaunchKernelGGL(split_rows, dim3(ceil_div(n2, 256)), dim3(256), 0, st, idx_2d, n2, sh,
+    MSMD_LAUNCH(split_rows, dim3(ceil_div(n2, 256)), dim3(256), 0, st, idx_2d, n2, sh,
                        w.bits, w.prefix, cap, mix2d, pair_2d);
   return launch_status();
 }

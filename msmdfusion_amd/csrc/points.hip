@@ -55,8 +55,13 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
     const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
     unsigned long long best = 0;
     auto visit = [&](int k, float d2) {
-      // larger distance first; ties: smaller (k mod bs, k div bs) first
-      uint32_t tb = ((uint32_t)(k & (bs_ref - 1)) << 21) | (uint32_t)(k >> bs_shift);
+      // larger distance first.  Ties: the reference's shared-memory tree keeps
+      // the LOWER slot of each (t, t+s) pair, s = bs/2 .. 1, so between two
+      // thread ids the one whose lowest differing bit is 0 wins: order by the
+      // bit-reversed thread id (k mod bs), then by k div bs (strided scan
+      // keeps the first maximum).
+      uint32_t rev = bs_shift ? (__brev((uint32_t)(k & (bs_ref - 1))) >> (32 - bs_shift)) : 0u;
+      uint32_t tb = (rev << 21) | (uint32_t)(k >> bs_shift);
       unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (uint32_t)~tb;
       best = key > best ? key : best;
     };
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
       }
       if (lane == 0) {
         uint32_t tb = ~(uint32_t)v;
-        int k = (int)((tb & 0x1FFFFFu) << bs_shift) | (int)(tb >> 21);
+        uint32_t tid_ref = bs_shift ? (__brev(tb >> 21) >> (32 - bs_shift)) : 0u;
+        int k = (int)((tb & 0x1FFFFFu) << bs_shift) | (int)tid_ref;
         s_old = k;
         idx[j] = k;
       }
@@ -224,7 +230,7 @@ MSMD_EXPORT int msmd_furthest_point_sample(const float* xyz, int b, int n, int m
   hipStream_t st = (hipStream_t)stream;
   const int bs = fps_block_size(n);
   const int ppt = ceil_div(n, 1024);
-#define FPS(P) hipLaunchKernelGGL(fps_kernel<P>, dim3(b), dim3(1024), 0, st, xyz, n, m, bs, temp, idx)
+#define FPS(P) MSMD_LAUNCH(fps_kernel<P>, dim3(b), dim3(1024), 0, st, xyz, n, m, bs, temp, idx)
   if (ppt <= 2) FPS(2);
   else if (ppt <= 4) FPS(4);
   else if (ppt <= 8) FPS(8);
@@ -241,7 +247,7 @@ MSMD_EXPORT int msmd_ball_query(const float* center_xyz, const float* xyz, int b
   if (b < 1 || n < 1 || m < 0 || nsample < 1 || !center_xyz || !xyz || !idx)
     return MSMD_ERR_INVALID_ARG;
   if (m == 0) return MSMD_OK;
-  hipLaunchKernelGGL(ball_query_kernel, dim3(ceil_div(m, 4), b), dim3(256), 0,
+  MSMD_LAUNCH(ball_query_kernel, dim3(ceil_div(m, 4), b), dim3(256), 0,
                      (hipStream_t)stream, center_xyz, xyz, n, m, min_radius * min_radius,
                      max_radius * max_radius, nsample, idx);
   return launch_status();
@@ -257,9 +263,9 @@ MSMD_EXPORT int msmd_nn_search(const int32_t* query_zyx, int nq, const int32_t* 
   auto* best = (unsigned long long*)scratch;
   hipMemsetAsync(best, 0xFF, sizeof(unsigned long long) * nq, st);
   if (nk > 0)
-    hipLaunchKernelGGL(nn_partial, dim3(ceil_div(nq, 256), ceil_div(nk, kNnChunk)), dim3(256), 0,
+    MSMD_LAUNCH(nn_partial, dim3(ceil_div(nq, 256), ceil_div(nk, kNnChunk)), dim3(256), 0,
                        st, query_zyx, nq, key_zyx, nk, best);
-  hipLaunchKernelGGL(nn_final, dim3(ceil_div(nq, 256)), dim3(256), 0, st, best, nq, dist_thresh,
+  MSMD_LAUNCH(nn_final, dim3(ceil_div(nq, 256)), dim3(256), 0, st, best, nq, dist_thresh,
                      out_idx);
   return launch_status();
 }
@@ -273,9 +279,9 @@ MSMD_EXPORT int msmd_nn_assign(const int32_t* group_idx, const int32_t* rep_nn, 
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(scratch, 0xFF, sizeof(int32_t) * nq, st);
   if (m > 0)
-    hipLaunchKernelGGL(assign_max, dim3(ceil_div((long)m * nsample, 256)), dim3(256), 0, st,
+    MSMD_LAUNCH(assign_max, dim3(ceil_div((long)m * nsample, 256)), dim3(256), 0, st,
                        group_idx, rep_nn, m, nsample, nq, scratch);
-  hipLaunchKernelGGL(assign_final, dim3(ceil_div(nq, 256)), dim3(256), 0, st, scratch, rep_nn, nq,
+  MSMD_LAUNCH(assign_final, dim3(ceil_div(nq, 256)), dim3(256), 0, st, scratch, rep_nn, nq,
                      query_nn);
   return launch_status();
 }
@@ -291,6 +297,9 @@ MSMD_EXPORT const char* msmd_status_string(int status) {
     case MSMD_ERR_RANGE: return "linear voxel id does not fit 32 bits";
     default: return "unknown status";
   }
+}
+MSMD_EXPORT const char* msmd_last_launch_error(void) {
+  return hipGetErrorString((hipError_t)g_last_detail);
 }
 MSMD_EXPORT int msmd_abi_version(void) { return 1; }
 MSMD_EXPORT int msmd_device_ok(void) {

@@ -206,8 +206,8 @@ MSMD_EXPORT int msmd_rulebook_subm3d(const int32_t* indices, int n, int batch_si
   auto* table = (unsigned long long*)workspace;
   hipMemsetAsync(table, 0xFF, sizeof(unsigned long long) << bits, st);
   const int nb = ceil_div(n, 256);
-  hipLaunchKernelGGL(subm_insert, dim3(nb), dim3(256), 0, st, indices, n, g, table, bits);
-  hipLaunchKernelGGL(subm_lookup, dim3(nb, g.kvol), dim3(256), 0, st, indices, n, g, table, bits,
+  MSMD_LAUNCH(subm_insert, dim3(nb), dim3(256), 0, st, indices, n, g, table, bits);
+  MSMD_LAUNCH(subm_lookup, dim3(nb, g.kvol), dim3(256), 0, st, indices, n, g, table, bits,
                      nbr);
   return launch_status();
 }
@@ -254,7 +254,7 @@ MSMD_EXPORT int msmd_rulebook_conv3d_count(const int32_t* indices, int n, int ba
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(w.bits, 0, sizeof(uint32_t) * w.words, st);
   if (n > 0)
-    hipLaunchKernelGGL(conv_mark, dim3(ceil_div(n, 256), g.kvol), dim3(256), 0, st, indices, n, g,
+    MSMD_LAUNCH(conv_mark, dim3(ceil_div(n, 256), g.kvol), dim3(256), 0, st, indices, n, g,
                        w.bits);
   device_scan(PopcCount{w.bits}, StorePrefix{w.prefix}, (int)w.words, w.tiles, n_out, -1, st);
   return launch_status();
@@ -279,7 +279,7 @@ MSMD_EXPORT int msmd_rulebook_conv3d_fill(const int32_t* indices, int n, int bat
   hipStream_t st = (hipStream_t)stream;
   if (n_out > 0) hipMemsetAsync(nbr_fwd, 0xFF, sizeof(int32_t) * (size_t)g.kvol * n_out, st);
   if (n > 0)
-    hipLaunchKernelGGL(conv_fill, dim3(ceil_div(n, 256), g.kvol), dim3(256), 0, st, indices, n, g,
+    MSMD_LAUNCH(conv_fill, dim3(ceil_div(n, 256), g.kvol), dim3(256), 0, st, indices, n, g,
                        w.bits, w.prefix, n_out, out_indices, nbr_fwd, nbr_bwd);
   return launch_status();
 }
@@ -318,7 +318,7 @@ MSMD_EXPORT int msmd_rulebook_pairs(const int32_t* nbr, int kernel_volume, int n
   }
   device_scan(PairCount{nbr, n_rows, rp}, PairEmit{nbr, n_rows, rp, ld, indice_pairs, tiles},
               kernel_volume * rp, tiles, total, -1, st);
-  hipLaunchKernelGGL(pair_counts, dim3(ceil_div(kernel_volume, 64)), dim3(64), 0, st, tiles, total,
+  MSMD_LAUNCH(pair_counts, dim3(ceil_div(kernel_volume, 64)), dim3(64), 0, st, tiles, total,
                      tpk, kernel_volume, indice_num);
   return launch_status();
 }

@@ -78,13 +78,13 @@ inline void device_scan(Count count, Emit emit, int n, int* tile_sums, int* tota
                         hipStream_t st) {
   const int nt = scan_num_tiles(n);
   if (nt == 0) {
-    hipLaunchKernelGGL(scan_tiles_top, dim3(1), dim3(1024), 0, st, tile_sums, 0, total, clamp);
+    MSMD_LAUNCH(scan_tiles_top, dim3(1), dim3(1024), 0, st, tile_sums, 0, total, clamp);
     return;
   }
-  hipLaunchKernelGGL(scan_tile_sums<Count>, dim3(nt), dim3(kScanBlock), 0, st, count, n,
+  MSMD_LAUNCH(scan_tile_sums<Count>, dim3(nt), dim3(kScanBlock), 0, st, count, n,
                      tile_sums);
-  hipLaunchKernelGGL(scan_tiles_top, dim3(1), dim3(1024), 0, st, tile_sums, nt, total, clamp);
-  hipLaunchKernelGGL((scan_apply<Count, Emit>), dim3(nt), dim3(kScanBlock), 0, st, count, emit, n,
+  MSMD_LAUNCH(scan_tiles_top, dim3(1), dim3(1024), 0, st, tile_sums, nt, total, clamp);
+  MSMD_LAUNCH((scan_apply<Count, Emit>), dim3(nt), dim3(kScanBlock), 0, st, count, emit, n,
                      tile_sums);
 }
 

@@ -165,10 +165,10 @@ int launch_fwd(const float* in, int cin, const float* wp, const int32_t* nbr, in
   const int rows_per_block = 4 * R * 16;
   dim3 grid(ceil_div(n_out, rows_per_block));
   if ((cin & 3) == 0)
-    hipLaunchKernelGGL((spconv_fwd_kernel<NT, R, true>), grid, dim3(256), 0, st, in, cin, wp, nbr,
+    MSMD_LAUNCH((spconv_fwd_kernel<NT, R, true>), grid, dim3(256), 0, st, in, cin, wp, nbr,
                        ld, n_out, kvol, flip, out, cout);
   else
-    hipLaunchKernelGGL((spconv_fwd_kernel<NT, R, false>), grid, dim3(256), 0, st, in, cin, wp,
+    MSMD_LAUNCH((spconv_fwd_kernel<NT, R, false>), grid, dim3(256), 0, st, in, cin, wp,
                        nbr, ld, n_out, kvol, flip, out, cout);
   return launch_status();
 }
@@ -293,7 +293,7 @@ MSMD_EXPORT int msmd_spconv_pack_weight(const float* weight, int kernel_volume, 
   size_t total = msmd_spconv_packed_weight_elems(kernel_volume, c_in, c_out);
   int nb = ceil_div((long)total, 256);
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, weight,
+  MSMD_LAUNCH(pack_weight_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, weight,
                      kernel_volume, c_in, c_out, transpose, packed);
   return launch_status();
 }
@@ -351,12 +351,12 @@ MSMD_EXPORT int msmd_spconv_wgrad_f32(const float* in_feat, int c_in, const floa
       ((uintptr_t)workspace & 255))
     return MSMD_ERR_WORKSPACE;
   const int slabs = ceil_div(c_in, 16 * kSlab) * ceil_div(c_out, 16 * kSlab);
-  hipLaunchKernelGGL(spconv_wgrad_kernel, dim3(nchunks, kernel_volume, slabs), dim3(256), 0, st,
+  MSMD_LAUNCH(spconv_wgrad_kernel, dim3(nchunks, kernel_volume, slabs), dim3(256), 0, st,
                      in_feat, c_in, d_out, c_out, indice_pairs, indice_num, ld, nchunks,
                      (float*)workspace);
   int rb = ceil_div(per_k, 256);
   if (rb > 64) rb = 64;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb, kernel_volume), dim3(256), 0, st,
+  MSMD_LAUNCH(wgrad_reduce_kernel, dim3(rb, kernel_volume), dim3(256), 0, st,
                      (const float*)workspace, indice_num, nchunks, per_k, d_weight);
   return launch_status();
 }

@@ -218,23 +218,23 @@ MSMD_EXPORT int msmd_hard_voxelize(const float* points, int num_points, int num_
   const int n = num_points;
   hipMemsetAsync(w.table, 0xFF, sizeof(unsigned long long) << w.bits, st);
   hipMemsetAsync(w.win, 0x7F, sizeof(int) * (size_t)max_voxels * max_points, st);
-  hipLaunchKernelGGL(vox_init_scalars, dim3(1), dim3(1), 0, st, w.istar, n);
+  MSMD_LAUNCH(vox_init_scalars, dim3(1), dim3(1), 0, st, w.istar, n);
   const int nb = ceil_div(n, 256);
   if (n > 0)
-    hipLaunchKernelGGL(vox_insert, dim3(nb), dim3(256), 0, st, points, n, num_features, g, w.key,
+    MSMD_LAUNCH(vox_insert, dim3(nb), dim3(256), 0, st, points, n, num_features, g, w.key,
                        w.slot, w.table, w.bits);
   device_scan(FirstFlag{w.key, w.slot, w.table}, RankEmit{w.rank, w.istar, max_voxels}, n,
               w.tiles, voxel_num, max_voxels, st);
   if (n > 0) {
-    hipLaunchKernelGGL(vox_assign, dim3(nb), dim3(256), 0, st, n, g, w.key, w.slot, w.table,
+    MSMD_LAUNCH(vox_assign, dim3(nb), dim3(256), 0, st, n, g, w.key, w.slot, w.table,
                        w.rank, w.istar, w.pv, w.win, max_points, coors);
     for (int r = 1; r < max_points; ++r)
-      hipLaunchKernelGGL(vox_round, dim3(nb), dim3(256), 0, st, n, w.pv, w.win, max_points, r);
+      MSMD_LAUNCH(vox_round, dim3(nb), dim3(256), 0, st, n, w.pv, w.win, max_points, r);
   }
   long work = (long)max_voxels * num_features;
   int gb = ceil_div(work, 256);
   if (gb > 4096) gb = 4096;
-  hipLaunchKernelGGL(vox_gather, dim3(gb), dim3(256), 0, st, points, num_features, w.win,
+  MSMD_LAUNCH(vox_gather, dim3(gb), dim3(256), 0, st, points, num_features, w.win,
                      max_points, voxel_num, voxels, num_points_per_voxel, voxel_mean);
   return launch_status();
 }
@@ -259,7 +259,7 @@ MSMD_EXPORT int msmd_voxel_mean(const float* voxels, const int32_t* num_points_p
   if (num_voxels < 0 || out_features > num_features || out_features < 1)
     return MSMD_ERR_INVALID_ARG;
   if (num_voxels == 0) return MSMD_OK;
-  hipLaunchKernelGGL(voxel_mean_kernel, dim3(ceil_div((long)num_voxels * out_features, 256)),
+  MSMD_LAUNCH(voxel_mean_kernel, dim3(ceil_div((long)num_voxels * out_features, 256)),
                      dim3(256), 0, (hipStream_t)stream, voxels, num_points_per_voxel, num_voxels,
                      max_points, num_features, out_features, out);
   return launch_status();

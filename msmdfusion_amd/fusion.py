@@ -1,0 +1,109 @@
+"""Detector-side glue of the hot path, as free functions / a small module:
+MSMDFusionDetector.voxelize (MSMDFusion.py:462-491), fetch_2D_voxels' voxel half
+(:371-393), voxel_modality_split (:251-325), extract_pts_feat's sparse part
+(:421-443).  The image branch, score_net and the dense BEV tail are outside the
+hot path; virtual points arrive here as ready [N,64] tensors.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import kernels as K
+from . import spconv
+
+
+@torch.no_grad()
+def voxelize_batch(voxel_layer, points, downscale_factor=1.0, base_voxel_size=None,
+                   fused_mean=False):
+    """MSMDFusion.py:462-491: per-sample hard voxelization at voxel size
+    base * downscale_factor, concatenated, batch id prepended to coors.
+    Returns (voxels | mean, num_points, coors[M,4]) -- the reference's order."""
+    base = list(base_voxel_size) if base_voxel_size is not None else [0.075, 0.075, 0.2]
+    voxel_layer.voxel_size = [v * downscale_factor for v in base]   # :475-478 mutates the layer
+    feats, coors, nums = [], [], []
+    for res in points:
+        if fused_mean:
+            f, c, n = voxel_layer.forward_mean(res)
+        else:
+            f, c, n = voxel_layer(res)
+        feats.append(f)
+        coors.append(c)
+        nums.append(n)
+    coors_batch = [F.pad(c, (1, 0), mode="constant", value=i) for i, c in enumerate(coors)]
+    return torch.cat(feats, 0), torch.cat(nums, 0), torch.cat(coors_batch, 0)
+
+
+def virtual_points_to_voxels(voxel_layer, fg_points, spatial_shape, downscale_factor, batch_size,
+                             base_voxel_size=None):
+    """fetch_2D_voxels after get_foreground2D (MSMDFusion.py:374-393): zero-pad
+    empty samples to 100 points (:376-380), voxelize at the stage's scale, mean
+    VFE over all 64 channels, xyz /= (13.5, 13.5, 2.0) (:388-389)."""
+    pts = []
+    for p in fg_points:
+        if p.shape[0] == 0:
+            p = p.new_zeros((100, p.shape[1]))
+        pts.append(p)
+    mean, _, coors = voxelize_batch(voxel_layer, pts, downscale_factor, base_voxel_size,
+                                    fused_mean=True)
+    norm = mean.new_tensor([13.5, 13.5, 2.0])
+    mean = torch.cat([mean[:, :3] / norm[None, :], mean[:, 3:]], 1)
+    return spconv.SparseConvTensor(mean, coors, spatial_shape, batch_size)
+
+
+def voxel_modality_split(voxel_3D, voxel_2D, batch_size):
+    """MSMDFusion.py:251-325: mark voxels present in both modalities.
+    indices become 5 columns (batch, mix_flag, z, y, x); syn_mix_3D / syn_mix_2D
+    list the matched rows of each tensor, aligned, in ascending (b,z,y,x) order.
+    Exact integer keys on the GPU (the reference's float32 keys + numba merge
+    alias for z >= 17 or x >= 1000: SURVEY Appendix B.3, deliberate fix)."""
+    idx3, idx2 = voxel_3D.indices, voxel_2D.indices
+    assert idx3.shape[1] == 4 and idx2.shape[1] == 4
+    shape = [max(a, b) for a, b in zip(voxel_3D.spatial_shape, voxel_2D.spatial_shape)]
+    mix3, mix2, pair3, pair2 = K.modality_split(idx3, idx2, batch_size, shape)
+    voxel_3D.indices = torch.cat([idx3[:, :1], mix3[:, None], idx3[:, 1:]], 1).contiguous()
+    voxel_2D.indices = torch.cat([idx2[:, :1], mix2[:, None], idx2[:, 1:]], 1).contiguous()
+    return voxel_3D, voxel_2D, pair3.long(), pair2.long()
+
+
+class SparseFusionPath(nn.Module):
+    """extract_pts_feat's sparse section (MSMDFusion.py:421-443) behind one
+    module: LiDAR clouds + per-stage virtual points -> (x[B,256,180,180],
+    x_mm[B,384,180,180]) ready for bev_fusion."""
+
+    def __init__(self, voxel_layer, middle_encoder, multimodal_encoder,
+                 spatial_shapes=([41, 1440, 1440], [21, 720, 720], [11, 360, 360], [5, 180, 180]),
+                 downscale_factors=(1, 2, 4, 8), fps_num_list=(2048,) * 4,
+                 radius_list=(6, 3, 2, 1), max_cluster_samples_list=(200, 100, 50, 25),
+                 dist_thresh_list=(13.3, 6.6, 3.3, 1.6), base_voxel_size=(0.075, 0.075, 0.2)):
+        super().__init__()
+        self.pts_voxel_layer = voxel_layer
+        self.pts_middle_encoder = middle_encoder
+        self.multimodal_middle_encoder = multimodal_encoder
+        self.spatial_shapes = [list(s) for s in spatial_shapes]
+        self.downscale_factors = list(downscale_factors)
+        self.fps_num_list = list(fps_num_list)
+        self.radius_list = list(radius_list)
+        self.max_cluster_samples_list = list(max_cluster_samples_list)
+        self.dist_thresh_list = list(dist_thresh_list)
+        self.base_voxel_size = list(base_voxel_size)
+
+    def forward(self, points, virtual_points_per_stage):
+        """points: list of B [N,5] clouds; virtual_points_per_stage: 4 lists of
+        B [Nv,64] tensors (what get_foreground2D yields per image scale)."""
+        B = len(points)
+        feats, _, coors = voxelize_batch(self.pts_voxel_layer, points, 1.0, self.base_voxel_size,
+                                         fused_mean=True)
+        x, encode_features = self.pts_middle_encoder(feats, coors, B)
+        v3, v2, s3, s2 = [], [], [], []
+        for i in range(4):
+            voxel_2D = virtual_points_to_voxels(self.pts_voxel_layer, virtual_points_per_stage[i],
+                                                self.spatial_shapes[i], self.downscale_factors[i],
+                                                B, self.base_voxel_size)
+            a, b, pa, pb = voxel_modality_split(encode_features[i].shadow_copy(), voxel_2D, B)
+            v3.append(a); v2.append(b); s3.append(pa); s2.append(pb)
+        stage_outs = self.multimodal_middle_encoder(
+            v3, v2, s3, s2, self.fps_num_list, self.radius_list, self.max_cluster_samples_list,
+            self.dist_thresh_list)
+        mm = stage_outs[-1].dense()
+        n, c, d, h, w = mm.shape
+        return x, mm.view(n, c * d, h, w)

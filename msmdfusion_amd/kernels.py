@@ -155,6 +155,26 @@ def pack_weight(weight_kio, transpose=False):
     return packed
 
 
+# bench.py sets this to a list to time individual launches with events recorded
+# on the launch stream: entries are (kind, start_event, end_event, meta).
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _prof_end(kind, start, **meta):
+    if start is not None:
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        PROFILE.append((kind, start, end, meta))
+
+
 def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False):
     """out[o] = sum_k feat[nbr[k,o]] @ W[k]  (implicit GEMM on MFMA)."""
     _need_cuda(feat, packed_weight, nbr)
@@ -162,9 +182,11 @@ def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False):
     n_in, c_in = f.shape
     kvol, ld = nbr.shape
     out = torch.empty((n_out, c_out), dtype=torch.float32, device=f.device)
+    ev = _prof_begin()
     check(lib.msmd_spconv_fwd_f32(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld, int(n_out),
                                   kvol, int(bool(weight_flip)), _p(out), int(c_out), _stream()),
           "msmd_spconv_fwd_f32")
+    _prof_end("spconv_fwd", ev, nbr=nbr, c_in=c_in, c_out=int(c_out), n_in=n_in, n_out=int(n_out))
     return out
 
 
@@ -177,8 +199,10 @@ def conv_wgrad(feat, d_out, pairs, num):
     dw = torch.empty((kvol, c_in, c_out), dtype=torch.float32, device=f.device)
     nbytes = lib.msmd_spconv_wgrad_workspace_bytes(kvol, ld, c_in, c_out)
     ws = _ws(nbytes, f.device)
+    ev = _prof_begin()
     check(lib.msmd_spconv_wgrad_f32(_p(f), c_in, _p(g), c_out, _p(pairs), _p(num), ld, kvol,
                                     _p(dw), _p(ws), nbytes, _stream()), "msmd_spconv_wgrad_f32")
+    _prof_end("spconv_wgrad", ev, num=num, c_in=c_in, c_out=c_out)
     return dw
 
 

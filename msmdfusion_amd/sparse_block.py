@@ -1,0 +1,72 @@
+"""SparseBasicBlock / make_sparse_convmodule: mmdet3d/ops/sparse_block.py:68-191.
+
+mmdet's BasicBlock (parent of SparseBasicBlock, sparse_block.py:6,94-101) is not
+in the reference tree; its constructor is restated from SURVEY Appendix C: conv1
+/ conv2 from build_conv_layer (3x3x3, bias=False), norms registered as
+`bn1`/`bn2` (build_norm_layer postfix 1|2) and exposed as norm1/norm2, ReLU
+in place -- hence checkpoint keys `...conv1.weight`, `...bn1.running_mean`."""
+from torch import nn
+
+from . import spconv
+from .registry import build_conv_layer, build_norm_layer
+
+
+class SparseBasicBlock(spconv.SparseModule):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, conv_cfg=None,
+                 norm_cfg=None):
+        super().__init__()
+        norm_cfg = dict(type="BN") if norm_cfg is None else norm_cfg
+        self.norm1_name, norm1 = build_norm_layer(norm_cfg, planes, postfix=1)
+        self.norm2_name, norm2 = build_norm_layer(norm_cfg, planes, postfix=2)
+        self.conv1 = build_conv_layer(conv_cfg, inplanes, planes, 3, stride=stride, padding=1,
+                                      dilation=1, bias=False)
+        self.add_module(self.norm1_name, norm1)
+        self.conv2 = build_conv_layer(conv_cfg, planes, planes, 3, padding=1, bias=False)
+        self.add_module(self.norm2_name, norm2)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    @property
+    def norm1(self):
+        return getattr(self, self.norm1_name)
+
+    @property
+    def norm2(self):
+        return getattr(self, self.norm2_name)
+
+    def forward(self, x):  # sparse_block.py:103-126
+        identity = x.features
+        assert x.features.dim() == 2, f"x.features.dim()={x.features.dim()}"
+        out = self.conv1(x)
+        out = out.replace_feature(self.norm1(out.features))
+        out = out.replace_feature(self.relu(out.features))
+        out = self.conv2(out)
+        out = out.replace_feature(self.norm2(out.features))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out = out.replace_feature(out.features + identity)
+        out = out.replace_feature(self.relu(out.features))
+        return out
+
+
+def make_sparse_convmodule(in_channels, out_channels, kernel_size, indice_key, stride=1,
+                           padding=0, conv_type="SubMConv3d", norm_cfg=None,
+                           order=("conv", "norm", "act")):
+    """sparse_block.py:129-191: SparseSequential(conv, BN1d, ReLU) -- children
+    named '0','1','2'."""
+    assert isinstance(order, tuple) and len(order) <= 3
+    assert set(order) | {"conv", "norm", "act"} == {"conv", "norm", "act"}
+    conv_cfg = dict(type=conv_type, indice_key=indice_key)
+    layers = []
+    for layer in order:
+        if layer == "conv":
+            layers.append(build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size,
+                                           stride=stride, padding=padding, bias=False))
+        elif layer == "norm":
+            layers.append(build_norm_layer(norm_cfg, out_channels)[1])
+        elif layer == "act":
+            layers.append(nn.ReLU(inplace=True))
+    return spconv.SparseSequential(*layers)

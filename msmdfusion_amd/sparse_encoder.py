@@ -1,0 +1,89 @@
+"""SparseEncoder: the LiDAR sparse backbone of TransFusion-L / MSMDFusion
+(mmdet3d/models/middle_encoders/sparse_encoder.py:10-209; layer table in
+SURVEY Appendix A.1).  Same constructor arguments, same module tree (so
+state_dict keys match: conv_input.0.weight,
+encoder_layers.encoder_layer1.0.conv1.weight, ...), same return value
+(spatial_features[B, C*D, H, W], encode_features list -- this fork's change at
+sparse_encoder.py:117-133)."""
+from torch import nn
+
+from . import spconv
+from .registry import MIDDLE_ENCODERS
+from .sparse_block import SparseBasicBlock, make_sparse_convmodule
+
+
+@MIDDLE_ENCODERS.register_module()
+class SparseEncoder(nn.Module):
+
+    def __init__(self, in_channels, sparse_shape, order=("conv", "norm", "act"),
+                 norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01), base_channels=16,
+                 output_channels=128,
+                 encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                 encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)),
+                 block_type="conv_module"):
+        super().__init__()
+        assert block_type in ["conv_module", "basicblock"]
+        assert isinstance(order, tuple) and len(order) == 3
+        assert set(order) == {"conv", "norm", "act"}
+        self.sparse_shape = sparse_shape
+        self.in_channels = in_channels
+        self.order = order
+        self.base_channels = base_channels
+        self.output_channels = output_channels
+        self.encoder_channels = encoder_channels
+        self.encoder_paddings = encoder_paddings
+        self.stage_num = len(encoder_channels)
+        self.fp16_enabled = False
+
+        input_order = ("conv",) if order[0] != "conv" else order   # pre- vs post-activation
+        self.conv_input = make_sparse_convmodule(
+            in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1, indice_key="subm1",
+            conv_type="SubMConv3d", order=input_order)
+        encoder_out_channels = self.make_encoder_layers(
+            make_sparse_convmodule, norm_cfg, base_channels, block_type=block_type)
+        self.conv_out = make_sparse_convmodule(
+            encoder_out_channels, output_channels, kernel_size=(3, 1, 1), stride=(2, 1, 1),
+            norm_cfg=norm_cfg, padding=0, indice_key="spconv_down2", conv_type="SparseConv3d")
+
+    def forward(self, voxel_features, coors, batch_size):
+        """voxel_features [N,C] fp32, coors [N,4] (b,z,y,x) -> (BEV, stage outputs)."""
+        x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size)
+        x = self.conv_input(x)
+        encode_features = [x]
+        for encoder_layer in self.encoder_layers:
+            x = encoder_layer(x)
+            encode_features.append(x)
+        out = self.conv_out(encode_features[-1])
+        spatial_features = out.dense()
+        n, c, d, h, w = spatial_features.shape
+        return spatial_features.view(n, c * d, h, w), encode_features
+
+    def make_encoder_layers(self, make_block, norm_cfg, in_channels, block_type="conv_module",
+                            conv_cfg=dict(type="SubMConv3d")):
+        """sparse_encoder.py:135-209.  In 'basicblock' mode every block but a
+        stage's last is a SparseBasicBlock (two SubM convs WITHOUT indice_key);
+        the last block of stages 1..n-1 is the stride-2 SparseConv3d."""
+        self.encoder_layers = spconv.SparseSequential()
+        out_channels = in_channels
+        last_stage = len(self.encoder_channels) - 1
+        for i, blocks in enumerate(self.encoder_channels):
+            blocks = tuple(blocks)
+            stage = []
+            for j, out_channels in enumerate(blocks):
+                padding = tuple(self.encoder_paddings[i])[j]
+                downsample = dict(stride=2, padding=padding, indice_key=f"spconv{i + 1}",
+                                  conv_type="SparseConv3d")
+                if block_type == "conv_module":
+                    kw = downsample if (i != 0 and j == 0) else dict(
+                        padding=padding, indice_key=f"subm{i + 1}", conv_type="SubMConv3d")
+                    stage.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, **kw))
+                elif j == len(blocks) - 1 and i != last_stage:
+                    stage.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg,
+                                            **downsample))
+                else:
+                    stage.append(SparseBasicBlock(out_channels, out_channels, norm_cfg=norm_cfg,
+                                                  conv_cfg=conv_cfg))
+                in_channels = out_channels
+            self.encoder_layers.add_module(f"encoder_layer{i + 1}",
+                                           spconv.SparseSequential(*stage))
+        return out_channels

@@ -1,0 +1,12 @@
+"""Drop-in for the slice of `spconv.pytorch` the reference's hot path imports
+(`import spconv.pytorch as spconv`, `from spconv.pytorch import functional as Fsp`:
+mmdet3d/models/middle_encoders/sparse_encoder.py:6,
+sparse_multimodal_encoder_painting.py:7,12, mmdet3d/ops/sparse_block.py:5,
+mmdet3d/models/detectors/MSMDFusion.py:15).  SURVEY Appendix C lists the surface."""
+from . import functional
+from .conv import ConvAlgo, SparseConv3d, SparseConvolution, SubMConv3d
+from .core import IndiceData, SparseConvTensor
+from .modules import SparseModule, SparseSequential, ToDense
+
+__all__ = ["functional", "ConvAlgo", "SparseConv3d", "SparseConvolution", "SubMConv3d",
+           "IndiceData", "SparseConvTensor", "SparseModule", "SparseSequential", "ToDense"]

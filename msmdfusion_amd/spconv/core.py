@@ -1,0 +1,147 @@
+"""SparseConvTensor and rulebook cache.
+
+Mirrors the spconv-2.x type the reference call sites construct and mutate
+(legacy twin mmdet3d/ops/spconv/structure.py:21-69):
+SparseConvTensor(features, indices, spatial_shape, batch_size) with
+.features/.indices/.spatial_shape/.batch_size/.indice_dict, .replace_feature(),
+.dense(), .find_indice_pair(), assignable .indices (MSMDFusion.py:322-323).
+"""
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .. import kernels as K
+
+
+class IndiceData:
+    """One rulebook (spconv-2.x ImplicitGemmIndiceData's role,
+    bug_fix/conv.py:416-436): the output-stationary neighbour tables plus,
+    built lazily for the weight gradient, the reference-format pair lists."""
+
+    def __init__(self, out_indices, indices, nbr_fwd, nbr_bwd, is_subm, spatial_shape,
+                 out_spatial_shape, ksize, stride, padding, dilation, algo=None):
+        self.out_indices = out_indices
+        self.indices = indices
+        self.nbr_fwd = nbr_fwd          # [K, n_out]
+        self.nbr_bwd = nbr_bwd          # [K, n_in]; None for SubM (fwd table, flipped)
+        self.is_subm = is_subm
+        self.spatial_shape = spatial_shape
+        self.out_spatial_shape = out_spatial_shape
+        self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
+        self.algo = algo
+        self._pairs = None
+
+    @property
+    def n_in(self):
+        return self.indices.shape[0]
+
+    @property
+    def n_out(self):
+        return self.out_indices.shape[0]
+
+    def pairs(self):
+        """(indice_pairs[K,2,ld], indice_num[K]) -- spconv_ops.h:55-59 format."""
+        if self._pairs is None:
+            self._pairs = K.rulebook_pairs(self.nbr_fwd, ld=max(self.n_in, self.n_out, 1))
+        return self._pairs
+
+
+def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,
+                   algo=None):
+    if any(d != 1 for d in dilation):
+        raise NotImplementedError("only dilation 1 is built (all reference configs use it)")
+    if subm:
+        if any(k % 2 == 0 for k in ksize):
+            raise NotImplementedError("SubM needs odd kernel sizes")
+        nbr = K.rulebook_subm(indices, batch_size, spatial_shape, ksize)
+        return IndiceData(indices, indices, nbr, None, True, list(spatial_shape),
+                          list(spatial_shape), ksize, [1, 1, 1], [k // 2 for k in ksize],
+                          dilation, algo)
+    out_idx, nbr_fwd, nbr_bwd, out_shape = K.rulebook_conv(indices, batch_size, spatial_shape,
+                                                           ksize, stride, padding)
+    return IndiceData(out_idx, indices, nbr_fwd, nbr_bwd, False, list(spatial_shape),
+                      list(out_shape), ksize, stride, padding, dilation, algo)
+
+
+class SparseConvTensor:
+
+    def __init__(self, features: torch.Tensor, indices: torch.Tensor,
+                 spatial_shape: List[int], batch_size: int, grid=None, voxel_num=None,
+                 indice_dict: Optional[dict] = None, benchmark: bool = False):
+        assert features.dim() == 2 and indices.dim() == 2
+        assert indices.dtype == torch.int32, "indices must be int32 (b,z,y,x)"
+        self._features = features
+        self.indices = indices
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = {} if indice_dict is None else indice_dict
+        self.grid = grid
+        self.voxel_num = voxel_num
+        self.benchmark = benchmark
+        self.benchmark_record = {}
+        self._timer = None
+        self.thrust_allocator = None
+        # rulebooks keyed by geometry + the identity of the indices tensor:
+        # a rulebook depends on nothing else, so every SubM conv over the same
+        # voxel set shares one (the reference rebuilds it for each of the 16
+        # indice_key=None convs of SparseEncoder).  Results are identical.
+        self._rb_cache = {}
+
+    # spconv 2.x forbids `x.features = ...` (hence replace_feature); the legacy
+    # type allowed it.  Both spellings work here.
+    @property
+    def features(self):
+        return self._features
+
+    @features.setter
+    def features(self, val):
+        self._features = val
+
+    def replace_feature(self, feature: torch.Tensor):
+        new = self.shadow_copy()
+        new._features = feature
+        return new
+
+    def shadow_copy(self):
+        new = SparseConvTensor(self._features, self.indices, self.spatial_shape, self.batch_size,
+                               self.grid, self.voxel_num, self.indice_dict, self.benchmark)
+        new.benchmark_record = self.benchmark_record
+        new._timer = self._timer
+        new.thrust_allocator = self.thrust_allocator
+        new._rb_cache = self._rb_cache
+        return new
+
+    @property
+    def spatial_size(self):
+        return int(np.prod(self.spatial_shape))
+
+    @property
+    def sparity(self):
+        return self.indices.shape[0] / np.prod(self.spatial_shape) / self.batch_size
+
+    def find_indice_pair(self, key) -> Optional[IndiceData]:
+        if key is None:
+            return None
+        return self.indice_dict.get(key)
+
+    def cached_rulebook(self, ksize, stride, padding, dilation, subm):
+        ident = (self.indices.data_ptr(), self.indices.shape[0], tuple(self.spatial_shape),
+                 tuple(ksize), tuple(stride), tuple(padding), tuple(dilation), bool(subm))
+        hit = self._rb_cache.get(ident)
+        if hit is not None and hit.indices is self.indices:
+            return hit
+        rb = build_rulebook(self.indices, self.batch_size, self.spatial_shape, list(ksize),
+                            list(stride), list(padding), list(dilation), subm)
+        self._rb_cache[ident] = rb
+        return rb
+
+    def dense(self, channels_first: bool = True):
+        """[B,C,D,H,W] (structure.py:55-64); channels_last returns the permuted
+        view of the same buffer."""
+        from .functional import dense as _dense
+        out = _dense(self._features, self.indices, self.batch_size, self.spatial_shape)
+        if channels_first:
+            return out
+        nd = len(self.spatial_shape)
+        return out.permute(0, *range(2, nd + 2), 1).contiguous()

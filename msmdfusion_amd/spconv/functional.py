@@ -1,0 +1,94 @@
+"""Autograd glue over the C ABI: the role of spconv.pytorch.functional
+(legacy twin: mmdet3d/ops/spconv/functional.py:20-75).
+
+Weights arrive as [K, Cin, Cout] (the layout indiceConv contracts with,
+spconv_ops.h:299); modules keep their parameter in spconv-2.x's KRSC layout
+and hand a permuted view in, so autograd maps the gradient back.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import kernels as K
+
+
+class _SparseConvFunction(Function):
+    """indice_conv / indice_subm_conv / implicit_gemm in one: forward and dgrad
+    are the same implicit-GEMM kernel, wgrad contracts over the pair lists."""
+
+    @staticmethod
+    def forward(ctx, features, weight_kio, rb):
+        ctx.rb = rb
+        ctx.save_for_backward(features, weight_kio)
+        packed = K.pack_weight(weight_kio)
+        return K.conv_forward(features, packed, rb.nbr_fwd, rb.n_out, weight_kio.shape[2])
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        features, weight_kio = ctx.saved_tensors
+        rb = ctx.rb
+        grad_out = grad_out.contiguous()
+        d_feat = d_w = None
+        if ctx.needs_input_grad[0]:
+            packed_t = K.pack_weight(weight_kio, transpose=True)
+            if rb.is_subm:   # forward table + flipped weights == backward table
+                d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_fwd, rb.n_in,
+                                        weight_kio.shape[1], weight_flip=True)
+            else:
+                d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_bwd, rb.n_in,
+                                        weight_kio.shape[1])
+        if ctx.needs_input_grad[1]:
+            pairs, num = rb.pairs()
+            d_w = K.conv_wgrad(features, grad_out, pairs, num)
+        return d_feat, d_w, None
+
+
+def sparse_conv(features, weight_kio, rb):
+    return _SparseConvFunction.apply(features, weight_kio, rb)
+
+
+class _DenseFunction(Function):
+    @staticmethod
+    def forward(ctx, features, indices, batch_size, spatial_shape):
+        ctx.save_for_backward(indices)
+        ctx.shape = list(spatial_shape)
+        return K.dense_scatter(features, indices, batch_size, spatial_shape)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (indices,) = ctx.saved_tensors
+        return K.dense_gather(grad.contiguous(), indices, ctx.shape), None, None, None
+
+
+def dense(features, indices, batch_size, spatial_shape):
+    return _DenseFunction.apply(features, indices, batch_size, spatial_shape)
+
+
+class _SparseAddFunction(Function):
+    @staticmethod
+    def forward(ctx, fa, ia, fb, ib, batch_size, spatial_shape):
+        oi, of, ma, mb = K.sparse_add(fa, ia, fb, ib, batch_size, spatial_shape)
+        ctx.save_for_backward(ma, mb)
+        ctx.mark_non_differentiable(oi)
+        return of, oi
+
+    @staticmethod
+    def backward(ctx, g_feat, _g_idx):
+        ma, mb = ctx.saved_tensors
+        g = g_feat.contiguous()
+        return g.index_select(0, ma.long()), None, g.index_select(0, mb.long()), None, None, None
+
+
+def sparse_add(*tensors):
+    """spconv.pytorch.functional.sparse_add (call site
+    sparse_multimodal_encoder_painting.py:455): union of the operands' voxel
+    sets in ascending linear id, features summed where they coincide."""
+    from .core import SparseConvTensor
+    assert len(tensors) >= 2
+    acc = tensors[0]
+    for other in tensors[1:]:
+        assert acc.spatial_shape == other.spatial_shape, "sparse_add needs equal spatial_shape"
+        assert acc.batch_size == other.batch_size
+        feat, idx = _SparseAddFunction.apply(acc.features, acc.indices, other.features,
+                                             other.indices, acc.batch_size, acc.spatial_shape)
+        acc = SparseConvTensor(feat, idx, acc.spatial_shape, acc.batch_size)
+    return acc

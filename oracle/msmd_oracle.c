@@ -231,6 +231,7 @@ ORC_API int orc_get_indice_pairs(const int32_t* indices, int n, int batch,
  * ------------------------------------------------------------------------- */
 static void mm_acc(const float* a, const float* b, float* c, int m, int k,
                    int n) { /* c[m,n] += a[m,k] b[k,n] */
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < m; ++i)
     for (int p = 0; p < k; ++p) {
       float av = a[(size_t)i * k + p];
@@ -265,11 +266,14 @@ ORC_API void orc_indice_conv_fwd(const float* feat, int n_in, int cin,
     if (hot <= 0 || (subm && k == centre)) continue;
     const int32_t* gi = pairs + ((size_t)k * 2 + (inverse ? 1 : 0)) * ld;
     const int32_t* si = pairs + ((size_t)k * 2 + (inverse ? 0 : 1)) * ld;
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < hot; ++i)
       memcpy(ibuf + (size_t)i * cin, feat + (size_t)gi[i] * cin,
              sizeof(float) * cin);
     memset(obuf, 0, sizeof(float) * (size_t)hot * cout);
     mm_acc(ibuf, filters + (size_t)k * cin * cout, obuf, hot, cin, cout);
+    /* within one offset every output row appears once (reordering.cu.h:99) */
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < hot; ++i) {
       float* o = out + (size_t)si[i] * cout;
       const float* b = obuf + (size_t)i * cout;
@@ -301,22 +305,31 @@ ORC_API void orc_indice_conv_bwd(const float* feat, int n_in, int cin,
     const int32_t* go = pairs + ((size_t)k * 2 + (inverse ? 0 : 1)) * ld;
     const float* w = filters + (size_t)k * cin * cout;
     float* dw = dfilters + (size_t)k * cin * cout;
-    for (int p = 0; p < hot; ++p) {
-      size_t ri = dense ? (size_t)p : (size_t)gi[p];
-      size_t ro = dense ? (size_t)p : (size_t)go[p];
-      const float* x = feat + ri * cin;
-      const float* g = dout + ro * cout;
-      float* dx = din + ri * cin;
-      for (int a = 0; a < cin; ++a) {
-        float xa = x[a], acc = 0.f;
-        const float* wr = w + (size_t)a * cout;
-        float* dwr = dw + (size_t)a * cout;
-        for (int b = 0; b < cout; ++b) {
-          dwr[b] += xa * g[b];
-          acc += g[b] * wr[b];
+#pragma omp parallel
+    {
+      /* per-thread dW partial, summed in thread order below */
+      float* part = (float*)calloc((size_t)cin * cout, sizeof(float));
+#pragma omp for schedule(static)
+      for (int p = 0; p < hot; ++p) {
+        size_t ri = dense ? (size_t)p : (size_t)gi[p];
+        size_t ro = dense ? (size_t)p : (size_t)go[p];
+        const float* x = feat + ri * cin;
+        const float* g = dout + ro * cout;
+        float* dx = din + ri * cin; /* an input row appears once per offset */
+        for (int a = 0; a < cin; ++a) {
+          float xa = x[a], acc = 0.f;
+          const float* wr = w + (size_t)a * cout;
+          float* dwr = part + (size_t)a * cout;
+          for (int b = 0; b < cout; ++b) {
+            dwr[b] += xa * g[b];
+            acc += g[b] * wr[b];
+          }
+          dx[a] += acc;
         }
-        dx[a] += acc;
       }
+#pragma omp critical
+      for (size_t e = 0; e < (size_t)cin * cout; ++e) dw[e] += part[e];
+      free(part);
     }
   }
 }

@@ -146,13 +146,14 @@ def linear_ids(indices, spatial_shape):
     return ((idx[:, 0] * d + idx[:, 1]) * h + idx[:, 2]) * w + idx[:, 3]
 
 
-def canonical_rulebook(out_indices, pairs, num, out_shape):
-    """SURVEY Appendix B.2 canonical form: output rows sorted by linear id;
-    pairs of each offset sorted by (out, in).  Returns
+def canonical_rulebook(out_indices, pairs, num, out_shape, keep_rows=False):
+    """SURVEY Appendix B.2 canonical form: output rows sorted by linear id
+    (keep_rows=True for SubM, whose output rows ARE the input rows, in input
+    order); pairs of each offset sorted by (out, in).  Returns
     (out_indices_sorted, [array[P_k,2] (in,out) per offset], perm) where
     perm[new_row] = old_row."""
     lid = linear_ids(out_indices, out_shape)
-    perm = np.argsort(lid, kind="stable")
+    perm = np.arange(lid.size) if keep_rows else np.argsort(lid, kind="stable")
     inv = np.empty_like(perm)
     inv[perm] = np.arange(perm.size)
     per_offset = []

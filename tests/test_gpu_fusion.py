@@ -1,0 +1,183 @@
+"""GPU parity of the GMA-Conv / multimodal path
+against the oracle composed step by step as the reference composes it
+(sparse_multimodal_encoder_painting.py:276-459, MSMDFusion.py:251-325)."""
+import numpy as np
+import pytest
+import torch
+
+from msmdfusion_amd import synthetic as S
+from oracle import oracle as O
+from test_gpu_modules import OracleSparse, _np, oracle_forward
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_fps_nn(query, key, fps_num, radius, max_cluster, thresh):
+    """fps_NN_fast (:276-323) with oracle pieces."""
+    nq = query.shape[0]
+    if nq <= fps_num:
+        return O.nn_search(query[:, 1:], key[:, 1:], thresh)
+    q = query[:, 1:].astype(np.float32)[None]
+    rep_idx = O.furthest_point_sample(q, fps_num)[0]
+    rep = query[rep_idx, 1:]
+    rep_nn = O.nn_search(rep, key[:, 1:], thresh)
+    grp = O.ball_query(0, radius, max_cluster, q, rep.astype(np.float32)[None])[0]
+    return O.nn_assign(grp, rep_nn, nq)
+
+
+def test_fps_nn_fast(dev):
+    from msmdfusion_amd.multimodal_encoder import fps_nn_fast
+    rng = np.random.RandomState(0)
+    shape = [41, 400, 400]
+    key = S.random_voxel_indices(9000, 1, shape, seed=1)
+    for nq, fps_num in [(500, 2048), (6000, 512)]:
+        query = S.random_voxel_indices(nq, 1, shape, seed=2 + nq)
+        exp = _oracle_fps_nn(query, key, fps_num, 6, 50, 13.3)
+        got = fps_nn_fast(torch.from_numpy(query).to(dev), torch.from_numpy(key).to(dev),
+                          fps_num, 6, 50, 13.3)
+        assert np.array_equal(_np(got), exp)
+        assert (exp >= 0).any() and (exp < 0).any() or nq <= fps_num
+
+
+def _make_inputs(dev, shape, n3, n2, c3, batch, seed):
+    rng = np.random.RandomState(seed)
+    i3 = S.random_voxel_indices(n3, batch, shape, seed=seed)
+    extra = S.random_voxel_indices(n2, batch, shape, seed=seed + 50)
+    i2 = np.concatenate([i3[::5], extra])
+    i2 = i2[np.sort(np.unique(i2, axis=0, return_index=True)[1])]
+    # group rows by sample (the reference's tensors always are)
+    i3 = i3[np.argsort(i3[:, 0], kind="stable")]
+    i2 = i2[np.argsort(i2[:, 0], kind="stable")]
+    f3 = rng.randn(i3.shape[0], c3).astype(np.float32)
+    f2 = rng.randn(i2.shape[0], 64).astype(np.float32)
+    return i3, f3, i2, f2
+
+
+def test_modality_split_function(dev):
+    from msmdfusion_amd import spconv
+    from msmdfusion_amd.fusion import voxel_modality_split
+    shape = [21, 100, 100]
+    i3, f3, i2, f2 = _make_inputs(dev, shape, 2500, 1500, 32, 2, 3)
+    a = spconv.SparseConvTensor(torch.from_numpy(f3).to(dev), torch.from_numpy(i3).to(dev), shape, 2)
+    b = spconv.SparseConvTensor(torch.from_numpy(f2).to(dev), torch.from_numpy(i2).to(dev), shape, 2)
+    a, b, s3, s2 = voxel_modality_split(a, b, 2)
+    assert a.indices.shape[1] == 5 and b.indices.shape[1] == 5
+    e3, e2, p3, p2 = [], [], [], []
+    for bi in range(2):
+        r3, r2 = np.flatnonzero(i3[:, 0] == bi), np.flatnonzero(i2[:, 0] == bi)
+        m3, m2, q3, q2 = O.modality_split(i3[r3, 1:], i2[r2, 1:], shape)
+        e3.append(m3); e2.append(m2); p3.append(r3[q3]); p2.append(r2[q2])
+    assert np.array_equal(_np(a.indices)[:, 1], np.concatenate(e3))
+    assert np.array_equal(_np(b.indices)[:, 1], np.concatenate(e2))
+    assert np.array_equal(_np(a.indices)[:, [0, 2, 3, 4]], i3)
+    assert np.array_equal(_np(s3), np.concatenate(p3)) and np.array_equal(_np(s2), np.concatenate(p2))
+    # matched rows really are the same voxel
+    assert np.array_equal(i3[_np(s3)], i2[_np(s2)])
+    # the reference's float32 keys agree with exact keys where they cannot alias (z<=15, x<1000)
+    lo3, lo2 = i3[(i3[:, 0] == 0) & (i3[:, 1] <= 15)], i2[(i2[:, 0] == 0) & (i2[:, 1] <= 15)]
+    fm = O.modality_split(lo3[:, 1:], lo2[:, 1:], shape, float_keys=True)
+    xm = O.modality_split(lo3[:, 1:], lo2[:, 1:], shape, float_keys=False)
+    assert all(np.array_equal(x, y) for x, y in zip(fm, xm))
+
+
+def _oracle_stage(enc, stage, i3, f3, i2, f2, shape, batch, dummy, fps_num, radius, mcs, thresh):
+    """grouped_sparse_conv (:325-430) with numpy + oracle ops."""
+    e3, e2, p3, p2 = [], [], [], []
+    for bi in range(batch):
+        r3, r2 = np.flatnonzero(i3[:, 0] == bi), np.flatnonzero(i2[:, 0] == bi)
+        m3, m2, q3, q2 = O.modality_split(i3[r3, 1:], i2[r2, 1:], shape)
+        e3.append(m3); e2.append(m2); p3.append(r3[q3]); p2.append(r2[q2])
+    mix3, mix2 = np.concatenate(e3), np.concatenate(e2)
+    s3, s2 = np.concatenate(p3), np.concatenate(p2)
+    o2_idx, o2_feat = i2[mix2 == 0], f2[mix2 == 0]
+    nn3 = np.full(o2_idx.shape[0], -1, np.int64)
+    base = 0
+    for bi in range(batch):
+        m2, m3 = o2_idx[:, 0] == bi, i3[:, 0] == bi
+        r = _oracle_fps_nn(o2_idx[m2], i3[m3], fps_num, radius, mcs, thresh).astype(np.int64)
+        nn3[m2] = np.where(r >= 0, r + base, r)
+        base += int(m3.sum())
+    lin = enc.cross_gate_control[stage][0]
+    cg = np.maximum(np.concatenate([f3, dummy]) @ _np(lin.weight).T + _np(lin.bias), 0)
+    o2_feat = cg[nn3] * o2_feat            # -1 -> last row, like the reference
+    only3 = OracleSparse(f3[mix3 == 0], i3[mix3 == 0], shape, batch)
+    lin = enc.gate_control[stage][0]
+    m3f, m2f = f3[s3], f2[s2]
+    m2f = np.maximum(m3f @ _np(lin.weight).T + _np(lin.bias), 0) * m2f
+    mixed_feat, mixed_idx = np.concatenate([m3f, m2f], 1), i2[s2]
+    name = f"stage_{stage + 1}"
+    only3 = oracle_forward(getattr(enc.grouped_sp_conv_blocks_3D, name), only3)
+    c3 = f3.shape[1]
+    uf = np.concatenate([np.pad(only3.feat, ((0, 0), (0, 64))), np.pad(o2_feat, ((0, 0), (c3, 0))),
+                         mixed_feat]).astype(np.float32)
+    ui = np.concatenate([only3.idx, o2_idx, mixed_idx]).astype(np.int32)
+    return oracle_forward(getattr(enc.aggregation_blocks, name), OracleSparse(uf, ui, shape, batch))
+
+
+@pytest.mark.parametrize("stage,n2,fps_num", [(0, 1500, 2048), (1, 4000, 512)])
+def test_gma_conv_stage_matches_oracle(dev, stage, n2, fps_num):
+    from msmdfusion_amd import spconv
+    from msmdfusion_amd.fusion import voxel_modality_split
+    from msmdfusion_amd.multimodal_encoder import SparseMultiModalEncoderPaint
+    torch.manual_seed(0)
+    enc = SparseMultiModalEncoderPaint(in_channels_2D=(64,) * 4, padding=(1, 1, [0, 1, 1], 0)) \
+        .to(dev).train()
+    c3 = enc.in_channels_3D[stage]
+    shape, batch = [21, 120, 120], 2
+    i3, f3, i2, f2 = _make_inputs(dev, shape, 3000, n2, c3, batch, 10 + stage)
+    dummy = np.random.RandomState(5).rand(1, c3).astype(np.float32)
+    enc.dummy_embedding_fn = lambda c, device: torch.from_numpy(dummy).to(device)
+    a = spconv.SparseConvTensor(torch.from_numpy(f3).to(dev), torch.from_numpy(i3).to(dev), shape, batch)
+    b = spconv.SparseConvTensor(torch.from_numpy(f2).to(dev), torch.from_numpy(i2).to(dev), shape, batch)
+    a, b, s3, s2 = voxel_modality_split(a, b, batch)
+    out = enc.grouped_sparse_conv(a, b, s3, s2, stage, fps_num, 6, 50, 13.3)
+    exp = _oracle_stage(enc, stage, i3, f3, i2, f2, shape, batch, dummy, fps_num, 6, 50, 13.3)
+    assert np.array_equal(_np(out.indices), exp.idx)
+    np.testing.assert_allclose(_np(out.features), exp.feat, rtol=1e-3, atol=3e-4)
+
+
+def test_sparse_fusion_path_end_to_end(dev):
+    """LC sparse path on small synthetic inputs: shapes, finiteness, autograd,
+    determinism with a pinned dummy embedding, checkpoint key names."""
+    from msmdfusion_amd.fusion import SparseFusionPath
+    from msmdfusion_amd.registry import build_middle_encoder
+    from msmdfusion_amd.voxelize import Voxelization
+    torch.manual_seed(0)
+    vox = Voxelization(S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, (120000, 160000))
+    enc = build_middle_encoder(dict(
+        type="SparseEncoder", in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128,
+        order=("conv", "norm", "act"),
+        encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+        encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)), block_type="basicblock"))
+    mm = build_middle_encoder(dict(          # configs/MSMDFusion_nusc_voxel_LC.py:182-190
+        type="SparseMultiModalEncoderPaint", in_channels_3D=(16, 32, 64, 128),
+        in_channels_2D=(64, 64, 64, 64), out_channels=(32, 64, 128, 128),
+        padding=(1, 1, [0, 1, 1], 0), order=("conv", "norm", "act"),
+        norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01)))
+    path = SparseFusionPath(vox, enc, mm).to(dev).train()
+    keys = set(path.state_dict().keys())
+    for k in ["multimodal_middle_encoder.aggregation_blocks.stage_1.conv1.weight",
+              "multimodal_middle_encoder.grouped_sp_conv_blocks_3D.stage_2.0.weight",
+              "multimodal_middle_encoder.grouped_sp_conv_blocks_2D.stage_1.0.weight",
+              "multimodal_middle_encoder.grouped_sp_conv_blocks_mix.stage_4.bn2.weight",
+              "multimodal_middle_encoder.gate_control.0.0.weight",
+              "multimodal_middle_encoder.cross_gate_control.3.0.bias",
+              "multimodal_middle_encoder.downscale_blocks.stage_4.0.weight",
+              "pts_middle_encoder.conv_input.0.weight"]:
+        assert k in keys, k
+    assert path.state_dict()["multimodal_middle_encoder.downscale_blocks.stage_4.0.weight"].shape \
+        == (192, 3, 1, 1, 192)
+    fixed = {c: torch.rand(1, c) for c in (16, 32, 64, 128)}
+    mm.dummy_embedding_fn = lambda c, device: fixed[c].to(device)
+    pts = [torch.from_numpy(S.lidar_sweep(i, n_az=300)).to(dev) for i in range(2)]
+    virt = [torch.from_numpy(S.virtual_points(i, n=12000)).to(dev) for i in range(2)]
+    x, x_mm = path(pts, [virt] * 4)
+    assert x.shape == (2, 256, 180, 180) and x_mm.shape == (2, 384, 180, 180)
+    assert torch.isfinite(x).all() and torch.isfinite(x_mm).all() and x_mm.abs().sum() > 0
+    x2, x_mm2 = path(pts, [virt] * 4)
+    assert torch.equal(x_mm, x_mm2)
+    (x.mean() + x_mm.mean()).backward()
+    used = [n for n, p in path.named_parameters() if p.grad is not None]
+    dead = [n for n, p in path.named_parameters() if p.grad is None]
+    assert all(("blocks_2D" in n or "blocks_mix" in n) for n in dead), dead   # built, never called
+    assert any("gate_control" in n for n in used)

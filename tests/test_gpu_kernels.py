@@ -95,7 +95,7 @@ def _check_rulebook(dev, idx, batch, shape, subm, ks, st, pd):
         assert np.array_equal(nbr.cpu().numpy(), exp)
         pairs, num = K.rulebook_pairs(nbr)
         assert np.array_equal(num.cpu().numpy(), nm)
-        _, can, _ = O.canonical_rulebook(oi, pr, nm, osz)
+        _, can, _ = O.canonical_rulebook(oi, pr, nm, osz, keep_rows=True)
         got = pairs.cpu().numpy()
         for k in range(nm.shape[0]):
             p = int(nm[k])

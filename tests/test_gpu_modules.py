@@ -1,0 +1,199 @@
+"""GPU parity of the module layer (the mirror of the reference's mmdet3d /
+spconv API) against the oracle composed the way the reference composes it."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from msmdfusion_amd import synthetic as S
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+class OracleSparse:
+    def __init__(self, feat, idx, shape, batch):
+        self.feat, self.idx, self.shape, self.batch = feat, idx, list(shape), batch
+
+
+def oracle_forward(module, x):
+    """Walk a module tree with oracle ops: SparseSequential (modules.py:125-137),
+    SparseBasicBlock (sparse_block.py:103-126), conv (spconv_ops.h:260-361),
+    BatchNorm1d with batch statistics, ReLU."""
+    from msmdfusion_amd import spconv
+    from msmdfusion_amd.sparse_block import SparseBasicBlock
+    if isinstance(module, spconv.SparseSequential):
+        for m in module._modules.values():
+            x = oracle_forward(m, x)
+        return x
+    if isinstance(module, SparseBasicBlock):
+        identity = x.feat
+        out = oracle_forward(module.conv1, x)
+        out = oracle_forward(module.norm1, out)
+        out = oracle_forward(module.relu, out)
+        out = oracle_forward(module.conv2, out)
+        out = oracle_forward(module.norm2, out)
+        out.feat = np.maximum(out.feat + identity, 0)
+        return out
+    if isinstance(module, spconv.SparseConvolution):
+        w = _np(module.weight_kio()).copy()
+        oi, pr, nm, osz = O.get_indice_pairs(x.idx, x.batch, x.shape, module.kernel_size,
+                                             module.stride, module.padding, 1, module.subm)
+        out = O.indice_conv_fwd(x.feat, w, pr, nm, oi.shape[0], subm=module.subm)
+        if not module.subm:   # HIP path orders outputs by linear id
+            coi, _, perm = O.canonical_rulebook(oi, pr, nm, osz)
+            oi, out = coi, out[perm]
+        return OracleSparse(out, oi, osz, x.batch)
+    if isinstance(module, nn.BatchNorm1d):
+        f = x.feat.astype(np.float64)
+        if module.training:
+            mean, var = f.mean(0), f.var(0)
+        else:
+            mean, var = _np(module.running_mean), _np(module.running_var)
+        y = (f - mean) / np.sqrt(var + module.eps) * _np(module.weight) + _np(module.bias)
+        return OracleSparse(y.astype(np.float32), x.idx, x.shape, x.batch)
+    if isinstance(module, nn.ReLU):
+        return OracleSparse(np.maximum(x.feat, 0), x.idx, x.shape, x.batch)
+    raise TypeError(type(module))
+
+
+def test_registry_builds_reference_cfg(dev):
+    from msmdfusion_amd import spconv
+    from msmdfusion_amd.registry import build_conv_layer, build_middle_encoder, build_norm_layer
+    conv = build_conv_layer(dict(type="SubMConv3d", indice_key="subm1"), 5, 16, 3, stride=1,
+                            padding=1, bias=False)
+    assert isinstance(conv, spconv.SubMConv3d) and conv.weight.shape == (16, 3, 3, 3, 5)
+    assert conv.bias is None and conv.indice_key == "subm1"
+    name, bn = build_norm_layer(dict(type="BN1d", eps=1e-3, momentum=0.01), 16, postfix=1)
+    assert name == "bn1" and bn.eps == 1e-3 and bn.momentum == 0.01
+    enc = build_middle_encoder(dict(
+        type="SparseEncoder", in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128,
+        order=("conv", "norm", "act"),
+        encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+        encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
+        block_type="basicblock"))
+    keys = set(enc.state_dict().keys())
+    for k in ["conv_input.0.weight", "conv_input.1.running_mean",
+              "encoder_layers.encoder_layer1.0.conv1.weight",
+              "encoder_layers.encoder_layer1.0.bn2.weight",
+              "encoder_layers.encoder_layer1.2.0.weight",
+              "encoder_layers.encoder_layer4.1.conv2.weight", "conv_out.0.weight"]:
+        assert k in keys, k
+    assert enc.encoder_layers.encoder_layer3[2][0].padding == [0, 1, 1]
+    assert enc.conv_out[0].kernel_size == [3, 1, 1] and enc.conv_out[0].stride == [2, 1, 1]
+    n_convs = sum(isinstance(m, spconv.SparseConvolution) for m in enc.modules())
+    assert n_convs == 21     # 17 SubM + 4 strided
+
+
+def test_conv_module_grads(dev):
+    """SubMConv3d / SparseConv3d modules: forward + autograd against the oracle
+    (covers the KRSC <-> [K,Cin,Cout] mapping)."""
+    from msmdfusion_amd import spconv
+    shape = [9, 40, 40]
+    idx = S.random_voxel_indices(800, 2, shape, seed=0)
+    rng = np.random.RandomState(0)
+    f = rng.randn(idx.shape[0], 16).astype(np.float32)
+    for cls, kw in [(spconv.SubMConv3d, dict(kernel_size=3, padding=1)),
+                    (spconv.SparseConv3d, dict(kernel_size=3, stride=2, padding=1))]:
+        torch.manual_seed(0)
+        conv = cls(16, 32, bias=True, indice_key="k", **kw).to(dev)
+        x = torch.from_numpy(f).to(dev).requires_grad_(True)
+        st = spconv.SparseConvTensor(x, torch.from_numpy(idx).to(dev), shape, 2)
+        out = conv(st)
+        g = rng.randn(out.features.shape[0], 32).astype(np.float32)
+        out.features.backward(torch.from_numpy(g).to(dev))
+        w = _np(conv.weight_kio()).copy()
+        oi, pr, nm, osz = O.get_indice_pairs(idx, 2, shape, conv.kernel_size, conv.stride,
+                                             conv.padding, 1, conv.subm)
+        exp = O.indice_conv_fwd(f, w, pr, nm, oi.shape[0], subm=conv.subm)
+        perm = np.arange(oi.shape[0])
+        if not conv.subm:
+            coi, _, perm = O.canonical_rulebook(oi, pr, nm, osz)
+            assert np.array_equal(_np(out.indices), coi)
+        np.testing.assert_allclose(_np(out.features), exp[perm] + _np(conv.bias), rtol=TOL,
+                                   atol=TOL)
+        g_or = np.zeros_like(g)
+        g_or[perm] = g
+        edin, edw = O.indice_conv_bwd(f, w, g_or, pr, nm, subm=conv.subm)
+        np.testing.assert_allclose(_np(x.grad), edin, rtol=TOL, atol=TOL)
+        dw_krsc = edw.transpose(2, 0, 1).reshape(conv.weight.shape)
+        np.testing.assert_allclose(_np(conv.weight.grad), dw_krsc, rtol=TOL, atol=5 * TOL)
+        np.testing.assert_allclose(_np(conv.bias.grad), g.sum(0), rtol=TOL, atol=5 * TOL)
+        assert out.indice_dict["k"].is_subm == conv.subm
+
+
+def test_sparse_encoder_forward_matches_oracle(dev):
+    from msmdfusion_amd.sparse_encoder import SparseEncoder
+    shape = [17, 64, 64]
+    torch.manual_seed(1)
+    enc = SparseEncoder(5, shape, output_channels=32, base_channels=16,
+                        encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64)),
+                        encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0)),
+                        block_type="basicblock").to(dev).train()
+    idx = S.random_voxel_indices(3000, 2, shape, seed=4)
+    f = np.random.RandomState(4).randn(idx.shape[0], 5).astype(np.float32)
+    bev, feats = enc(torch.from_numpy(f).to(dev), torch.from_numpy(idx).to(dev), 2)
+    x = OracleSparse(f, idx, shape, 2)
+    x = oracle_forward(enc.conv_input, x)
+    exp_feats = [x]
+    for layer in enc.encoder_layers:
+        x = oracle_forward(layer, x)
+        exp_feats.append(x)
+    out = oracle_forward(enc.conv_out, exp_feats[-1])
+    assert len(feats) == len(exp_feats)
+    for got, exp in zip(feats, exp_feats):
+        assert np.array_equal(_np(got.indices), exp.idx)
+        assert got.spatial_shape == list(exp.shape)
+        np.testing.assert_allclose(_np(got.features), exp.feat, rtol=1e-3, atol=2e-4)
+    dense = O.dense(out.feat, out.idx, 2, out.shape)
+    np.testing.assert_allclose(_np(bev), dense.reshape(2, -1, out.shape[1], out.shape[2]),
+                               rtol=1e-3, atol=2e-4)
+    # the 12 SubM convs of 3 stages share one rulebook per voxel set
+    (bev.sum()).backward()
+    assert all(p.grad is not None for p in enc.parameters())
+
+
+def test_voxelization_module_and_vfe(dev):
+    from msmdfusion_amd.voxel_encoder import HardSimpleVFE
+    from msmdfusion_amd.voxelize import Voxelization
+    pts = S.lidar_sweep(2, n_az=400)
+    layer = Voxelization(S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, (120000, 160000)).to(dev)
+    layer.voxel_size = [v * 2 for v in S.VOXEL_SIZE]   # MSMDFusion.py:475-478 mutates it
+    v, c, n = layer(torch.from_numpy(pts).to(dev))
+    ev, ec, en = O.hard_voxelize(pts, layer.voxel_size, S.POINT_CLOUD_RANGE, 10, 120000)
+    assert np.array_equal(_np(v), ev) and np.array_equal(_np(c), ec) and np.array_equal(_np(n), en)
+    vfe = HardSimpleVFE(num_features=5)
+    np.testing.assert_allclose(_np(vfe(v, n, c)), O.voxel_mean(ev, en, 5), rtol=1e-6, atol=1e-6)
+    m, c2, n2 = layer.forward_mean(torch.from_numpy(pts).to(dev))
+    np.testing.assert_allclose(_np(m), O.voxel_mean(ev, en, 5), rtol=1e-6, atol=1e-6)
+
+
+def test_sparse_add_functional(dev):
+    from msmdfusion_amd import spconv
+    from msmdfusion_amd.spconv import functional as Fsp
+    shape = [11, 50, 50]
+    a = S.random_voxel_indices(700, 2, shape, seed=8)
+    b = np.concatenate([a[::2], S.random_voxel_indices(500, 2, shape, seed=9)])
+    b = b[np.sort(np.unique(b, axis=0, return_index=True)[1])]
+    rng = np.random.RandomState(3)
+    fa, fb = rng.randn(a.shape[0], 96).astype(np.float32), rng.randn(b.shape[0], 96).astype(np.float32)
+    ta = spconv.SparseConvTensor(torch.from_numpy(fa).to(dev).requires_grad_(True),
+                                 torch.from_numpy(a).to(dev), shape, 2)
+    tb = spconv.SparseConvTensor(torch.from_numpy(fb).to(dev).requires_grad_(True),
+                                 torch.from_numpy(b).to(dev), shape, 2)
+    out = Fsp.sparse_add(ta, tb)
+    eoi, eof, ma, mb = O.sparse_add(fa, a, fb, b, shape)
+    assert np.array_equal(_np(out.indices), eoi)
+    np.testing.assert_allclose(_np(out.features), eof, rtol=1e-6, atol=1e-6)
+    # dense cross-check (independent pin): dense(a)+dense(b) == dense(a+b)
+    d = O.dense(fa, a, 2, shape) + O.dense(fb, b, 2, shape)
+    np.testing.assert_allclose(_np(out.dense()), d, rtol=1e-6, atol=1e-6)
+    g = rng.randn(*eof.shape).astype(np.float32)
+    out.features.backward(torch.from_numpy(g).to(dev))
+    np.testing.assert_allclose(_np(ta.features.grad), g[ma])
+    np.testing.assert_allclose(_np(tb.features.grad), g[mb])
