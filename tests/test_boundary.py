@@ -1,0 +1,102 @@
+"""The drop-in boundary, checked without a GPU: libmsmd_hip.so loads, exports
+every symbol include/msmd_hip.h declares, the ctypes table mirrors the header,
+argument validation works on the host side, and the product package never
+touches the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "msmd_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(msmd_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
+        decls[m.group(1)] = len(args)
+    return decls
+
+
+def test_library_exports_every_declared_symbol():
+    from msmdfusion_amd import _lib
+    decls = _declared()
+    assert len(decls) >= 28
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True,
+                        text=True, check=True).stdout
+    exported = set(re.findall(r" T (msmd_\w+)", nm))
+    assert set(decls) <= exported, sorted(set(decls) - exported)
+    assert exported <= set(decls), "undeclared exports: %s" % sorted(exported - set(decls))
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in decls:
+        assert getattr(lib, name) is not None
+
+
+def test_ctypes_table_mirrors_header():
+    from msmdfusion_amd import _lib
+    decls = _declared()
+    assert set(_lib.SIGNATURES) == set(decls)
+    for name, (_, argtypes) in _lib.SIGNATURES.items():
+        assert len(argtypes) == decls[name], name
+    assert _lib.lib.msmd_abi_version() == _lib.ABI_VERSION
+    assert _lib.lib.msmd_status_string(0) == b"ok"
+    assert b"workspace" in _lib.lib.msmd_status_string(-2)
+
+
+def test_host_side_argument_validation():
+    """Bad arguments are rejected before anything is enqueued (no GPU needed)."""
+    from msmdfusion_amd._lib import float_arr, int3, lib
+    assert lib.msmd_hard_voxelize(None, 10, 5, float_arr([0.1] * 3), float_arr([0, 0, 0, 1, 1, 1]),
+                                  10, 100, None, None, None, None, None, None, 0, None) == -1
+    assert lib.msmd_rulebook_subm3d(None, -1, 1, int3([4, 4, 4]), int3([3, 3, 3]), None, None, 0,
+                                    None) == -1
+    # 70000^3 cells cannot be indexed with 32-bit linear ids
+    assert lib.msmd_rulebook_subm3d(None, 0, 1, int3([70000] * 3), int3([3, 3, 3]), None, None, 0,
+                                    None) == -5
+    assert lib.msmd_spconv_fwd_f32(None, 0, 16, None, None, 0, 10, 27, 0, None, 16, None) == -1
+    # c_out = 7*16 has no built kernel
+    assert lib.msmd_spconv_fwd_f32(ctypes.c_void_p(256), 1, 16, ctypes.c_void_p(256),
+                                   ctypes.c_void_p(256), 1, 1, 27, 0, ctypes.c_void_p(256), 112,
+                                   None) == -3
+    assert lib.msmd_voxelize_workspace_bytes(30000, 120000, 10) > 120000 * 10 * 4
+    assert lib.msmd_spconv_packed_weight_elems(27, 5, 16) == 27 * 1 * 1 * 256
+    assert lib.msmd_device_ok() in (0, 1)
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under msmdfusion_amd/ may import
+    or call it, and the package has no CPU fallback branches."""
+    pkg = os.path.join(ROOT, "msmdfusion_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "libmsmd_oracle" not in text and "msmd_oracle" not in text, f
+
+
+def test_kernels_refuse_cpu_tensors():
+    import torch
+    from msmdfusion_amd import kernels as K
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        K.rulebook_subm(torch.zeros((4, 4), dtype=torch.int32), 1, [4, 4, 4], 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        K.hard_voxelize(torch.zeros((4, 5)), [0.1] * 3, [0, 0, 0, 1, 1, 1], 10, 100)
+
+
+def test_synthetic_generators_are_seeded_and_shaped():
+    import numpy as np
+    from msmdfusion_amd import synthetic as S
+    a, b = S.lidar_sweep(3), S.lidar_sweep(3)
+    assert np.array_equal(a, b) and a.dtype == np.float32 and a.shape[1] == 5
+    assert 25000 < a.shape[0] < 32000
+    v = S.virtual_points(1)
+    assert v.shape == (49980, 64) and np.isfinite(v).all()
+    idx = S.random_voxel_indices(500, 2, [5, 30, 30], seed=0)
+    assert np.unique(idx, axis=0).shape[0] == idx.shape[0]
+    assert (idx.min(0) >= 0).all() and (idx.max(0) < [2, 5, 30, 30]).all()

@@ -1,0 +1,245 @@
+"""CPU tests (no GPU): the oracle is pinned against
+  (1) the literal vectors of the reference's own tests,
+  (2) outputs of the reference's own CPU code, committed as
+      tests/golden/reference_vectors.npz (tests/golden/make_golden.py),
+  (3) the live reference build oracle/_ref/ when present (build container),
+  (4) independent dense-conv / hand-derived cases where no reference exists
+      here (spconv 2.x sparse_add, numba modality split).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from msmdfusion_amd import synthetic as S
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.npz")
+GEOMS = [("subm3", True, [3, 3, 3], [1, 1, 1], [1, 1, 1]),
+         ("down_p1", False, [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+         ("down_p011", False, [3, 3, 3], [2, 2, 2], [0, 1, 1]),
+         ("out_311", False, [3, 1, 1], [2, 1, 1], [0, 0, 0]),
+         ("down_k3s1p0", False, [3, 3, 3], [1, 1, 1], [0, 0, 0]),
+         ("down_k2s2", False, [2, 2, 2], [2, 2, 2], [0, 0, 0]),
+         ("subm133", True, [1, 3, 3], [1, 1, 1], [0, 1, 1]),
+         ("down_s3p2", False, [3, 3, 3], [3, 3, 3], [2, 2, 2])]
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+# ---------------------------------------------------------------- (1) reference test literals
+def test_voxel_generator_known_answer():
+    """tests/test_models/test_voxel_encoder/test_voxel_generator.py:6-22."""
+    np.random.seed(0)
+    points = np.random.rand(1000, 4)
+    v, c, n = O.hard_voxelize(points.astype(np.float32), [0.5, 0.5, 0.5],
+                              [0, -40, -3, 70.4, 40, 1], 1000, 20000)
+    expected = np.array([[7, 81, 1], [6, 81, 0], [7, 80, 1], [6, 81, 1], [7, 81, 0], [6, 80, 1],
+                         [7, 80, 0], [6, 80, 0]])
+    assert np.array_equal(c, expected)
+    assert v.shape == (8, 1000, 4)
+    assert np.array_equal(n, [120, 121, 127, 134, 115, 127, 125, 131])
+
+
+def test_fps_known_answer():
+    """tests/test_models/test_common_modules/test_pointnet_ops.py:9-23."""
+    xyz = np.array([[[-0.2748, 1.0020, -1.1674], [0.1015, 1.3952, -1.2681],
+                     [-0.8070, 2.4137, -0.5845], [-1.0001, 2.1982, -0.5859],
+                     [0.3841, 1.8983, -0.7431]],
+                    [[-1.0696, 3.0758, -0.1899], [-0.2559, 3.5521, -0.1402],
+                     [0.8164, 4.0081, -0.1839], [-1.1000, 3.0213, -0.8205],
+                     [-0.0518, 3.7251, -0.3950]]], np.float32)
+    assert np.array_equal(O.furthest_point_sample(xyz, 3), [[0, 2, 4], [0, 2, 1]])
+
+
+BQ_NEW = np.array([[[-0.0740, 1.3147, -1.3625], [-2.2769, 2.7817, -0.2334],
+                    [-0.4003, 2.4666, -0.5116], [-0.0740, 1.3147, -1.3625],
+                    [-0.0740, 1.3147, -1.3625]],
+                   [[-2.0289, 2.4952, -0.1708], [-2.0668, 6.0278, -0.4875],
+                    [0.4066, 1.4211, -0.2947], [-2.0289, 2.4952, -0.1708],
+                    [-2.0289, 2.4952, -0.1708]]], np.float32)
+BQ_XYZ = np.array([[[-0.0740, 1.3147, -1.3625], [0.5555, 1.0399, -1.3634],
+                    [-0.4003, 2.4666, -0.5116], [-0.5251, 2.4379, -0.8466],
+                    [-0.9691, 1.1418, -1.3733], [-0.2232, 0.9561, -1.3626],
+                    [-2.2769, 2.7817, -0.2334], [-0.2822, 1.3192, -1.3645],
+                    [0.1533, 1.5024, -1.0432], [0.4917, 1.1529, -1.3496]],
+                   [[-2.0289, 2.4952, -0.1708], [-0.7188, 0.9956, -0.5096],
+                    [-2.0668, 6.0278, -0.4875], [-1.9304, 3.3092, 0.6610],
+                    [0.0949, 1.4332, 0.3140], [-1.2879, 2.0008, -0.7791],
+                    [-0.7252, 0.9611, -0.6371], [0.4066, 1.4211, -0.2947],
+                    [0.3220, 1.4447, 0.3548], [-0.9744, 2.3856, -1.2000]]], np.float32)
+BQ_EXP1 = [[[0] * 5, [6] * 5, [2] * 5, [0] * 5, [0] * 5], [[0] * 5, [2] * 5, [7] * 5, [0] * 5, [0] * 5]]
+BQ_EXP2 = [[[0, 5, 7, 0, 0], [6] * 5, [2, 3, 2, 2, 2], [0, 5, 7, 0, 0], [0, 5, 7, 0, 0]],
+           [[0] * 5, [2] * 5, [7] * 5, [0] * 5, [0] * 5]]
+
+
+def test_ball_query_known_answer():
+    """test_pointnet_ops.py:26-73 (both radius settings)."""
+    assert np.array_equal(O.ball_query(0, 0.2, 5, BQ_XYZ, BQ_NEW), BQ_EXP1)
+    assert np.array_equal(O.ball_query(0.2, 0.4, 5, BQ_XYZ, BQ_NEW), BQ_EXP2)
+
+
+# ---------------------------------------------------------------- (2) committed reference outputs
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_voxelize_vs_reference_vectors(gold, tag):
+    p = gold[f"vox_{tag}_params"]
+    v, c, n = O.hard_voxelize(gold["vox_points"], p[:3], S.POINT_CLOUD_RANGE, int(p[3]), int(p[4]))
+    assert np.array_equal(c, gold[f"vox_{tag}_coors"])
+    assert np.array_equal(n, gold[f"vox_{tag}_num"])
+    assert np.array_equal(v, gold[f"vox_{tag}_voxels"])
+    if tag == "c":
+        assert c.shape[0] == 1500      # the max_voxels break really fired
+
+
+@pytest.mark.parametrize("name,subm,ks,st,pd", GEOMS)
+def test_rulebook_vs_reference_vectors(gold, name, subm, ks, st, pd):
+    shape = gold["rb_shape"].tolist()
+    oi, pr, nm, osz = O.get_indice_pairs(gold["rb_indices"], 2, shape, ks, st, pd, 1, subm)
+    assert list(osz) == gold[f"rb_{name}_oshape"].tolist()
+    assert np.array_equal(oi, gold[f"rb_{name}_out"])
+    assert np.array_equal(nm, gold[f"rb_{name}_num"])
+    assert np.array_equal(pr, gold[f"rb_{name}_pairs"])
+
+
+@pytest.mark.parametrize("name,subm", [(g[0], g[1]) for g in GEOMS[:4]])
+def test_conv_vs_reference_vectors(gold, name, subm):
+    out = O.indice_conv_fwd(gold[f"conv_{name}_feat"], gold[f"conv_{name}_w"],
+                            gold[f"rb_{name}_pairs"], gold[f"rb_{name}_num"],
+                            gold[f"rb_{name}_out"].shape[0], subm=subm)
+    np.testing.assert_allclose(out, gold[f"conv_{name}_out"], rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------- (3) live reference build
+needs_ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+
+
+@needs_ref
+def test_live_reference_voxelize_and_rulebooks():
+    pts = S.lidar_sweep(3, n_az=200)
+    for mp, mv in [(10, 120000), (2, 900)]:
+        a = O.hard_voxelize(pts, S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, mp, mv)
+        b = O.hard_voxelize(pts, S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, mp, mv, use_ref=True)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    _, c, _ = O.hard_voxelize(pts, S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 120000)
+    idx = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+    for _, subm, ks, st, pd in GEOMS:
+        a = O.get_indice_pairs(idx, 1, S.SPARSE_SHAPE, ks, st, pd, 1, subm)
+        b = O.get_indice_pairs(idx, 1, S.SPARSE_SHAPE, ks, st, pd, 1, subm, use_ref=True)
+        assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3]))
+
+
+# ---------------------------------------------------------------- (4) independent pins
+def _dense_conv(feat, idx, shape, batch, w_kio, ks, st, pd):
+    """torch.nn.functional.conv3d on the densified input (the cross-check
+    mmdet3d/ops/spconv/test_utils.py:145-193 builds)."""
+    dense = torch.from_numpy(O.dense(feat, idx, batch, shape))
+    kvol, cin, cout = w_kio.shape
+    w = torch.from_numpy(w_kio).reshape(*ks, cin, cout).permute(4, 3, 0, 1, 2).contiguous()
+    return torch.nn.functional.conv3d(dense.double(), w.double(), stride=st, padding=pd).numpy()
+
+
+@pytest.mark.parametrize("name,subm,ks,st,pd", GEOMS[:6])
+def test_sparse_conv_equals_dense_conv(name, subm, ks, st, pd):
+    shape, batch = [7, 12, 12], 2
+    idx = S.random_voxel_indices(150, batch, shape, seed=5)
+    rng = np.random.RandomState(1)
+    f = rng.randn(idx.shape[0], 6).astype(np.float32)
+    kvol = int(np.prod(ks))
+    w = rng.randn(kvol, 6, 4).astype(np.float32)
+    oi, pr, nm, osz = O.get_indice_pairs(idx, batch, shape, ks, st, pd, 1, subm)
+    out = O.indice_conv_fwd(f, w, pr, nm, oi.shape[0], subm=subm)
+    ref = _dense_conv(f, idx, shape, batch, w, ks, st, [k // 2 for k in ks] if subm else pd)
+    got = ref[oi[:, 0], :, oi[:, 1], oi[:, 2], oi[:, 3]]
+    np.testing.assert_allclose(out, got, rtol=1e-4, atol=1e-4)
+    if not subm:   # every output site the dense conv can reach from an active input is present
+        reach = _dense_conv(np.ones((idx.shape[0], 1), np.float32), idx, shape, batch,
+                            np.ones((kvol, 1, 1), np.float32), ks, st, pd)[:, 0] > 0
+        assert reach.sum() == oi.shape[0]
+        assert reach[oi[:, 0], oi[:, 1], oi[:, 2], oi[:, 3]].all()
+
+
+def test_conv_backward_matches_autograd_of_dense_conv():
+    shape, batch, ks = [5, 9, 9], 1, [3, 3, 3]
+    idx = S.random_voxel_indices(80, batch, shape, seed=2)
+    rng = np.random.RandomState(0)
+    f = rng.randn(idx.shape[0], 3).astype(np.float32)
+    w = rng.randn(27, 3, 5).astype(np.float32)
+    for subm, st, pd in [(True, [1, 1, 1], [1, 1, 1]), (False, [2, 2, 2], [1, 1, 1])]:
+        oi, pr, nm, osz = O.get_indice_pairs(idx, batch, shape, ks, st, pd, 1, subm)
+        g = rng.randn(oi.shape[0], 5).astype(np.float32)
+        din, dw = O.indice_conv_bwd(f, w, g, pr, nm, subm=subm)
+        ft = torch.from_numpy(f).double().requires_grad_(True)
+        wt = torch.from_numpy(w).double().requires_grad_(True)
+        ii = torch.from_numpy(idx).long()
+        dense = torch.zeros(batch, *shape, 3, dtype=torch.double)        # channels last
+        dense = dense.index_put((ii[:, 0], ii[:, 1], ii[:, 2], ii[:, 3]), ft)
+        dense = dense.permute(0, 4, 1, 2, 3)
+        y = torch.nn.functional.conv3d(dense, wt.reshape(3, 3, 3, 3, 5).permute(4, 3, 0, 1, 2),
+                                       stride=st, padding=pd)
+        oo = torch.from_numpy(oi).long()
+        loss = (y[oo[:, 0], :, oo[:, 1], oo[:, 2], oo[:, 3]] * torch.from_numpy(g).double()).sum()
+        loss.backward()
+        np.testing.assert_allclose(din, ft.grad.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(dw, wt.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_sparse_add_hand_case_and_dense_identity():
+    shape = [2, 3, 3]
+    ia = np.array([[0, 1, 2, 2], [0, 0, 0, 1], [1, 0, 0, 0]], np.int32)
+    ib = np.array([[1, 0, 0, 0], [0, 0, 0, 0], [0, 1, 2, 2]], np.int32)
+    fa = np.array([[1, 2], [3, 4], [5, 6]], np.float32)
+    fb = np.array([[10, 20], [30, 40], [50, 60]], np.float32)
+    oi, of, ma, mb = O.sparse_add(fa, ia, fb, ib, shape)
+    assert oi.tolist() == [[0, 0, 0, 0], [0, 0, 0, 1], [0, 1, 2, 2], [1, 0, 0, 0]]
+    assert of.tolist() == [[30, 40], [3, 4], [51, 62], [15, 26]]
+    assert ma.tolist() == [2, 1, 3] and mb.tolist() == [3, 0, 2]
+    a = S.random_voxel_indices(200, 2, [5, 20, 20], seed=1)
+    b = S.random_voxel_indices(150, 2, [5, 20, 20], seed=2)
+    rng = np.random.RandomState(0)
+    fa, fb = rng.randn(a.shape[0], 3).astype(np.float32), rng.randn(b.shape[0], 3).astype(np.float32)
+    oi, of, _, _ = O.sparse_add(fa, a, fb, b, [5, 20, 20])
+    np.testing.assert_allclose(O.dense(of, oi, 2, [5, 20, 20]),
+                               O.dense(fa, a, 2, [5, 20, 20]) + O.dense(fb, b, 2, [5, 20, 20]))
+    lid = O.linear_ids(oi, [5, 20, 20])
+    assert (np.diff(lid) > 0).all()
+
+
+def test_modality_split_hand_case_and_float_key_aliasing():
+    shape = [41, 1440, 1440]
+    z3 = np.array([[0, 0, 5], [3, 7, 9], [1, 1, 1], [40, 2, 2]], np.int32)
+    z2 = np.array([[1, 1, 1], [0, 0, 6], [40, 2, 2], [9, 9, 9]], np.int32)
+    m3, m2, p3, p2 = O.modality_split(z3, z2, shape)
+    assert m3.tolist() == [0, 0, 1, 1] and m2.tolist() == [1, 0, 1, 0]
+    assert p3.tolist() == [2, 3] and p2.tolist() == [0, 2]
+    # the reference's float32 key y*1e3 + x aliases for x >= 1000 ...
+    a = np.array([[0, 5, 1000]], np.int32)
+    b = np.array([[0, 6, 0]], np.int32)
+    assert O.modality_split(a, b, shape, float_keys=True)[0].tolist() == [1]   # false match
+    assert O.modality_split(a, b, shape, float_keys=False)[0].tolist() == [0]  # exact keys
+    # ... and loses low bits of x once the key passes 2^24 (z >= 17)
+    a = np.array([[20, 100, 3]], np.int32)
+    b = np.array([[20, 100, 4]], np.int32)
+    assert O.modality_split(a, b, shape, float_keys=True)[0].tolist() == [1]
+    assert O.modality_split(a, b, shape, float_keys=False)[0].tolist() == [0]
+
+
+def test_dense_hand_case():
+    f = np.array([[1, 2], [3, 4]], np.float32)
+    idx = np.array([[1, 0, 1, 2], [0, 1, 0, 0]], np.int32)
+    d = O.dense(f, idx, 2, [2, 2, 3])
+    assert d.shape == (2, 2, 2, 2, 3) and d.sum() == 10
+    assert d[1, :, 0, 1, 2].tolist() == [1, 2] and d[0, :, 1, 0, 0].tolist() == [3, 4]
+
+
+def test_nn_assign_last_write_wins_and_fps_tie_order():
+    grp = np.array([[0, 1, 1], [1, 2, 2], [3, 3, 3]], np.int32)
+    assert O.nn_assign(grp, np.array([7, 8, -1], np.int32), 5).tolist() == [7, 8, 8, -1, -1]
+    # all points equidistant from point 0: the reference's tree keeps the lower
+    # slot of each pair -> among tied thread ids the bit-reversed-smallest wins
+    xyz = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0]]], np.float32)
+    assert O.fps_block_size(5) == 4
+    assert O.furthest_point_sample(xyz, 2).tolist() == [[0, 4]]   # k=4 shares thread 0 with k=0
