@@ -165,12 +165,22 @@ int msmd_spconv_pack_weight(const float* weight /* [K,c_in,c_out] */,
                             int transpose /* pack W[k]^T: [c_out,c_in] */,
                             float* packed, msmd_stream_t stream);
 
+/* `row_order` (NULL or a permutation of [0,n_out)): the order in which output
+ * rows are tiled.  Any permutation gives bit-identical results; sorting rows
+ * by msmd_rulebook_row_masks() lets whole waves / workgroups skip the kernel
+ * offsets none of their rows is connected through. */
 int msmd_spconv_fwd_f32(const float* in_feat /* [n_in,c_in] */, int n_in,
                         int c_in, const float* packed_weight,
                         const int32_t* nbr /* [K,ld] */, int ld, int n_out,
                         int kernel_volume, int weight_flip,
+                        const int32_t* row_order /* [n_out] or NULL */,
                         float* out_feat /* [n_out,c_out] */, int c_out,
                         msmd_stream_t stream);
+
+/* masks[o] = bitset over k of (nbr[k][o] >= 0); kernel_volume <= 64. */
+int msmd_rulebook_row_masks(const int32_t* nbr /* [K,n_rows] */,
+                            int kernel_volume, int n_rows, uint64_t* masks,
+                            msmd_stream_t stream);
 
 /* dW[k] = sum over pairs p of offset k: in[pairs[k,0,p],:]^T (x) dout[pairs[k,1,p],:]
  * (spconv_ops.h:399,438).  Deterministic two-pass reduction. */
@@ -183,6 +193,32 @@ int msmd_spconv_wgrad_f32(const float* in_feat, int c_in, const float* d_out,
                           int kernel_volume, float* d_weight /* [K,c_in,c_out] */,
                           void* workspace, size_t workspace_bytes,
                           msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * a9/a10  BatchNorm1d (+ residual) (+ ReLU) on sparse-tensor features [n,c]
+ * replaces: the nn.BatchNorm1d + nn.ReLU(inplace) pair make_sparse_convmodule
+ *           appends to every sparse conv (mmdet3d/ops/sparse_block.py:161-190)
+ *           and SparseBasicBlock's relu(bn2(conv2(x)) + identity) (:103-126).
+ * training != 0: batch statistics (biased variance for normalisation,
+ * running_var updated with the unbiased one, torch semantics; running_* may be
+ * NULL = track_running_stats False, tools/train.py:205-211); else running stats.
+ * save_mean / save_invstd [c] are outputs the backward needs.  c % 4 == 0.
+ * ------------------------------------------------------------------------ */
+size_t msmd_bn_workspace_bytes(int n, int c);
+
+int msmd_bn_act_fwd_f32(const float* x /* [n,c] */, const float* residual /* or NULL */,
+                        int n, int c, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, int training,
+                        float momentum, float eps, int relu, float* y,
+                        float* save_mean, float* save_invstd, void* workspace,
+                        size_t workspace_bytes, msmd_stream_t stream);
+
+int msmd_bn_act_bwd_f32(const float* x, const float* y /* fwd output, for the ReLU mask */,
+                        const float* dy, int n, int c, const float* gamma,
+                        const float* save_mean, const float* save_invstd,
+                        int training, int relu, float* dx,
+                        float* dresidual /* or NULL */, float* dgamma, float* dbeta,
+                        void* workspace, size_t workspace_bytes, msmd_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * a12  SparseConvTensor.dense(): BEV scatter

@@ -1,0 +1,287 @@
+// bn.hip -- BatchNorm1d (+ residual) (+ ReLU) over sparse-tensor features [N,C].
+//
+// The reference applies nn.BatchNorm1d and nn.ReLU(inplace) to .features after
+// every sparse conv (make_sparse_convmodule, mmdet3d/ops/sparse_block.py:161-190;
+// SparseBasicBlock.forward :103-126: relu(bn2(conv2(.)) + identity)): three to
+// five elementwise / reduction launches per conv, each a full pass over [N,C].
+// Here: forward = one statistics pass + one fused normalise(+residual)(+ReLU)
+// pass; backward = one reduction pass + one fused pass.  All passes stream
+// 16-byte vectors, coalesced; reductions are per-block partials combined in
+// fixed order in fp64 (deterministic, no float atomics).  HBM-bound:
+// algorithmic bytes fwd = 4NC(2 reads + 1 write [+1 residual]), bwd = 4NC(3-4
+// reads + 1-2 writes).
+#include "common.hpp"
+
+namespace msmd {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBnRows = 256;  // rows per partial block
+
+// Partial sums of u and v per channel over a block of rows, where (u,v) come
+// from a per-element functor.  Threads own a fixed float4 channel group.
+template <typename F>
+__device__ __forceinline__ void block_channel_sums(F f, int n, int c, float* __restrict__ part) {
+  __shared__ f32x4 sm[2 * 256];
+  const int c4 = c >> 2;
+  const int used = (256 / c4) * c4;  // threads with a fixed channel group
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * kBnRows;
+  const int r1 = (r0 + kBnRows) < n ? (r0 + kBnRows) : n;
+  f32x4 su = (f32x4){0.f, 0.f, 0.f, 0.f}, sv = su;
+  if (tid < used) {
+    const int g = tid % c4;
+    const long e0 = (long)r0 * c4, e1 = (long)r1 * c4;
+    for (long e = e0 + tid; e < e1; e += used) {
+      f32x4 u, v;
+      f(e, g, u, v);
+      su += u;
+      sv += v;
+    }
+  }
+  sm[tid] = su;
+  sm[256 + tid] = sv;
+  __syncthreads();
+  if (tid < c4) {
+    f32x4 a = sm[tid], b = sm[256 + tid];
+    for (int t = tid + c4; t < used; t += c4) {
+      a += sm[t];
+      b += sm[256 + t];
+    }
+    f32x4* o = (f32x4*)(part + (size_t)blockIdx.x * 2 * c);
+    o[tid] = a;
+    o[c4 + tid] = b;
+  }
+}
+
+struct FwdStat {
+  const f32x4* x;
+  __device__ void operator()(long e, int, f32x4& u, f32x4& v) const {
+    u = x[e];
+    v = u * u;
+  }
+};
+__global__ __launch_bounds__(256) void bn_fwd_partial(const float* __restrict__ x, int n, int c,
+                                                      float* __restrict__ part) {
+  block_channel_sums(FwdStat{(const f32x4*)x}, n, c, part);
+}
+
+// Finalize kernels run with grid = ceil(c/16), block = 256 = 16 channels x 16
+// partial-lanes: lane j sums partial blocks j, j+16, ... in fp64, then the 16
+// lane sums are added in lane order (fixed order -> deterministic).  Returns
+// the channel this thread must finalise (lane 0 of each channel) or -1.
+__device__ __forceinline__ int combine_partials(const float* __restrict__ part, int nblk, int c,
+                                                double* s_out, double* ss_out) {
+  __shared__ double sm[2][16][17];
+  const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double s = 0, ss = 0;
+  if (ch < c)
+    for (int b = lane; b < nblk; b += 16) {
+      s += part[(size_t)b * 2 * c + ch];
+      ss += part[(size_t)b * 2 * c + c + ch];
+    }
+  sm[0][cl][lane] = s;
+  sm[1][cl][lane] = ss;
+  __syncthreads();
+  if (lane != 0 || ch >= c) return -1;
+  s = 0;
+  ss = 0;
+  for (int j = 0; j < 16; ++j) {
+    s += sm[0][cl][j];
+    ss += sm[1][cl][j];
+  }
+  *s_out = s;
+  *ss_out = ss;
+  return ch;
+}
+
+// mean / invstd from the partials (fp64 combine), running-stat update
+// (torch semantics: running_var takes the unbiased variance).
+__global__ __launch_bounds__(256) void bn_fwd_finalize(const float* __restrict__ part, int nblk,
+                                                       int n, int c, float eps, float momentum,
+                                                       float* running_mean, float* running_var,
+                                                       float* __restrict__ mean,
+                                                       float* __restrict__ invstd) {
+  double s, ss;
+  const int ch = combine_partials(part, nblk, c, &s, &ss);
+  if (ch < 0) return;
+  double m = s / n;
+  double var = ss / n - m * m;
+  if (var < 0) var = 0;
+  mean[ch] = (float)m;
+  invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    double unbiased = n > 1 ? var * n / (n - 1) : var;
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_eval_stats(const float* __restrict__ rm,
+                                                     const float* __restrict__ rv, int c, float eps,
+                                                     float* mean, float* invstd) {
+  int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  mean[ch] = rm[ch];
+  invstd[ch] = 1.f / sqrtf(rv[ch] + eps);
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_apply(const float* __restrict__ x,
+                                                    const float* __restrict__ res, long total4,
+                                                    int c4, const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int relu,
+                                                    float* __restrict__ y) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long)gridDim.x * 256) {
+    const int g = (int)(e % c4);
+    f32x4 v = ((const f32x4*)x)[e];
+    const f32x4 m = ((const f32x4*)mean)[g], is = ((const f32x4*)invstd)[g];
+    const f32x4 ga = ((const f32x4*)gamma)[g], be = ((const f32x4*)beta)[g];
+    v = (v - m) * is * ga + be;
+    if (res) v += ((const f32x4*)res)[e];
+    if (relu) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[s] = v[s] > 0.f ? v[s] : 0.f;
+    }
+    ((f32x4*)y)[e] = v;
+  }
+}
+
+struct BwdStat {  // u = dy_eff, v = dy_eff * xhat
+  const f32x4 *x, *y, *dy, *mean, *invstd;
+  int relu;
+  __device__ void operator()(long e, int g, f32x4& u, f32x4& v) const {
+    u = dy[e];
+    if (relu) {
+      f32x4 yy = y[e];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) u[s] = yy[s] > 0.f ? u[s] : 0.f;
+    }
+    v = u * ((x[e] - mean[g]) * invstd[g]);
+  }
+};
+__global__ __launch_bounds__(256) void bn_bwd_partial(const float* x, const float* y,
+                                                      const float* dy, int n, int c,
+                                                      const float* mean, const float* invstd,
+                                                      int relu, float* __restrict__ part) {
+  block_channel_sums(BwdStat{(const f32x4*)x, (const f32x4*)y, (const f32x4*)dy,
+                             (const f32x4*)mean, (const f32x4*)invstd, relu},
+                     n, c, part);
+}
+__global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__ part, int nblk,
+                                                       int c, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta) {
+  double s, ss;
+  const int ch = combine_partials(part, nblk, c, &s, &ss);
+  if (ch < 0) return;
+  dbeta[ch] = (float)s;
+  dgamma[ch] = (float)ss;
+}
+// training: dx = gamma*invstd*(dy - dbeta/N - xhat*dgamma/N); eval: gamma*invstd*dy
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ x,
+                                                    const float* __restrict__ y,
+                                                    const float* __restrict__ dy, long total4,
+                                                    int c4, float inv_n,
+                                                    const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ dgamma,
+                                                    const float* __restrict__ dbeta, int relu,
+                                                    int training, float* __restrict__ dx,
+                                                    float* __restrict__ dres) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long)gridDim.x * 256) {
+    const int g = (int)(e % c4);
+    f32x4 d = ((const f32x4*)dy)[e];
+    if (relu) {
+      f32x4 yy = ((const f32x4*)y)[e];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) d[s] = yy[s] > 0.f ? d[s] : 0.f;
+    }
+    if (dres) ((f32x4*)dres)[e] = d;
+    const f32x4 is = ((const f32x4*)invstd)[g], ga = ((const f32x4*)gamma)[g];
+    f32x4 r = d;
+    if (training) {
+      const f32x4 xh = (((const f32x4*)x)[e] - ((const f32x4*)mean)[g]) * is;
+      r = d - ((const f32x4*)dbeta)[g] * inv_n - xh * ((const f32x4*)dgamma)[g] * inv_n;
+    }
+    ((f32x4*)dx)[e] = r * is * ga;
+  }
+}
+
+inline int bn_blocks(int n) { return ceil_div(n > 0 ? n : 1, kBnRows); }
+inline int stream_blocks(long total4) {
+  long b = (total4 + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+}  // namespace msmd
+
+using namespace msmd;
+
+MSMD_EXPORT size_t msmd_bn_workspace_bytes(int n, int c) {
+  return align_up(sizeof(float) * (size_t)bn_blocks(n) * 2 * c);
+}
+
+MSMD_EXPORT int msmd_bn_act_fwd_f32(const float* x, const float* residual, int n, int c,
+                                    const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, int training, float momentum, float eps,
+                                    int relu, float* y, float* save_mean, float* save_invstd,
+                                    void* workspace, size_t workspace_bytes,
+                                    msmd_stream_t stream) {
+  if (n < 0 || c < 4 || (c & 3) || c > 1024 || !gamma || !beta || !save_mean || !save_invstd)
+    return c > 0 && ((c & 3) || c > 1024) ? MSMD_ERR_UNSUPPORTED : MSMD_ERR_INVALID_ARG;
+  if (!training && (!running_mean || !running_var)) return MSMD_ERR_INVALID_ARG;
+  if (n == 0) return MSMD_OK;
+  if (!x || !y) return MSMD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = bn_blocks(n);
+  if (training) {
+    if (workspace_bytes < sizeof(float) * (size_t)nblk * 2 * c || ((uintptr_t)workspace & 255))
+      return MSMD_ERR_WORKSPACE;
+    float* part = (float*)workspace;
+    MSMD_LAUNCH(bn_fwd_partial, dim3(nblk), dim3(256), 0, st, x, n, c, part);
+    MSMD_LAUNCH(bn_fwd_finalize, dim3(ceil_div(c, 16)), dim3(256), 0, st, part, nblk, n, c, eps,
+                momentum, running_mean, running_var, save_mean, save_invstd);
+  } else {
+    MSMD_LAUNCH(bn_eval_stats, dim3(ceil_div(c, 256)), dim3(256), 0, st, running_mean,
+                running_var, c, eps, save_mean, save_invstd);
+  }
+  const long total4 = (long)n * (c >> 2);
+  MSMD_LAUNCH(bn_fwd_apply, dim3(stream_blocks(total4)), dim3(256), 0, st, x, residual, total4,
+              c >> 2, save_mean, save_invstd, gamma, beta, relu, y);
+  return launch_status();
+}
+
+MSMD_EXPORT int msmd_bn_act_bwd_f32(const float* x, const float* y, const float* dy, int n, int c,
+                                    const float* gamma, const float* save_mean,
+                                    const float* save_invstd, int training, int relu, float* dx,
+                                    float* dresidual, float* dgamma, float* dbeta,
+                                    void* workspace, size_t workspace_bytes,
+                                    msmd_stream_t stream) {
+  if (n < 0 || c < 4 || (c & 3) || c > 1024 || !gamma || !save_mean || !save_invstd || !dgamma ||
+      !dbeta)
+    return MSMD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    hipMemsetAsync(dgamma, 0, sizeof(float) * c, st);
+    hipMemsetAsync(dbeta, 0, sizeof(float) * c, st);
+    return MSMD_OK;
+  }
+  if (!x || !dy || !dx || (relu && !y)) return MSMD_ERR_INVALID_ARG;
+  const int nblk = bn_blocks(n);
+  if (workspace_bytes < sizeof(float) * (size_t)nblk * 2 * c || ((uintptr_t)workspace & 255))
+    return MSMD_ERR_WORKSPACE;
+  float* part = (float*)workspace;
+  MSMD_LAUNCH(bn_bwd_partial, dim3(nblk), dim3(256), 0, st, x, y, dy, n, c, save_mean,
+              save_invstd, relu, part);
+  MSMD_LAUNCH(bn_bwd_finalize, dim3(ceil_div(c, 16)), dim3(256), 0, st, part, nblk, c, dgamma,
+              dbeta);
+  const long total4 = (long)n * (c >> 2);
+  MSMD_LAUNCH(bn_bwd_apply, dim3(stream_blocks(total4)), dim3(256), 0, st, x, y, dy, total4,
+              c >> 2, 1.f / (float)n, save_mean, save_invstd, gamma, dgamma, dbeta, relu, training,
+              dx, dresidual);
+  return launch_status();
+}

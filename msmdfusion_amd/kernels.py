@@ -175,7 +175,23 @@ def _prof_end(kind, start, **meta):
         PROFILE.append((kind, start, end, meta))
 
 
-def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False):
+def row_mask_order(nbr):
+    """Permutation of the rows of nbr[K,n] that sorts them by neighbour mask
+    (rows with identical empty offsets become adjacent).  The masks come from
+    the C ABI; the sort itself is torch.argsort (device radix sort) -- it only
+    chooses a tiling order, results are identical for any permutation."""
+    _need_cuda(nbr)
+    kvol, n = nbr.shape
+    if kvol > 64 or n == 0:
+        return None
+    masks = torch.empty((n,), dtype=torch.int64, device=nbr.device)
+    check(lib.msmd_rulebook_row_masks(_p(nbr), kvol, n, _p(masks), _stream()),
+          "msmd_rulebook_row_masks")
+    keys = masks.int() if kvol <= 31 else masks     # 32-bit keys: half the radix passes
+    return torch.sort(keys, stable=False)[1].int()
+
+
+def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False, row_order=None):
     """out[o] = sum_k feat[nbr[k,o]] @ W[k]  (implicit GEMM on MFMA)."""
     _need_cuda(feat, packed_weight, nbr)
     f = feat.contiguous().float()
@@ -184,7 +200,8 @@ def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False):
     out = torch.empty((n_out, c_out), dtype=torch.float32, device=f.device)
     ev = _prof_begin()
     check(lib.msmd_spconv_fwd_f32(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld, int(n_out),
-                                  kvol, int(bool(weight_flip)), _p(out), int(c_out), _stream()),
+                                  kvol, int(bool(weight_flip)), _p(row_order), _p(out),
+                                  int(c_out), _stream()),
           "msmd_spconv_fwd_f32")
     _prof_end("spconv_fwd", ev, nbr=nbr, c_in=c_in, c_out=int(c_out), n_in=n_in, n_out=int(n_out))
     return out
@@ -204,6 +221,46 @@ def conv_wgrad(feat, d_out, pairs, num):
                                     _p(dw), _p(ws), nbytes, _stream()), "msmd_spconv_wgrad_f32")
     _prof_end("spconv_wgrad", ev, num=num, c_in=c_in, c_out=c_out)
     return dw
+
+
+# ------------------------------------------------------------------ BN (+residual)(+ReLU)
+def bn_act_forward(x, residual, gamma, beta, running_mean, running_var, training, momentum, eps,
+                   relu):
+    """-> (y, save_mean, save_invstd)"""
+    _need_cuda(x, gamma, beta)
+    xx = x.contiguous().float()
+    n, c = xx.shape
+    dev = xx.device
+    y = torch.empty_like(xx)
+    mean = torch.empty((c,), dtype=torch.float32, device=dev)
+    invstd = torch.empty((c,), dtype=torch.float32, device=dev)
+    nbytes = lib.msmd_bn_workspace_bytes(n, c)
+    ws = _ws(nbytes, dev)
+    res = None if residual is None else residual.contiguous().float()
+    check(lib.msmd_bn_act_fwd_f32(_p(xx), _p(res), n, c, _p(gamma), _p(beta), _p(running_mean),
+                                  _p(running_var), int(bool(training)), float(momentum),
+                                  float(eps), int(bool(relu)), _p(y), _p(mean), _p(invstd), _p(ws),
+                                  nbytes, _stream()), "msmd_bn_act_fwd_f32")
+    return y, mean, invstd
+
+
+def bn_act_backward(x, y, dy, gamma, save_mean, save_invstd, training, relu, want_residual):
+    """-> (dx, dresidual | None, dgamma, dbeta)"""
+    _need_cuda(x, dy)
+    xx, g = x.contiguous().float(), dy.contiguous().float()
+    n, c = xx.shape
+    dev = xx.device
+    dx = torch.empty_like(xx)
+    dres = torch.empty_like(xx) if want_residual else None
+    dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
+    dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+    nbytes = lib.msmd_bn_workspace_bytes(n, c)
+    ws = _ws(nbytes, dev)
+    check(lib.msmd_bn_act_bwd_f32(_p(xx), _p(y), _p(g), n, c, _p(gamma), _p(save_mean),
+                                  _p(save_invstd), int(bool(training)), int(bool(relu)), _p(dx),
+                                  _p(dres), _p(dgamma), _p(dbeta), _p(ws), nbytes, _stream()),
+          "msmd_bn_act_bwd_f32")
+    return dx, dres, dgamma, dbeta
 
 
 # ------------------------------------------------------------------ dense / sets

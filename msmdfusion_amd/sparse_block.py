@@ -9,6 +9,7 @@ from torch import nn
 
 from . import spconv
 from .registry import build_conv_layer, build_norm_layer
+from .spconv.functional import bn_act
 
 
 class SparseBasicBlock(spconv.SparseModule):
@@ -40,15 +41,13 @@ class SparseBasicBlock(spconv.SparseModule):
     def forward(self, x):  # sparse_block.py:103-126
         identity = x.features
         assert x.features.dim() == 2, f"x.features.dim()={x.features.dim()}"
+        # relu(norm1(.)) and relu(norm2(.) + identity) each run as one fused op
         out = self.conv1(x)
-        out = out.replace_feature(self.norm1(out.features))
-        out = out.replace_feature(self.relu(out.features))
+        out = out.replace_feature(bn_act(out.features, self.norm1, relu=True))
         out = self.conv2(out)
-        out = out.replace_feature(self.norm2(out.features))
         if self.downsample is not None:
             identity = self.downsample(x)
-        out = out.replace_feature(out.features + identity)
-        out = out.replace_feature(self.relu(out.features))
+        out = out.replace_feature(bn_act(out.features, self.norm2, relu=True, residual=identity))
         return out
 
 

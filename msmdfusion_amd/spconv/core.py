@@ -31,6 +31,8 @@ class IndiceData:
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
         self.algo = algo
         self._pairs = None
+        self._order_fwd = None
+        self._order_bwd = None
 
     @property
     def n_in(self):
@@ -45,6 +47,20 @@ class IndiceData:
         if self._pairs is None:
             self._pairs = K.rulebook_pairs(self.nbr_fwd, ld=max(self.n_in, self.n_out, 1))
         return self._pairs
+
+    def order_fwd(self):
+        """Tiling order of the output rows (sorted by neighbour mask); for SubM
+        the same order serves dgrad (its table is the forward one mirrored)."""
+        if self._order_fwd is None:
+            self._order_fwd = (K.row_mask_order(self.nbr_fwd),)
+        return self._order_fwd[0]
+
+    def order_bwd(self):
+        if self.is_subm:
+            return self.order_fwd()
+        if self._order_bwd is None:
+            self._order_bwd = (K.row_mask_order(self.nbr_bwd),)
+        return self._order_bwd[0]
 
 
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,

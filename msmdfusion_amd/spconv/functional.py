@@ -20,7 +20,8 @@ class _SparseConvFunction(Function):
         ctx.rb = rb
         ctx.save_for_backward(features, weight_kio)
         packed = K.pack_weight(weight_kio)
-        return K.conv_forward(features, packed, rb.nbr_fwd, rb.n_out, weight_kio.shape[2])
+        return K.conv_forward(features, packed, rb.nbr_fwd, rb.n_out, weight_kio.shape[2],
+                              row_order=rb.order_fwd())
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -32,10 +33,11 @@ class _SparseConvFunction(Function):
             packed_t = K.pack_weight(weight_kio, transpose=True)
             if rb.is_subm:   # forward table + flipped weights == backward table
                 d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_fwd, rb.n_in,
-                                        weight_kio.shape[1], weight_flip=True)
+                                        weight_kio.shape[1], weight_flip=True,
+                                        row_order=rb.order_bwd())
             else:
                 d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_bwd, rb.n_in,
-                                        weight_kio.shape[1])
+                                        weight_kio.shape[1], row_order=rb.order_bwd())
         if ctx.needs_input_grad[1]:
             pairs, num = rb.pairs()
             d_w = K.conv_wgrad(features, grad_out, pairs, num)
@@ -44,6 +46,55 @@ class _SparseConvFunction(Function):
 
 def sparse_conv(features, weight_kio, rb):
     return _SparseConvFunction.apply(features, weight_kio, rb)
+
+
+class _BNActFunction(Function):
+    """BatchNorm1d (+ residual) (+ ReLU) in two fused passes each way
+    (csrc/bn.hip) instead of torch's 3-5 launches per conv."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, training, momentum,
+                eps, relu):
+        y, mean, invstd = K.bn_act_forward(x, residual, gamma, beta, running_mean, running_var,
+                                           training, momentum, eps, relu)
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.cfg = (bool(training), bool(relu), residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        training, relu, has_res = ctx.cfg
+        dx, dres, dgamma, dbeta = K.bn_act_backward(x, y, dy, gamma, mean, invstd, training, relu,
+                                                    has_res and ctx.needs_input_grad[1])
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_act(x, bn, relu=False, residual=None):
+    """Apply an nn.BatchNorm1d module (its parameters / buffers / mode) fused
+    with an optional residual add and ReLU.  Same semantics as
+    relu(bn(x) + residual), including the running-stat update."""
+    if x.shape[0] == 0:     # SparseSequential skips dense modules on empty tensors
+        return x
+    fusable = (x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and bn.affine
+               and bn.momentum is not None)
+    if not fusable:
+        y = bn(x)
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if relu else y
+    # nn.modules.batchnorm._BatchNorm.forward: batch statistics when training or
+    # when there are no buffers; the buffers are handed to the kernel (and, in
+    # training, updated) only when `not training or track_running_stats`
+    # (tools/train.py:205-211 flips track_running_stats on frozen layers).
+    use_batch_stats = bn.training or bn.running_mean is None
+    pass_running = (not bn.training) or bn.track_running_stats
+    rm = bn.running_mean if pass_running else None
+    rv = bn.running_var if pass_running else None
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BNActFunction.apply(x, residual, bn.weight, bn.bias, rm, rv, use_batch_stats,
+                                bn.momentum, bn.eps, relu)
 
 
 class _DenseFunction(Function):

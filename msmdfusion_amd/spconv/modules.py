@@ -63,14 +63,25 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        from .functional import bn_act
+        mods = list(self._modules.items())
+        i = 0
+        while i < len(mods):
+            k, module = mods[i]
+            i += 1
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 self._sparity_dict[k] = input.sparity
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
-                    input = input.replace_feature(module(input.features))
+                    if isinstance(module, nn.BatchNorm1d):
+                        # [BN1d, ReLU] (make_sparse_convmodule) runs as one fused op
+                        relu = i < len(mods) and isinstance(mods[i][1], nn.ReLU)
+                        input = input.replace_feature(bn_act(input.features, module, relu=relu))
+                        i += int(relu)
+                    else:
+                        input = input.replace_feature(module(input.features))
             else:
                 input = module(input)
         return input

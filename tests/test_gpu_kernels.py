@@ -172,6 +172,14 @@ def test_subm_conv_fwd_bwd(dev, cin, cout):
     wd = t(w, dev)
     out = K.conv_forward(t(f, dev), K.pack_weight(wd), nbr, n, cout)
     np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=TOL, atol=TOL)
+    # any tiling order gives bit-identical results (mask-sorted and random)
+    order = K.row_mask_order(nbr)
+    assert sorted(order.cpu().tolist()) == list(range(n))
+    out_o = K.conv_forward(t(f, dev), K.pack_weight(wd), nbr, n, cout, row_order=order)
+    assert torch.equal(out, out_o)
+    perm = torch.randperm(n, device=dev).int()
+    assert torch.equal(out, K.conv_forward(t(f, dev), K.pack_weight(wd), nbr, n, cout,
+                                           row_order=perm))
     # dgrad: forward table read with flipped weights and W^T
     din = K.conv_forward(t(g, dev), K.pack_weight(wd, transpose=True), nbr, n, cin,
                          weight_flip=True)

@@ -158,6 +158,55 @@ def test_sparse_encoder_forward_matches_oracle(dev):
     assert all(p.grad is not None for p in enc.parameters())
 
 
+@pytest.mark.parametrize("c,relu,res", [(16, True, False), (80, True, True), (128, False, False),
+                                        (192, True, True)])
+def test_fused_bn_act_matches_torch(dev, c, relu, res):
+    """bn_act == relu(bn(x) + residual) of torch (float64 reference): outputs,
+    all gradients, running statistics; training and eval."""
+    from msmdfusion_amd.spconv.functional import bn_act
+    torch.manual_seed(c)
+    n = 3000
+    x = (torch.randn(n, c, device=dev) * 2 + 0.5)
+    r = torch.randn(n, c, device=dev) if res else None
+    g = torch.randn(n, c, device=dev)
+    for training in (True, False):
+        bn = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev)
+        ref = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev).double()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+            bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2)
+            ref.load_state_dict(bn.state_dict())
+        bn.train(training); ref.train(training)
+        xa = x.clone().requires_grad_(True)
+        ra = r.clone().requires_grad_(True) if res else None
+        y = bn_act(xa, bn, relu=relu, residual=ra)
+        y.backward(g)
+        xb = x.double().requires_grad_(True)
+        rb = r.double().requires_grad_(True) if res else None
+        yb = ref(xb)
+        if res:
+            yb = yb + rb
+        if relu:
+            yb = torch.relu(yb)
+        yb.backward(g.double())
+        np.testing.assert_allclose(_np(y), _np(yb), rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(_np(xa.grad), _np(xb.grad), rtol=1e-4, atol=2e-5)
+        if res:
+            np.testing.assert_allclose(_np(ra.grad), _np(rb.grad), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(_np(bn.weight.grad), _np(ref.weight.grad), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(_np(bn.bias.grad), _np(ref.bias.grad), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(_np(bn.running_mean), _np(ref.running_mean), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(_np(bn.running_var), _np(ref.running_var), rtol=1e-5, atol=1e-6)
+        assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+    # frozen layer (tools/train.py:205-211): batch statistics, buffers untouched
+    bn = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev).train()
+    bn.track_running_stats = False
+    before = bn.running_mean.clone()
+    y = bn_act(x, bn, relu=False)
+    assert torch.equal(bn.running_mean, before)
+    np.testing.assert_allclose(_np(y.mean(0)), _np(bn.bias), atol=1e-4)
+
+
 def test_voxelization_module_and_vfe(dev):
     from msmdfusion_amd.voxel_encoder import HardSimpleVFE
     from msmdfusion_amd.voxelize import Voxelization
