@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--diag", action="store_true", help="print host enqueue vs step time")
     ap.add_argument("--no-profile", action="store_true",
                     help="skip per-launch event timing of the conv kernels")
     return ap.parse_args()
@@ -67,8 +68,7 @@ class Backbone(torch.nn.Module):
     def voxelize(self, points):
         """transfusion.py:76-101 with the VFE fused into the gather."""
         feats, coors = [], []
-        for b, pts in enumerate(points):
-            mean, c, _ = self.voxel_layer.forward_mean(pts)
+        for b, (mean, c, _) in enumerate(self.voxel_layer.forward_batch(points, fused_mean=True)):
             feats.append(mean)
             coors.append(F.pad(c, (1, 0), mode="constant", value=b))
         return torch.cat(feats, 0), torch.cat(coors, 0)
@@ -175,13 +175,28 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.diag and rank == 0:     # host enqueue time vs device time, outside the timed region
+        for _ in range(3):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            step()
+            b = time.perf_counter()
+            torch.cuda.synchronize()
+            c = time.perf_counter()
+            print("diag: enqueue %.2f ms, step %.2f ms" % ((b - a) * 1e3, (c - a) * 1e3),
+                  file=sys.stderr)
+    # Per-launch HIP events (recorded on the launch stream) bracket every conv
+    # launch of a few timed steps only: on ROCm a timing event is a barrier
+    # packet that drains the queue, so bracketing all ~85 launches of every
+    # step would slow the measured throughput by ~25 %.
     prof = None if args.no_profile else []
-    K.PROFILE = prof
+    sampled = set() if prof is None else {0, args.steps // 2}
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        K.PROFILE = prof if i in sampled else None
         loss = step()
     torch.cuda.synchronize()
     if world > 1:

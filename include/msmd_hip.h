@@ -174,13 +174,19 @@ int msmd_spconv_fwd_f32(const float* in_feat /* [n_in,c_in] */, int n_in,
                         const int32_t* nbr /* [K,ld] */, int ld, int n_out,
                         int kernel_volume, int weight_flip,
                         const int32_t* row_order /* [n_out] or NULL */,
+                        int32_t* tile_counter /* [1] scratch or NULL */,
                         float* out_feat /* [n_out,c_out] */, int c_out,
                         msmd_stream_t stream);
+/* tile_counter != NULL selects the persistent form: a fixed number of resident
+ * workgroups draw row tiles from *tile_counter (zeroed by the call) -- with a
+ * heaviest-first row_order this balances the very uneven per-tile cost. */
 
-/* masks[o] = bitset over k of (nbr[k][o] >= 0); kernel_volume <= 64. */
+/* masks[o] = bitset over k of (nbr[k][o] >= 0); sort_keys[o] orders rows
+ * heaviest mask first with equal masks adjacent.  Either output may be NULL.
+ * kernel_volume <= 64. */
 int msmd_rulebook_row_masks(const int32_t* nbr /* [K,n_rows] */,
                             int kernel_volume, int n_rows, uint64_t* masks,
-                            msmd_stream_t stream);
+                            int64_t* sort_keys, msmd_stream_t stream);
 
 /* dW[k] = sum over pairs p of offset k: in[pairs[k,0,p],:]^T (x) dout[pairs[k,1,p],:]
  * (spconv_ops.h:399,438).  Deterministic two-pass reduction. */

@@ -27,6 +27,8 @@
 // (spconv_ops.h:399,438) contracts over the compact pair lists.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace msmd {
 namespace {
 
@@ -69,130 +71,414 @@ template <int NT, int R, bool VEC>
 __global__ __launch_bounds__(256) void spconv_fwd_kernel(
     const float* __restrict__ in, int cin, const float* __restrict__ wp,
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
-    const int32_t* __restrict__ order, float* __restrict__ out, int cout) {
+    const int32_t* __restrict__ order, int* __restrict__ tile_counter, float* __restrict__ out,
+    int cout, int dbg) {
   __shared__ f32x4 wl[kTC * NT * 64];
+  __shared__ int s_tile;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int T = (cin + 15) / 16;
-  const int row0 = (blockIdx.x * 4 + wave) * (R * 16);
+  constexpr int kTileRows = 4 * R * 16;
+  const int n_tiles = (n_out + kTileRows - 1) / kTileRows;
 
-  f32x4 acc[R][NT];
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // Persistent workgroups pull tiles from a global counter.  With rows sorted
+  // heaviest-mask-first the tiles arrive in decreasing cost, so this is
+  // longest-processing-time-first list scheduling: CUs that drew cheap tiles
+  // simply draw more (a static grid left the MFMA pipes idle ~45 % of the time
+  // on the 128-channel layers because tile cost varies 3x with the mask).
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = tile_counter ? atomicAdd(tile_counter, 1) : (int)blockIdx.x;
+    __syncthreads();
+    const int tile = s_tile;
+    if (tile >= n_tiles) break;
+    const int row0 = (tile * 4 + wave) * (R * 16);
 
-  int rows[R];  // output row of this lane's column j in group r, or -1
+    f32x4 acc[R][NT];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int p = row0 + r * 16 + j;
-    rows[r] = p < n_out ? (order ? order[p] : p) : -1;
-  }
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int k = 0; k < kvol; ++k) {
-    const int kw = flip ? kvol - 1 - k : k;
-    int src[R];
-    bool any = false;
+    int rows[R];  // output row of this lane's column j in group r, or -1
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      src[r] = rows[r] >= 0 ? nbr[(size_t)k * ld + rows[r]] : -1;
-      any |= src[r] >= 0;
+      const int p = row0 + r * 16 + j;
+      rows[r] = p < n_out ? (order ? order[p] : p) : -1;
     }
-    const bool wave_any = __any(any);
-    // block-uniform: nobody needs this offset -> no weight staging, no MFMAs
-    if (!__syncthreads_or(wave_any)) continue;
-    for (int t0 = 0; t0 < T; t0 += kTC) {
-      const int tc = (T - t0) < kTC ? (T - t0) : kTC;
-      // ---- stage W[kw][t0 .. t0+tc) : tc*NT*64 float4, straight copy ----
-      if (t0 > 0) __syncthreads();
-      {
-        const f32x4* g = (const f32x4*)wp + ((size_t)kw * T + t0) * NT * 64;
-        for (int e = threadIdx.x; e < tc * NT * 64; e += 256) wl[e] = g[e];
-      }
-      // ---- gather this wave's input rows (overlaps the fill) ----
-      f32x4 b[R][kTC];
-      if (wave_any) {
+
+    for (int k = 0; k < kvol; ++k) {
+      const int kw = flip ? kvol - 1 - k : k;
+      int src[R];
+      bool any = false;
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+      for (int r = 0; r < R; ++r) {
+        src[r] = rows[r] >= 0 ? nbr[(size_t)k * ld + rows[r]] : -1;
+        any |= src[r] >= 0;
+      }
+      const bool wave_any = __any(any);
+      // block-uniform: nobody needs this offset -> no weight staging, no MFMAs
+      // (the barrier also fences the previous offset's reads of wl / s_tile)
+      if (!__syncthreads_or(wave_any)) continue;
+      for (int t0 = 0; t0 < T; t0 += kTC) {
+        const int tc = (T - t0) < kTC ? (T - t0) : kTC;
+        // ---- stage W[kw][t0 .. t0+tc) : tc*NT*64 float4, straight copy ----
+        if (t0 > 0) __syncthreads();
+        if (!(dbg & 2)) {
+          const f32x4* g = (const f32x4*)wp + ((size_t)kw * T + t0) * NT * 64;
+          for (int e = threadIdx.x; e < tc * NT * 64; e += 256) wl[e] = g[e];
+        }
+        // ---- gather this wave's input rows (overlaps the fill) ----
+        f32x4 b[R][kTC];
+        if (wave_any) {
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int t = 0; t < kTC; ++t) {
+              f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+              const int c0 = 16 * (t0 + t) + 4 * q;
+              if (t < tc && src[r] >= 0 && !(dbg & 1)) {
+                const float* p = in + (size_t)src[r] * cin + c0;
+                if (VEC) {
+                  if (c0 < cin) v = *(const f32x4*)p;
+                } else {
+#pragma unroll
+                  for (int s = 0; s < 4; ++s)
+                    if (c0 + s < cin) v[s] = p[s];
+                }
+              }
+              b[r][t] = v;
+            }
+        }
+        __syncthreads();
+        if (wave_any) {
 #pragma unroll
           for (int t = 0; t < kTC; ++t) {
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int c0 = 16 * (t0 + t) + 4 * q;
-            if (t < tc && src[r] >= 0) {
-              const float* p = in + (size_t)src[r] * cin + c0;
-              if (VEC) {
-                if (c0 < cin) v = *(const f32x4*)p;
-              } else {
+            if (t < tc) {
+#pragma unroll
+              for (int n = 0; n < NT; ++n) {
+                const f32x4 a = wl[(t * NT + n) * 64 + lane];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                  if (c0 + s < cin) v[s] = p[s];
+#pragma unroll
+                  for (int r = 0; r < R; ++r)
+                    acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[r][t][s],
+                                                                     acc[r][n], 0, 0, 0);
               }
-            }
-            b[r][t] = v;
-          }
-      }
-      __syncthreads();
-      if (wave_any) {
-#pragma unroll
-        for (int t = 0; t < kTC; ++t) {
-          if (t < tc) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              const f32x4 a = wl[(t * NT + n) * 64 + lane];
-#pragma unroll
-              for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                  acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[r][t][s], acc[r][n],
-                                                                   0, 0, 0);
             }
           }
         }
       }
     }
-  }
-  // ---- epilogue: lane (j,q) holds out[row j][16n + 4q .. +3] ----
+    // ---- epilogue: lane (j,q) holds out[row j][16n + 4q .. +3] ----
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    if (rows[r] < 0) continue;
-    float* o = out + (size_t)rows[r] * cout;
+    for (int r = 0; r < R; ++r) {
+      if (rows[r] < 0) continue;
+      float* o = out + (size_t)rows[r] * cout;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int c0 = 16 * n + 4 * q;
-      if ((cout & 3) == 0) {
-        if (c0 < cout) *(f32x4*)(o + c0) = acc[r][n];
-      } else {
+      for (int n = 0; n < NT; ++n) {
+        const int c0 = 16 * n + 4 * q;
+        if ((cout & 3) == 0) {
+          if (c0 < cout) *(f32x4*)(o + c0) = acc[r][n];
+        } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          if (c0 + s < cout) o[c0 + s] = acc[r][n][s];
+          for (int s = 0; s < 4; ++s)
+            if (c0 + s < cout) o[c0 + s] = acc[r][n][s];
+        }
       }
     }
+    if (!tile_counter) break;
+    __syncthreads();  // every thread has read s_tile / wl before the next draw
   }
+}
+
+// Tuning knobs (defaults chosen from on-device sweeps, tools/conv_sweep.py);
+// MSMD_FWD_SLOTS / MSMD_FWD_R override them for experiments.
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+inline int fwd_slots_per_cu() {
+  static const int v = env_int("MSMD_FWD_SLOTS", 3);
+  return v;
+}
+inline int fwd_rows_variant() {  // 0 = per-NT default, 1 / 2 = force R
+  static const int v = env_int("MSMD_FWD_R", 0);
+  return v;
+}
+
+inline int fwd_pipe_enabled() {
+  static const int v = env_int("MSMD_FWD_PIPE", 1);
+  return v;
+}
+
+// ---------------------------------------------------- pipelined forward ----
+// Same math and tiling as spconv_fwd_kernel, restructured so that no memory
+// latency sits on the MFMA critical path (PMC on the unpipelined kernel: MFMA
+// pipe 41 % busy, waves 36 % in s_waitcnt/barrier -- every offset paid one
+// dependent nbr load, one weight copy and one row gather round trip):
+//   * the tile's whole neighbour table slice nbr[0..K)[rows] is staged in LDS
+//     once (one latency), which also yields the tile's list of active offsets;
+//   * work items = (active offset, 64-channel chunk).  While item i's MFMAs
+//     run out of LDS buffer i&1, item i+1's packed weights (global -> regs) and
+//     gathered input rows (global -> MFMA operand regs) are already in flight;
+//     one barrier per item (double-buffered weights);
+//   * R == 1 interleaves two output tiles per weight step so consecutive
+//     MFMAs never hit the same accumulator (40-cycle dependent latency vs
+//     32-cycle issue on v_mfma_f32_16x16x4_f32).
+constexpr int kMaxK = 32;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// NT: c_out/16 tiles, R: 16-row groups per wave, KC: 16-channel steps per item
+// (requires c_in % (16*KC) == 0 and c_out % 4 == 0: no tails, straight-line code).
+template <int NT, int R, int KC>
+__global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(
+    const float* __restrict__ in, int cin, const float* __restrict__ wp,
+    const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
+    const int32_t* __restrict__ order, int* __restrict__ tile_counter, float* __restrict__ out,
+    int cout) {
+  constexpr int kRows = 4 * R * 16;
+  constexpr int kPieces = KC * NT;      // 1-KiB (64 x float4) pieces per weight chunk
+  constexpr int kWF4 = kPieces * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* wl = (f32x4*)smem;                      // [2][kWF4]
+  int* nb = (int*)(wl + 2 * kWF4);               // [kMaxK][kRows]
+  int* srow = nb + kMaxK * kRows;                // [kRows]
+  int* act = srow + kRows;                       // [kMaxK]
+  int* klist = act + kMaxK;                      // [kMaxK]
+  int* sctl = klist + kMaxK;                     // [0] tile, [1] #active offsets
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int nchunk = cin / (16 * KC);
+  const int n_tiles = (n_out + kRows - 1) / kRows;
+  const size_t chunk_f4 = (size_t)kWF4;          // packed weights: [k][chunk][kWF4]
+
+  for (;;) {
+    if (tid == 0) sctl[0] = tile_counter ? atomicAdd(tile_counter, 1) : (int)blockIdx.x;
+    if (tid < kMaxK) act[tid] = 0;
+    __syncthreads();
+    const int tile = sctl[0];
+    if (tile >= n_tiles) break;
+    if (tid < kRows) {
+      const int p = tile * kRows + tid;
+      srow[tid] = p < n_out ? (order ? order[p] : p) : -1;
+    }
+    __syncthreads();
+    for (int e = tid; e < kvol * kRows; e += 256) {
+      const int k = e / kRows, rr = e - k * kRows;
+      const int row = srow[rr];
+      const int v = row >= 0 ? nbr[(size_t)k * ld + row] : -1;
+      nb[k * kRows + rr] = v;
+      if (v >= 0) act[k] = 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int n = 0;
+      for (int k = 0; k < kvol; ++k)
+        if (act[k]) klist[n++] = k;
+      sctl[1] = n;
+    }
+    __syncthreads();
+    const int n_items = sctl[1] * nchunk;
+
+    f32x4 acc[R][NT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int lr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) lr[r] = (wave * R + r) * 16 + j;
+
+    // Start item `it`: weights by LDS-DMA into buffer it&1 (no registers, no
+    // ds_write pass), gathered rows into the operand registers `b`.
+    auto issue = [&](int it, f32x4 (&b)[R][KC], int (&valid)[R]) {
+      const int k = klist[it / nchunk];
+      const int ch = it % nchunk;
+      const int kw = flip ? kvol - 1 - k : k;
+      const f32x4* g = (const f32x4*)wp + ((size_t)kw * nchunk + ch) * chunk_f4;
+      f32x4* wb = wl + (it & 1) * kWF4;
+#pragma unroll
+      for (int p = 0; p < (kPieces + 3) / 4; ++p) {
+        const int piece = wave + 4 * p;
+        if (kPieces % 4 == 0 || piece < kPieces)
+          __builtin_amdgcn_global_load_lds((glb_void*)(g + piece * 64 + lane),
+                                           (lds_void*)(wb + piece * 64), 16, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int src = nb[k * kRows + lr[r]];
+        valid[r] = src;
+        const float* row = in + (size_t)(src < 0 ? 0 : src) * cin + ch * (16 * KC) + 4 * q;
+#pragma unroll
+        for (int t = 0; t < KC; ++t) b[r][t] = *(const f32x4*)(row + 16 * t);
+      }
+    };
+    auto compute = [&](int it, f32x4 (&b)[R][KC], const int (&valid)[R]) {
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        any |= valid[r] >= 0;
+        if (valid[r] < 0) {
+#pragma unroll
+          for (int t = 0; t < KC; ++t) b[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      if (!__any(any)) return;
+      const f32x4* wb = wl + (it & 1) * kWF4;
+#pragma unroll
+      for (int t = 0; t < KC; ++t) {
+        if (R >= 2) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const f32x4 a = wb[(t * NT + n) * 64 + lane];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int r = 0; r < R; ++r)
+                acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[r][t][s], acc[r][n], 0,
+                                                                 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int n = 0; n < NT; n += 2) {
+            const f32x4 a0 = wb[(t * NT + n) * 64 + lane];
+            const f32x4 a1 = wb[(t * NT + (n + 1 < NT ? n + 1 : n)) * 64 + lane];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              acc[0][n] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b[0][t][s], acc[0][n], 0, 0, 0);
+              if (n + 1 < NT)
+                acc[0][n + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b[0][t][s],
+                                                                     acc[0][n + 1], 0, 0, 0);
+            }
+          }
+        }
+      }
+    };
+    // one pipeline step: wait for item `it`'s data, start item it+1, compute it
+    f32x4 b0[R][KC], b1[R][KC];
+    int v0[R], v1[R];
+#define MSMD_STEP(IT, BC, VC, BN, VN)                          \
+  {                                                            \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           \
+    __syncthreads();                                           \
+    if ((IT) + 1 < n_items) issue((IT) + 1, BN, VN);           \
+    compute((IT), BC, VC);                                     \
+  }
+    if (n_items > 0) issue(0, b0, v0);
+    for (int it = 0; it < n_items; it += 2) {
+      MSMD_STEP(it, b0, v0, b1, v1);
+      if (it + 1 < n_items) MSMD_STEP(it + 1, b1, v1, b0, v0);
+    }
+#undef MSMD_STEP
+    // ---- epilogue: lane (j,q) holds out[row j][16n + 4q .. +3] ----
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = srow[lr[r]];
+      if (row < 0) continue;
+      float* o = out + (size_t)row * cout + 4 * q;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        if (16 * n + 4 * q < cout) *(f32x4*)(o + 16 * n) = acc[r][n];
+    }
+    if (!tile_counter) break;
+    __syncthreads();  // LDS tables are reused by the next tile
+  }
+}
+
+template <int NT, int R, int KC>
+int launch_fwd_pipe(const float* in, int cin, const float* wp, const int32_t* nbr, int ld,
+                    int n_out, int kvol, int flip, const int32_t* order, int* tile_counter,
+                    float* out, int cout, hipStream_t st) {
+  constexpr int kRows = 4 * R * 16;
+  const size_t smem = sizeof(f32x4) * 2 * KC * NT * 64 +
+                      sizeof(int) * ((size_t)kMaxK * kRows + kRows + 2 * kMaxK + 8);
+  const int n_tiles = ceil_div(n_out, kRows);
+  int nblk = n_tiles;
+  if (tile_counter) {
+    hipMemsetAsync(tile_counter, 0, sizeof(int), st);
+    const int slots = 256 * fwd_slots_per_cu();
+    if (nblk > slots) nblk = slots;
+  }
+  auto kern = spconv_fwd_pipe_kernel<NT, R, KC>;
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  MSMD_LAUNCH(kern, dim3(nblk), dim3(256), smem, st, in, cin, wp, nbr, ld, n_out, kvol, flip,
+              order, tile_counter, out, cout);
+  return launch_status();
+}
+
+// Largest chunk (in 16-channel steps) that divides c_in and keeps two weight
+// buffers within LDS: KC in {4, 2, 1}.
+template <int NT, int R>
+int dispatch_fwd_pipe(const float* in, int cin, const float* wp, const int32_t* nbr, int ld,
+                      int n_out, int kvol, int flip, const int32_t* order, int* tile_counter,
+                      float* out, int cout, hipStream_t st) {
+  const int T = cin / 16;
+  static const int kc_force = env_int("MSMD_FWD_KC", 0);
+  if (kc_force == 1 || (kc_force == 2 && T % 2 != 0))
+    return launch_fwd_pipe<NT, R, 1>(in, cin, wp, nbr, ld, n_out, kvol, flip, order, tile_counter,
+                                     out, cout, st);
+  if (kc_force == 2)
+    return launch_fwd_pipe<NT, R, 2>(in, cin, wp, nbr, ld, n_out, kvol, flip, order,
+                                     tile_counter, out, cout, st);
+  if (NT <= 8 && T % 4 == 0)
+    return launch_fwd_pipe<NT, R, 4>(in, cin, wp, nbr, ld, n_out, kvol, flip, order,
+                                     tile_counter, out, cout, st);
+  if (T % 2 == 0)
+    return launch_fwd_pipe<NT, R, 2>(in, cin, wp, nbr, ld, n_out, kvol, flip, order,
+                                     tile_counter, out, cout, st);
+  return launch_fwd_pipe<NT, R, 1>(in, cin, wp, nbr, ld, n_out, kvol, flip, order, tile_counter,
+                                   out, cout, st);
 }
 
 template <int NT, int R>
 int launch_fwd(const float* in, int cin, const float* wp, const int32_t* nbr, int ld, int n_out,
-               int kvol, int flip, const int32_t* order, float* out, int cout, hipStream_t st) {
+               int kvol, int flip, const int32_t* order, int* tile_counter, float* out, int cout,
+               hipStream_t st) {
+  if (fwd_pipe_enabled() && (cin & 15) == 0 && (cout & 3) == 0 && kvol <= kMaxK && NT >= 4)
+    return dispatch_fwd_pipe<NT, R>(in, cin, wp, nbr, ld, n_out, kvol, flip, order, tile_counter,
+                                    out, cout, st);
   const int rows_per_block = 4 * R * 16;
-  dim3 grid(ceil_div(n_out, rows_per_block));
+  const int n_tiles = ceil_div(n_out, rows_per_block);
+  int nblk = n_tiles;
+  if (tile_counter) {
+    hipMemsetAsync(tile_counter, 0, sizeof(int), st);
+    const int slots = 256 * fwd_slots_per_cu();
+    if (nblk > slots) nblk = slots;
+  }
+  dim3 grid(nblk);
+  static const int dbg = env_int("MSMD_DBG", 0);  // ablation bits, experiments only
   if ((cin & 3) == 0)
     MSMD_LAUNCH((spconv_fwd_kernel<NT, R, true>), grid, dim3(256), 0, st, in, cin, wp, nbr, ld,
-                n_out, kvol, flip, order, out, cout);
+                n_out, kvol, flip, order, tile_counter, out, cout, dbg);
   else
     MSMD_LAUNCH((spconv_fwd_kernel<NT, R, false>), grid, dim3(256), 0, st, in, cin, wp, nbr, ld,
-                n_out, kvol, flip, order, out, cout);
+                n_out, kvol, flip, order, tile_counter, out, cout, dbg);
   return launch_status();
 }
 
-// Neighbour mask of every output row: bit k set when nbr[k][row] >= 0 (K <= 64).
+// Neighbour mask of every output row: bit k set when nbr[k][row] >= 0 (K <= 64),
+// and a sort key that orders rows heaviest first, equal masks adjacent:
+// key = (K - popcount) << K | mask  (K <= 27: fits 32 bits; else the raw mask).
 __global__ __launch_bounds__(256) void row_mask_kernel(const int32_t* __restrict__ nbr, int kvol,
-                                                       int n, unsigned long long* __restrict__ m) {
+                                                       int n, unsigned long long* __restrict__ m,
+                                                       long long* __restrict__ key) {
   int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= n) return;
   unsigned long long v = 0;
   for (int k = 0; k < kvol; ++k)
     if (nbr[(size_t)k * n + o] >= 0) v |= 1ull << k;
-  m[o] = v;
+  if (m) m[o] = v;
+  if (key)
+    key[o] = kvol <= 31 ? (long long)(((unsigned long long)(kvol - __popcll(v)) << kvol) | v)
+                        : (long long)(v >> 1);
 }
 
 // ------------------------------------------------------------------ wgrad --
@@ -362,37 +648,42 @@ MSMD_EXPORT int msmd_spconv_pack_weight(const float* weight, int kernel_volume, 
 }
 
 MSMD_EXPORT int msmd_rulebook_row_masks(const int32_t* nbr, int kernel_volume, int n_rows,
-                                        uint64_t* masks, msmd_stream_t stream) {
+                                        uint64_t* masks, int64_t* sort_keys,
+                                        msmd_stream_t stream) {
   if (kernel_volume < 1 || kernel_volume > 64) return MSMD_ERR_UNSUPPORTED;
-  if (n_rows < 0 || (n_rows > 0 && (!nbr || !masks))) return MSMD_ERR_INVALID_ARG;
+  if (n_rows < 0 || (n_rows > 0 && (!nbr || (!masks && !sort_keys)))) return MSMD_ERR_INVALID_ARG;
   if (n_rows == 0) return MSMD_OK;
   MSMD_LAUNCH(row_mask_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, (hipStream_t)stream,
-              nbr, kernel_volume, n_rows, (unsigned long long*)masks);
+              nbr, kernel_volume, n_rows, (unsigned long long*)masks, (long long*)sort_keys);
   return launch_status();
 }
 
 MSMD_EXPORT int msmd_spconv_fwd_f32(const float* in_feat, int n_in, int c_in,
                                     const float* packed_weight, const int32_t* nbr, int ld,
                                     int n_out, int kernel_volume, int weight_flip,
-                                    const int32_t* row_order, float* out_feat, int c_out,
-                                    msmd_stream_t stream) {
+                                    const int32_t* row_order, int32_t* tile_counter,
+                                    float* out_feat, int c_out, msmd_stream_t stream) {
   if (n_in < 0 || n_out < 0 || c_in < 1 || c_out < 1 || kernel_volume < 1 || ld < n_out)
     return MSMD_ERR_INVALID_ARG;
   if (n_out == 0) return MSMD_OK;
   if (!packed_weight || !nbr || !out_feat || (n_in > 0 && !in_feat)) return MSMD_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int NT = (c_out + 15) / 16;
+  if (NT < 4) {  // narrow layers are latency-bound: natural row order, static grid
+    row_order = nullptr;
+    tile_counter = nullptr;
+  }
 #define FWD(NTv, Rv)                                                                       \
   return launch_fwd<NTv, Rv>(in_feat, c_in, packed_weight, nbr, ld, n_out, kernel_volume, \
-                             weight_flip, row_order, out_feat, c_out, st)
+                             weight_flip, row_order, tile_counter, out_feat, c_out, st)
   switch (NT) {
     case 1: FWD(1, 2);
     case 2: FWD(2, 2);
     case 3: FWD(3, 2);
-    case 4: FWD(4, 2);
-    case 5: FWD(5, 2);
-    case 6: FWD(6, 2);
-    case 8: FWD(8, 2);
+    case 4: if (fwd_rows_variant() == 2) FWD(4, 2); else FWD(4, 1);
+    case 5: if (fwd_rows_variant() == 2) FWD(5, 2); else FWD(5, 1);
+    case 6: if (fwd_rows_variant() == 2) FWD(6, 2); else FWD(6, 1);
+    case 8: if (fwd_rows_variant() == 2) FWD(8, 2); else FWD(8, 1);
     case 12: FWD(12, 1);
     default: break;
   }

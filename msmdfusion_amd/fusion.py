@@ -21,11 +21,7 @@ def voxelize_batch(voxel_layer, points, downscale_factor=1.0, base_voxel_size=No
     base = list(base_voxel_size) if base_voxel_size is not None else [0.075, 0.075, 0.2]
     voxel_layer.voxel_size = [v * downscale_factor for v in base]   # :475-478 mutates the layer
     feats, coors, nums = [], [], []
-    for res in points:
-        if fused_mean:
-            f, c, n = voxel_layer.forward_mean(res)
-        else:
-            f, c, n = voxel_layer(res)
+    for f, c, n in voxel_layer.forward_batch(points, fused_mean=fused_mean):
         feats.append(f)
         coors.append(c)
         nums.append(n)

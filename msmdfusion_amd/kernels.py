@@ -68,6 +68,37 @@ def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels,
             mean[:m] if want_mean else None)
 
 
+def hard_voxelize_batch(points_list, voxel_size, coors_range, max_points, max_voxels,
+                        want_voxels=True, want_mean=False):
+    """hard_voxelize for every sample of a batch with ONE host read: all
+    launches are enqueued first, the B voxel counts come back together (the
+    reference syncs 4 times per sample, voxelization_cuda.cu:231-323)."""
+    pending = []
+    for points in points_list:
+        _need_cuda(points)
+        pts = points.contiguous().float()
+        n, c = pts.shape
+        dev = pts.device
+        voxels = torch.empty((max_voxels, max_points, c), dtype=torch.float32, device=dev) \
+            if want_voxels else None
+        mean = torch.empty((max_voxels, c), dtype=torch.float32, device=dev) if want_mean else None
+        coors = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
+        npv = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
+        count = torch.empty((1,), dtype=torch.int32, device=dev)
+        nbytes = lib.msmd_voxelize_workspace_bytes(n, max_voxels, max_points)
+        ws = _ws(nbytes, dev)
+        check(lib.msmd_hard_voxelize(_p(pts), n, c, float_arr(voxel_size),
+                                     float_arr(coors_range), int(max_points), int(max_voxels),
+                                     _p(voxels), _p(coors), _p(npv), _p(mean), _p(count), _p(ws),
+                                     nbytes, _stream()), "msmd_hard_voxelize")
+        pending.append((voxels, coors, npv, mean, count, pts, ws))
+    if not pending:
+        return []
+    counts = torch.cat([p[4] for p in pending]).tolist()
+    return [(v[:m] if want_voxels else None, c[:m], n[:m], mu[:m] if want_mean else None)
+            for (v, c, n, mu, _, _, _), m in zip(pending, counts)]
+
+
 def voxel_mean(voxels, num_points, out_features=None):
     _need_cuda(voxels, num_points)
     v = voxels.contiguous().float()
@@ -184,10 +215,11 @@ def row_mask_order(nbr):
     kvol, n = nbr.shape
     if kvol > 64 or n == 0:
         return None
-    masks = torch.empty((n,), dtype=torch.int64, device=nbr.device)
-    check(lib.msmd_rulebook_row_masks(_p(nbr), kvol, n, _p(masks), _stream()),
+    keys = torch.empty((n,), dtype=torch.int64, device=nbr.device)
+    check(lib.msmd_rulebook_row_masks(_p(nbr), kvol, n, None, _p(keys), _stream()),
           "msmd_rulebook_row_masks")
-    keys = masks.int() if kvol <= 31 else masks     # 32-bit keys: half the radix passes
+    if 2 * kvol <= 32 or (kvol <= 27):   # key fits 32 bits: half the radix passes
+        keys = (keys - 2147483648).int()   # unsigned order under a signed compare
     return torch.sort(keys, stable=False)[1].int()
 
 
@@ -198,10 +230,13 @@ def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False, row_
     n_in, c_in = f.shape
     kvol, ld = nbr.shape
     out = torch.empty((n_out, c_out), dtype=torch.float32, device=f.device)
+    # persistent tile scheduler whenever a (heaviest-first) order is supplied
+    counter = torch.empty((1,), dtype=torch.int32, device=f.device) \
+        if row_order is not None else None
     ev = _prof_begin()
     check(lib.msmd_spconv_fwd_f32(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld, int(n_out),
-                                  kvol, int(bool(weight_flip)), _p(row_order), _p(out),
-                                  int(c_out), _stream()),
+                                  kvol, int(bool(weight_flip)), _p(row_order), _p(counter),
+                                  _p(out), int(c_out), _stream()),
           "msmd_spconv_fwd_f32")
     _prof_end("spconv_fwd", ev, nbr=nbr, c_in=c_in, c_out=int(c_out), n_in=n_in, n_out=int(n_out))
     return out

@@ -5,6 +5,7 @@ state_dict keys match: conv_input.0.weight,
 encoder_layers.encoder_layer1.0.conv1.weight, ...), same return value
 (spatial_features[B, C*D, H, W], encode_features list -- this fork's change at
 sparse_encoder.py:117-133)."""
+import torch
 from torch import nn
 
 from . import spconv
@@ -48,6 +49,9 @@ class SparseEncoder(nn.Module):
     def forward(self, voxel_features, coors, batch_size):
         """voxel_features [N,C] fp32, coors [N,4] (b,z,y,x) -> (BEV, stage outputs)."""
         x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size)
+        # all 21 rulebooks (4 SubM voxel sets + 4 strided) before any feature work
+        convs = [m for m in self.modules() if isinstance(m, spconv.SparseConvolution)]
+        x.plan(convs, need_grad=torch.is_grad_enabled())
         x = self.conv_input(x)
         encode_features = [x]
         for encoder_layer in self.encoder_layers:

@@ -48,6 +48,14 @@ class IndiceData:
             self._pairs = K.rulebook_pairs(self.nbr_fwd, ld=max(self.n_in, self.n_out, 1))
         return self._pairs
 
+    def prepare(self, need_grad):
+        """Compute everything derived from the table now (tiling orders, and
+        the pair lists when a weight gradient will be needed) so that the
+        feature pass enqueues no index work and never waits on the host."""
+        if need_grad:
+            self.pairs()
+        return self
+
     def order_fwd(self):
         """Tiling order of the output rows (sorted by neighbour mask); for SubM
         the same order serves dgrad (its table is the forward one mirrored)."""
@@ -151,6 +159,28 @@ class SparseConvTensor:
                             list(stride), list(padding), list(dilation), subm)
         self._rb_cache[ident] = rb
         return rb
+
+    def plan(self, convs, need_grad):
+        """Index-only pre-pass: build (or fetch) the rulebook of every sparse
+        conv in `convs` (execution order), following the voxel set through the
+        strided ones.  Rulebooks depend on indices only, never on features, so
+        the whole chain -- including its host reads of output-voxel counts --
+        runs before the first feature kernel; the feature pass then finds every
+        rulebook in the shared cache."""
+        t = self
+        for conv in convs:
+            if getattr(conv, "conv1x1", False):
+                continue
+            rb = t.find_indice_pair(conv.indice_key) if conv.subm else None
+            if rb is None:
+                rb = t.cached_rulebook(conv.kernel_size, conv.stride, conv.padding,
+                                       conv.dilation, conv.subm)
+            rb.prepare(need_grad)
+            if not conv.subm:
+                t = t.shadow_copy()
+                t.indices = rb.out_indices
+                t.spatial_shape = rb.out_spatial_shape
+        return t
 
     def dense(self, channels_first: bool = True):
         """[B,C,D,H,W] (structure.py:55-64); channels_last returns the permuted

@@ -11,6 +11,12 @@ from torch.autograd import Function
 from .. import kernels as K
 
 
+def _wants_order(c_in, c_out):
+    """The pipelined kernel (c_out >= 64, c_in % 16 == 0) profits from the
+    mask-sorted tiling order; the narrow layers ignore it."""
+    return c_out >= 64 and c_in % 16 == 0
+
+
 class _SparseConvFunction(Function):
     """indice_conv / indice_subm_conv / implicit_gemm in one: forward and dgrad
     are the same implicit-GEMM kernel, wgrad contracts over the pair lists."""
@@ -20,8 +26,9 @@ class _SparseConvFunction(Function):
         ctx.rb = rb
         ctx.save_for_backward(features, weight_kio)
         packed = K.pack_weight(weight_kio)
-        return K.conv_forward(features, packed, rb.nbr_fwd, rb.n_out, weight_kio.shape[2],
-                              row_order=rb.order_fwd())
+        c_in, c_out = weight_kio.shape[1], weight_kio.shape[2]
+        return K.conv_forward(features, packed, rb.nbr_fwd, rb.n_out, c_out,
+                              row_order=rb.order_fwd() if _wants_order(c_in, c_out) else None)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -31,13 +38,14 @@ class _SparseConvFunction(Function):
         d_feat = d_w = None
         if ctx.needs_input_grad[0]:
             packed_t = K.pack_weight(weight_kio, transpose=True)
+            order = rb.order_bwd() if _wants_order(weight_kio.shape[2], weight_kio.shape[1]) \
+                else None
             if rb.is_subm:   # forward table + flipped weights == backward table
                 d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_fwd, rb.n_in,
-                                        weight_kio.shape[1], weight_flip=True,
-                                        row_order=rb.order_bwd())
+                                        weight_kio.shape[1], weight_flip=True, row_order=order)
             else:
                 d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_bwd, rb.n_in,
-                                        weight_kio.shape[1], row_order=rb.order_bwd())
+                                        weight_kio.shape[1], row_order=order)
         if ctx.needs_input_grad[1]:
             pairs, num = rb.pairs()
             d_w = K.conv_wgrad(features, grad_out, pairs, num)

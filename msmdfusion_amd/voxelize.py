@@ -57,6 +57,16 @@ class Voxelization(nn.Module):
         return voxelization_mean(input, self.voxel_size, self.point_cloud_range,
                                  self.max_num_points, self._max_voxels())
 
+    @torch.no_grad()
+    def forward_batch(self, points_list, fused_mean=False):
+        """The per-sample loop of the detectors' voxelize()
+        (MSMDFusion.py:479-483) with all launches enqueued before the single
+        host read of the voxel counts.  -> list of (voxels|mean, coors, num)."""
+        res = K.hard_voxelize_batch(points_list, self.voxel_size, self.point_cloud_range,
+                                    self.max_num_points, self._max_voxels(),
+                                    want_voxels=not fused_mean, want_mean=fused_mean)
+        return [((mu if fused_mean else v), c, n) for v, c, n, mu in res]
+
     def __repr__(self):
         return (f"{self.__class__.__name__}(voxel_size={self.voxel_size}, point_cloud_range="
                 f"{self.point_cloud_range}, max_num_points={self.max_num_points}, "

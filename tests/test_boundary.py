@@ -58,13 +58,13 @@ def test_host_side_argument_validation():
     # 70000^3 cells cannot be indexed with 32-bit linear ids
     assert lib.msmd_rulebook_subm3d(None, 0, 1, int3([70000] * 3), int3([3, 3, 3]), None, None, 0,
                                     None) == -5
-    assert lib.msmd_spconv_fwd_f32(None, 0, 16, None, None, 0, 10, 27, 0, None, None, 16,
+    assert lib.msmd_spconv_fwd_f32(None, 0, 16, None, None, 0, 10, 27, 0, None, None, None, 16,
                                    None) == -1
     # c_out = 7*16 has no built kernel
     assert lib.msmd_spconv_fwd_f32(ctypes.c_void_p(256), 1, 16, ctypes.c_void_p(256),
-                                   ctypes.c_void_p(256), 1, 1, 27, 0, None, ctypes.c_void_p(256),
-                                   112, None) == -3
-    assert lib.msmd_rulebook_row_masks(None, 100, 0, None, None) == -3
+                                   ctypes.c_void_p(256), 1, 1, 27, 0, None, None,
+                                   ctypes.c_void_p(256), 112, None) == -3
+    assert lib.msmd_rulebook_row_masks(None, 100, 0, None, None, None) == -3
     assert lib.msmd_bn_act_fwd_f32(None, None, 10, 6, None, None, None, None, 1, 0.1, 1e-3, 1,
                                    None, None, None, None, 0, None) != 0
     assert lib.msmd_voxelize_workspace_bytes(30000, 120000, 10) > 120000 * 10 * 4
