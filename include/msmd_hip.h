@@ -160,9 +160,12 @@ int msmd_rulebook_pairs(const int32_t* nbr /* [K,n_rows] */, int kernel_volume,
  * ------------------------------------------------------------------------ */
 size_t msmd_spconv_packed_weight_elems(int kernel_volume, int c_in, int c_out);
 
-int msmd_spconv_pack_weight(const float* weight /* [K,c_in,c_out] */,
-                            int kernel_volume, int c_in, int c_out,
-                            int transpose /* pack W[k]^T: [c_out,c_in] */,
+int msmd_spconv_pack_weight(const float* weight, int kernel_volume, int c_in,
+                            int c_out,
+                            int flags /* bit0: pack W[k]^T (dgrad);
+                                         bit1: weight is KRSC [c_out,K,c_in]
+                                               (bug_fix/conv.py:114-117) instead
+                                               of [K,c_in,c_out] */,
                             float* packed, msmd_stream_t stream);
 
 /* `row_order` (NULL or a permutation of [0,n_out)): the order in which output
@@ -197,6 +200,7 @@ int msmd_spconv_wgrad_f32(const float* in_feat, int c_in, const float* d_out,
                           int c_out, const int32_t* indice_pairs /* [K,2,ld] */,
                           const int32_t* indice_num /* [K] device */, int ld,
                           int kernel_volume, float* d_weight /* [K,c_in,c_out] */,
+                          int krsc_out /* != 0: d_weight is [c_out,K,c_in] */,
                           void* workspace, size_t workspace_bytes,
                           msmd_stream_t stream);
 

@@ -40,8 +40,9 @@ constexpr int kTC = 4;  // 16-channel steps of c_in staged per LDS fill (64 chan
 // packed[((k*T + t)*NT + n)*256 + l*4 + s] = W[k][16t + 4(l>>4) + s][16n + (l&15)]
 // (zero outside c_in x c_out).  transpose: W[k] is read as W[k][col][row].
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int kvol,
-                                                          int cin, int cout, int transpose,
+                                                          int cin, int cout, int flags,
                                                           float* __restrict__ packed) {
+  const int transpose = flags & 1, krsc = flags & 2;  // krsc: w is [c_out][K][c_in]
   const int ci = transpose ? cout : cin, co = transpose ? cin : cout;  // effective dims
   const int T = (ci + 15) / 16, NT = (co + 15) / 16;
   long total = (long)kvol * T * NT * 256;
@@ -53,8 +54,10 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     int k = tile / ((long)NT * T);
     int c = 16 * t + 4 * (l >> 4) + s, d = 16 * n + (l & 15);
     float v = 0.f;
-    if (c < ci && d < co)
-      v = transpose ? w[((size_t)k * cin + d) * cout + c] : w[((size_t)k * cin + c) * cout + d];
+    if (c < ci && d < co) {
+      const int wi = transpose ? d : c, wo = transpose ? c : d;  // (c_in, c_out) index of W[k]
+      v = krsc ? w[((size_t)wo * kvol + k) * cin + wi] : w[((size_t)k * cin + wi) * cout + wo];
+    }
     packed[e] = v;
   }
 }
@@ -613,7 +616,8 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const int32_t* __restrict__ num,
-                                                           int nchunks, int per_k,
+                                                           int nchunks, int per_k, int cin,
+                                                           int cout, int kvol, int krsc,
                                                            float* __restrict__ dw) {
   const int k = blockIdx.y;
   const int P = num[k];
@@ -621,7 +625,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (int e = blockIdx.x * 256 + threadIdx.x; e < per_k; e += gridDim.x * 256) {
     float s = 0.f;
     for (int c = 0; c < used; ++c) s += partial[((size_t)k * nchunks + c) * per_k + e];
-    dw[(size_t)k * per_k + e] = s;
+    if (krsc) {  // d_weight is [c_out][K][c_in] (the module's parameter layout)
+      const int ci = e / cout, co = e - ci * cout;
+      dw[((size_t)co * kvol + k) * cin + ci] = s;
+    } else {
+      dw[(size_t)k * per_k + e] = s;
+    }
   }
 }
 
@@ -635,7 +644,7 @@ MSMD_EXPORT size_t msmd_spconv_packed_weight_elems(int kernel_volume, int c_in, 
 }
 
 MSMD_EXPORT int msmd_spconv_pack_weight(const float* weight, int kernel_volume, int c_in,
-                                        int c_out, int transpose, float* packed,
+                                        int c_out, int flags, float* packed,
                                         msmd_stream_t stream) {
   if (!weight || !packed || kernel_volume < 1 || c_in < 1 || c_out < 1)
     return MSMD_ERR_INVALID_ARG;
@@ -643,7 +652,7 @@ MSMD_EXPORT int msmd_spconv_pack_weight(const float* weight, int kernel_volume, 
   int nb = ceil_div((long)total, 256);
   if (nb > 2048) nb = 2048;
   MSMD_LAUNCH(pack_weight_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, weight,
-                     kernel_volume, c_in, c_out, transpose, packed);
+                     kernel_volume, c_in, c_out, flags, packed);
   return launch_status();
 }
 
@@ -700,8 +709,8 @@ MSMD_EXPORT size_t msmd_spconv_wgrad_workspace_bytes(int kernel_volume, int ld, 
 MSMD_EXPORT int msmd_spconv_wgrad_f32(const float* in_feat, int c_in, const float* d_out,
                                       int c_out, const int32_t* indice_pairs,
                                       const int32_t* indice_num, int ld, int kernel_volume,
-                                      float* d_weight, void* workspace, size_t workspace_bytes,
-                                      msmd_stream_t stream) {
+                                      float* d_weight, int krsc_out, void* workspace,
+                                      size_t workspace_bytes, msmd_stream_t stream) {
   if (c_in < 1 || c_out < 1 || kernel_volume < 1 || ld < 0 || !d_weight || !indice_num)
     return MSMD_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -727,6 +736,7 @@ MSMD_EXPORT int msmd_spconv_wgrad_f32(const float* in_feat, int c_in, const floa
   int rb = ceil_div(per_k, 256);
   if (rb > 64) rb = 64;
   MSMD_LAUNCH(wgrad_reduce_kernel, dim3(rb, kernel_volume), dim3(256), 0, st,
-                     (const float*)workspace, indice_num, nchunks, per_k, d_weight);
+              (const float*)workspace, indice_num, nchunks, per_k, c_in, c_out, kernel_volume,
+              krsc_out, d_weight);
   return launch_status();
 }

@@ -174,15 +174,20 @@ def rulebook_pairs(nbr, ld=None):
 
 
 # ------------------------------------------------------------------ convolution
-def pack_weight(weight_kio, transpose=False):
-    """weight [K,Cin,Cout] fp32 -> MFMA-fragment order (see spconv.hip)."""
-    _need_cuda(weight_kio)
-    w = weight_kio.contiguous().float()
-    kvol, cin, cout = w.shape
+def pack_weight(weight, transpose=False, krsc=False):
+    """weight -> MFMA-fragment order (see spconv.hip).  weight is [K,Cin,Cout]
+    or, with krsc=True, the modules' KRSC parameter [Cout,kd,kh,kw,Cin]."""
+    _need_cuda(weight)
+    w = weight.contiguous().float()
+    if krsc:
+        cout, cin = w.shape[0], w.shape[-1]
+        kvol = w.numel() // (cout * cin)
+    else:
+        kvol, cin, cout = w.shape
     packed = torch.empty((lib.msmd_spconv_packed_weight_elems(kvol, cin, cout),),
                          dtype=torch.float32, device=w.device)
-    check(lib.msmd_spconv_pack_weight(_p(w), kvol, cin, cout, int(bool(transpose)), _p(packed),
-                                      _stream()), "msmd_spconv_pack_weight")
+    check(lib.msmd_spconv_pack_weight(_p(w), kvol, cin, cout, int(bool(transpose)) | (2 if krsc else 0),
+                                      _p(packed), _stream()), "msmd_spconv_pack_weight")
     return packed
 
 
@@ -242,18 +247,21 @@ def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False, row_
     return out
 
 
-def conv_wgrad(feat, d_out, pairs, num):
-    """dW[K,Cin,Cout] from the compact pair lists."""
+def conv_wgrad(feat, d_out, pairs, num, krsc_shape=None):
+    """dW from the compact pair lists: [K,Cin,Cout], or laid out as the KRSC
+    parameter when krsc_shape (= weight.shape) is given."""
     _need_cuda(feat, d_out, pairs, num)
     f, g = feat.contiguous().float(), d_out.contiguous().float()
     kvol, _, ld = pairs.shape
     c_in, c_out = f.shape[1], g.shape[1]
-    dw = torch.empty((kvol, c_in, c_out), dtype=torch.float32, device=f.device)
+    dw = torch.empty((kvol, c_in, c_out) if krsc_shape is None else tuple(krsc_shape),
+                     dtype=torch.float32, device=f.device)
     nbytes = lib.msmd_spconv_wgrad_workspace_bytes(kvol, ld, c_in, c_out)
     ws = _ws(nbytes, f.device)
     ev = _prof_begin()
     check(lib.msmd_spconv_wgrad_f32(_p(f), c_in, _p(g), c_out, _p(pairs), _p(num), ld, kvol,
-                                    _p(dw), _p(ws), nbytes, _stream()), "msmd_spconv_wgrad_f32")
+                                    _p(dw), int(krsc_shape is not None), _p(ws), nbytes,
+                                    _stream()), "msmd_spconv_wgrad_f32")
     _prof_end("spconv_wgrad", ev, num=num, c_in=c_in, c_out=c_out)
     return dw
 

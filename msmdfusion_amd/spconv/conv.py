@@ -152,7 +152,7 @@ class SparseConvolution(SparseModule):
         if input.indices.shape[0] == 0 and datas.n_out == 0:
             out_features = features.new_zeros((0, self.out_channels))
         else:
-            out_features = Fsp.sparse_conv(features, self.weight_kio(), datas)
+            out_features = Fsp.sparse_conv(features, self.weight, datas, krsc=True)
         if self.bias is not None:
             out_features = out_features + self.bias
         out_tensor = out_tensor.replace_feature(out_features)

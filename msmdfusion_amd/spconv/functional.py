@@ -22,38 +22,41 @@ class _SparseConvFunction(Function):
     are the same implicit-GEMM kernel, wgrad contracts over the pair lists."""
 
     @staticmethod
-    def forward(ctx, features, weight_kio, rb):
-        ctx.rb = rb
-        ctx.save_for_backward(features, weight_kio)
-        packed = K.pack_weight(weight_kio)
-        c_in, c_out = weight_kio.shape[1], weight_kio.shape[2]
+    def forward(ctx, features, weight, rb, krsc):
+        ctx.rb, ctx.krsc = rb, krsc
+        ctx.save_for_backward(features, weight)
+        packed = K.pack_weight(weight, krsc=krsc)
+        c_in, c_out = (weight.shape[-1], weight.shape[0]) if krsc else weight.shape[1:]
         return K.conv_forward(features, packed, rb.nbr_fwd, rb.n_out, c_out,
                               row_order=rb.order_fwd() if _wants_order(c_in, c_out) else None)
 
     @staticmethod
     def backward(ctx, grad_out):
-        features, weight_kio = ctx.saved_tensors
-        rb = ctx.rb
+        features, weight = ctx.saved_tensors
+        rb, krsc = ctx.rb, ctx.krsc
+        c_in, c_out = (weight.shape[-1], weight.shape[0]) if krsc else weight.shape[1:]
         grad_out = grad_out.contiguous()
         d_feat = d_w = None
         if ctx.needs_input_grad[0]:
-            packed_t = K.pack_weight(weight_kio, transpose=True)
-            order = rb.order_bwd() if _wants_order(weight_kio.shape[2], weight_kio.shape[1]) \
-                else None
+            packed_t = K.pack_weight(weight, transpose=True, krsc=krsc)
+            order = rb.order_bwd() if _wants_order(c_out, c_in) else None
             if rb.is_subm:   # forward table + flipped weights == backward table
-                d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_fwd, rb.n_in,
-                                        weight_kio.shape[1], weight_flip=True, row_order=order)
+                d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_fwd, rb.n_in, c_in,
+                                        weight_flip=True, row_order=order)
             else:
-                d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_bwd, rb.n_in,
-                                        weight_kio.shape[1], row_order=order)
+                d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_bwd, rb.n_in, c_in,
+                                        row_order=order)
         if ctx.needs_input_grad[1]:
             pairs, num = rb.pairs()
-            d_w = K.conv_wgrad(features, grad_out, pairs, num)
-        return d_feat, d_w, None
+            d_w = K.conv_wgrad(features, grad_out, pairs, num,
+                               krsc_shape=weight.shape if krsc else None)
+        return d_feat, d_w, None, None
 
 
-def sparse_conv(features, weight_kio, rb):
-    return _SparseConvFunction.apply(features, weight_kio, rb)
+def sparse_conv(features, weight, rb, krsc=False):
+    """weight: [K,Cin,Cout], or the KRSC module parameter with krsc=True (read
+    and differentiated in place -- no permute/contiguous copies per step)."""
+    return _SparseConvFunction.apply(features, weight, rb, krsc)
 
 
 class _BNActFunction(Function):
