@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--diag", action="store_true", help="print host enqueue vs step time")
+    ap.add_argument("--workload", choices=["transfusion_l", "lc"], default="transfusion_l",
+                    help="transfusion_l = BASELINE configs[1] (the headline); lc = configs[2], "
+                         "the full MSMDFusion-LC sparse path (virtual points, GMA-Conv, sparse_add)")
     ap.add_argument("--no-profile", action="store_true",
                     help="skip per-launch event timing of the conv kernels")
     return ap.parse_args()
@@ -77,6 +80,39 @@ class Backbone(torch.nn.Module):
         feats, coors = self.voxelize(points)
         bev, _ = self.middle_encoder(feats, coors, len(points))
         return bev
+
+
+class FusionBackbone(torch.nn.Module):
+    """MSMDFusionDetector.extract_pts_feat's sparse section
+    (mmdet3d/models/detectors/MSMDFusion.py:421-443) with the LC config
+    (configs/MSMDFusion_nusc_voxel_LC.py:141-190): LiDAR encoder frozen
+    (freeze_lidar_components, tools/train.py:185-219), fusion stack trained."""
+
+    def __init__(self):
+        super().__init__()
+        from msmdfusion_amd import synthetic as S
+        from msmdfusion_amd.distributed import freeze_unused_fusion_blocks
+        from msmdfusion_amd.fusion import SparseFusionPath
+        from msmdfusion_amd.registry import build_middle_encoder
+        from msmdfusion_amd.voxelize import Voxelization
+        vox = Voxelization(S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, S.MAX_NUM_POINTS, S.MAX_VOXELS)
+        enc = build_middle_encoder(ENCODER_CFG)
+        mm = build_middle_encoder(dict(
+            type="SparseMultiModalEncoderPaint", in_channels_3D=(16, 32, 64, 128),
+            in_channels_2D=(64, 64, 64, 64), out_channels=(32, 64, 128, 128),
+            padding=(1, 1, [0, 1, 1], 0), order=("conv", "norm", "act"),
+            norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01)))
+        for p in enc.parameters():
+            p.requires_grad = False
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.track_running_stats = False
+        freeze_unused_fusion_blocks(mm)     # built, never called: no find_unused_parameters
+        self.path = SparseFusionPath(vox, enc, mm)
+
+    def forward(self, points, virtual):
+        x, x_mm = self.path(points, [virtual] * 4)
+        return torch.cat([x, x_mm], 1)
 
 
 def cpu_baseline(seed):
@@ -151,7 +187,9 @@ def main():
     from msmdfusion_amd import synthetic as S
 
     torch.manual_seed(0)
-    model = Backbone().to(dev).train()
+    lc = args.workload == "lc"
+    spg = 2 if lc else SAMPLES_PER_GPU      # configs/MSMDFusion_nusc_voxel_LC.py:104
+    model = (FusionBackbone() if lc else Backbone()).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     net = model
     if world > 1:
@@ -160,12 +198,13 @@ def main():
     # AdamW lr=1e-4, wd=0.01: configs/transfusion_nusc_voxel_L.py optimizer
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
 
-    clouds = [torch.from_numpy(S.lidar_sweep(rank * SAMPLES_PER_GPU + i)).to(dev)
-              for i in range(SAMPLES_PER_GPU)]
-    target = torch.randn(SAMPLES_PER_GPU, 256, 180, 180, device=dev)
+    clouds = [torch.from_numpy(S.lidar_sweep(rank * spg + i)).to(dev) for i in range(spg)]
+    virtual = [torch.from_numpy(S.virtual_points(rank * spg + i)).to(dev) for i in range(spg)] \
+        if lc else None
+    target = torch.randn(spg, 640 if lc else 256, 180, 180, device=dev)
 
     def step():
-        bev = net(clouds)
+        bev = net(clouds, virtual) if lc else net(clouds)
         loss = (bev * target).mean()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 10.0)     # grad_clip max_norm=10 (config)
@@ -210,20 +249,27 @@ def main():
     assert torch.isfinite(loss).item()
 
     if rank == 0:
-        n_samples = args.steps * SAMPLES_PER_GPU * world
+        n_samples = args.steps * spg * world
         out = {
-            "metric": "samples/sec TransFusion-L voxel backbone fwd+bwd (nuScenes 0.075m voxel)",
+            "metric": ("samples/sec MSMDFusion-LC sparse fusion path fwd+bwd (nuScenes 0.075m voxel)"
+                       if lc else
+                       "samples/sec TransFusion-L voxel backbone fwd+bwd (nuScenes 0.075m voxel)"),
             "value": round(n_samples / elapsed, 3), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: TransFusion-L voxel backbone (voxelize+VFE+"
-                                   "SparseEncoder->BEV), fwd+bwd+AdamW, 4 synthetic ~28.7k-pt "
-                                   "clouds/GPU, 0.075 m voxels, fp32",
-                       "global_batch": SAMPLES_PER_GPU * world, "parallelism": "dp%d" % world},
+            "config": {"workload": ("configs[2]: MSMDFusion-LC sparse path (LiDAR SparseEncoder "
+                                    "frozen + 4-scale virtual-point voxels + modality split + "
+                                    "GMA-Conv + sparse_add + downscale -> BEV 640ch), fwd+bwd+"
+                                    "AdamW, 2 x (28.7k LiDAR + 50k virtual pts)/GPU, fp32"
+                                    if lc else
+                                    "configs[1]: TransFusion-L voxel backbone (voxelize+VFE+"
+                                    "SparseEncoder->BEV), fwd+bwd+AdamW, 4 synthetic ~28.7k-pt "
+                                    "clouds/GPU, 0.075 m voxels, fp32"),
+                       "global_batch": spg * world, "parallelism": "dp%d" % world},
         }
         out["roofline"] = roofline(prof) if prof else None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not lc:
             out["cpu_baseline"] = cpu_baseline(0)
         print(json.dumps(out))
     if world > 1:

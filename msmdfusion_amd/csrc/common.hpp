@@ -61,6 +61,10 @@ inline int next_pow2_bits(long v) {  // smallest b with (1<<b) >= v
 }
 
 // ---- 32-bit key -> slot hash (multiplicative, table size 2^bits) ----------
+// (A locality-preserving "8 consecutive x share one 64-byte bucket" variant was
+// measured and rejected: with linear probing the occupied buckets of dense
+// scan lines overflow into each other -- voxelization of the 1.1 M-point
+// stress case went from 0.56 ms to 2.7 ms, the SubM lookup gained only 6 %.)
 __device__ __forceinline__ uint32_t hash_slot(uint32_t key, int bits) {
   return (key * 0x9E3779B1u) >> (32 - bits);
 }

@@ -22,11 +22,16 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 
 // PPT > 0: points per thread held in registers (n <= 1024*PPT).
 // PPT == 0: any n, coordinates and distances streamed from memory each round.
+// Per round: every thread updates its points' running distances against the
+// last selected point (broadcast through LDS by the thread that owns it -- no
+// global read on the serial critical path), keeps its best (distance, tie
+// rank), and the block reduces with wave shuffles + one LDS hop.
 template <int PPT>
 __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz, int n, int m,
                                                    int bs_ref, float* __restrict__ temp,
                                                    int32_t* __restrict__ idx) {
   __shared__ unsigned long long red[16];
+  __shared__ float s_xyz[3];
   __shared__ int s_old;
   if (m <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -34,7 +39,16 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
   temp += (size_t)blockIdx.x * n;
   idx += (size_t)blockIdx.x * m;
   constexpr int P = PPT > 0 ? PPT : 1;
-  float px[P], py[P], pz[P], pd[P];
+  const int bs_shift = 31 - __clz(bs_ref);  // bs_ref is a power of two
+  // tie rank of point k: the reference's shared-memory tree keeps the LOWER slot
+  // of each (t, t+s) pair, s = bs/2 .. 1, so between two thread ids the one
+  // whose lowest differing bit is 0 wins: order by the bit-reversed thread id
+  // (k mod bs), then by k div bs (the strided scan keeps its first maximum).
+  auto tie_rank = [&](int k) -> uint32_t {
+    uint32_t rev = bs_shift ? (__brev((uint32_t)(k & (bs_ref - 1))) >> (32 - bs_shift)) : 0u;
+    return (rev << 21) | (uint32_t)(k >> bs_shift);
+  };
+  float px[P], py[P], pz[P], pd[P];  // 4*PPT registers: PPT = 24 just fits 128 VGPRs
   if (PPT > 0) {
 #pragma unroll
     for (int s = 0; s < P; ++s) {
@@ -43,39 +57,39 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
       px[s] = ok ? xyz[k * 3 + 0] : 0.f;
       py[s] = ok ? xyz[k * 3 + 1] : 0.f;
       pz[s] = ok ? xyz[k * 3 + 2] : 0.f;
-      pd[s] = 1e10f;
+      pd[s] = ok ? 1e10f : -1.f;        // padding never wins (distances are >= 0)
     }
   } else {
     for (int k = tid; k < n; k += 1024) temp[k] = 1e10f;
   }
-  int old = 0;
-  if (tid == 0) idx[0] = 0;
-  const int bs_shift = 31 - __clz(bs_ref);  // bs_ref is a power of two
+  if (tid == 0) {
+    idx[0] = 0;
+    s_xyz[0] = xyz[0];
+    s_xyz[1] = xyz[1];
+    s_xyz[2] = xyz[2];
+  }
+  __syncthreads();
   for (int j = 1; j < m; ++j) {
-    const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
-    unsigned long long best = 0;
-    auto visit = [&](int k, float d2) {
-      // larger distance first.  Ties: the reference's shared-memory tree keeps
-      // the LOWER slot of each (t, t+s) pair, s = bs/2 .. 1, so between two
-      // thread ids the one whose lowest differing bit is 0 wins: order by the
-      // bit-reversed thread id (k mod bs), then by k div bs (strided scan
-      // keeps the first maximum).
-      uint32_t rev = bs_shift ? (__brev((uint32_t)(k & (bs_ref - 1))) >> (32 - bs_shift)) : 0u;
-      uint32_t tb = (rev << 21) | (uint32_t)(k >> bs_shift);
-      unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (uint32_t)~tb;
-      best = key > best ? key : best;
-    };
+    const float x1 = s_xyz[0], y1 = s_xyz[1], z1 = s_xyz[2];
+    // pass 1: update running distances, thread-local maximum (no index
+    // tracking: keeps the unrolled loop at ~10 VALU per point and inside the
+    // 128-VGPR budget of a 1024-thread workgroup); pass 2: among the points
+    // that hold that maximum, the smallest tie rank.
+    float best_d = -1.f;
+    uint32_t best_t = 0xFFFFFFFFu;
     if (PPT > 0) {
 #pragma unroll
       for (int s = 0; s < P; ++s) {
-        int k = tid + 1024 * s;
-        if (k < n) {
-          float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
-          float d = dx * dx + dy * dy + dz * dz;
-          float d2 = fminf(d, pd[s]);
-          pd[s] = d2;
-          visit(k, d2);
-        }
+        float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
+        float d = dx * dx + dy * dy + dz * dz;
+        float d2 = fminf(d, pd[s]);      // padding: min(d, -1) = -1
+        pd[s] = d2;
+        best_d = fmaxf(best_d, d2);
+      }
+#pragma unroll
+      for (int s = 0; s < P; ++s) {
+        const uint32_t t = tie_rank(tid + 1024 * s);
+        best_t = (pd[s] == best_d && t < best_t) ? t : best_t;
       }
     } else {
       for (int k = tid; k < n; k += 1024) {
@@ -83,9 +97,16 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
         float d = dx * dx + dy * dy + dz * dz;
         float d2 = fminf(d, temp[k]);
         temp[k] = d2;
-        visit(k, d2);
+        const uint32_t t = tie_rank(k);
+        bool better = d2 > best_d || (d2 == best_d && t < best_t);
+        best_d = better ? d2 : best_d;
+        best_t = better ? t : best_t;
       }
     }
+    // larger distance first, then smaller tie rank: one 64-bit max
+    unsigned long long best =
+        best_d < 0.f ? 0ull
+                     : ((unsigned long long)__float_as_uint(best_d) << 32) | (uint32_t)~best_t;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       unsigned long long other = shfl_xor_u64(best, o);
@@ -93,23 +114,34 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
     }
     if (lane == 0) red[wave] = best;
     __syncthreads();
-    if (wave == 0) {
-      unsigned long long v = lane < 16 ? red[lane] : 0;
+    unsigned long long v = red[lane & 15];
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        unsigned long long other = shfl_xor_u64(v, o);
-        v = other > v ? other : v;
+    for (int o = 8; o > 0; o >>= 1) {
+      unsigned long long other = shfl_xor_u64(v, o);
+      v = other > v ? other : v;
+    }
+    const uint32_t tb = ~(uint32_t)v;
+    const uint32_t tid_ref = bs_shift ? (__brev(tb >> 21) >> (32 - bs_shift)) : 0u;
+    const int old = (int)((tb & 0x1FFFFFu) << bs_shift) | (int)tid_ref;
+    if (tid == 0) idx[j] = old;
+    // the owner of `old` publishes its coordinates for the next round
+    if (PPT > 0) {
+      if ((old & 1023) == tid) {
+        const int so = old >> 10;
+#pragma unroll
+        for (int s = 0; s < P; ++s)
+          if (s == so) {
+            s_xyz[0] = px[s];
+            s_xyz[1] = py[s];
+            s_xyz[2] = pz[s];
+          }
       }
-      if (lane == 0) {
-        uint32_t tb = ~(uint32_t)v;
-        uint32_t tid_ref = bs_shift ? (__brev(tb >> 21) >> (32 - bs_shift)) : 0u;
-        int k = (int)((tb & 0x1FFFFFu) << bs_shift) | (int)tid_ref;
-        s_old = k;
-        idx[j] = k;
-      }
+    } else if (tid == 0) {
+      s_xyz[0] = xyz[old * 3];
+      s_xyz[1] = xyz[old * 3 + 1];
+      s_xyz[2] = xyz[old * 3 + 2];
     }
     __syncthreads();
-    old = s_old;
   }
 }
 
@@ -235,6 +267,7 @@ MSMD_EXPORT int msmd_furthest_point_sample(const float* xyz, int b, int n, int m
   else if (ppt <= 4) FPS(4);
   else if (ppt <= 8) FPS(8);
   else if (ppt <= 16) FPS(16);
+  else if (ppt <= 20) FPS(20);
   else if (ppt <= 24) FPS(24);
   else FPS(0);
 #undef FPS
