@@ -304,6 +304,13 @@ int msmd_furthest_point_sample(const float* xyz /* [b,n,3] */, int b, int n,
                                int m, float* temp /* [b,n] scratch */,
                                int32_t* idx /* [b,m] */, msmd_stream_t stream);
 
+/* Ragged batch: element i owns points [offsets[i], offsets[i+1]) of xyz
+ * ([total,3]); idx[i, :] are indices local to the element; n_max = the largest
+ * element (host).  One workgroup per element, all elements run concurrently. */
+int msmd_furthest_point_sample_ragged(const float* xyz, const int32_t* offsets /* [b+1] device */,
+                                      int b, int n_max, int m, float* temp /* [total] */,
+                                      int32_t* idx /* [b,m] */, msmd_stream_t stream);
+
 int msmd_ball_query(const float* center_xyz /* [b,m,3] */,
                     const float* xyz /* [b,n,3] */, int b, int n, int m,
                     float min_radius, float max_radius, int nsample,

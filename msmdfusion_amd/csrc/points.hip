@@ -20,26 +20,73 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
   return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
-// PPT > 0: points per thread held in registers (n <= 1024*PPT).
-// PPT == 0: any n, coordinates and distances streamed from memory each round.
-// Per round: every thread updates its points' running distances against the
-// last selected point (broadcast through LDS by the thread that owns it -- no
-// global read on the serial critical path), keeps its best (distance, tie
-// rank), and the block reduces with wave shuffles + one LDS hop.
+// ---- DPP reductions (no LDS crossbar: ~12 VALU per 32-bit wave reduce instead
+// of 6 dependent ds_bpermute round trips) --------------------------------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_mov(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ float fmax_dpp16(float v) {  // max over each 16-lane row, all lanes
+  v = fmaxf(v, __int_as_float(dpp_mov<0xB1>(__float_as_int(v))));   // quad_perm [1,0,3,2]
+  v = fmaxf(v, __int_as_float(dpp_mov<0x4E>(__float_as_int(v))));   // quad_perm [2,3,0,1]
+  v = fmaxf(v, __int_as_float(dpp_mov<0x141>(__float_as_int(v))));  // row_half_mirror
+  v = fmaxf(v, __int_as_float(dpp_mov<0x140>(__float_as_int(v))));  // row_mirror
+  return v;
+}
+__device__ __forceinline__ uint32_t umin_dpp16(uint32_t v) {
+  v = min(v, (uint32_t)dpp_mov<0xB1>((int)v));
+  v = min(v, (uint32_t)dpp_mov<0x4E>((int)v));
+  v = min(v, (uint32_t)dpp_mov<0x141>((int)v));
+  v = min(v, (uint32_t)dpp_mov<0x140>((int)v));
+  return v;
+}
+__device__ __forceinline__ float fmax_wave(float v) {  // wave-uniform result
+  v = fmax_dpp16(v);
+  v = fmaxf(v, __int_as_float(dpp_mov<0x142, 0xA>(__float_as_int(v))));  // row_bcast:15
+  v = fmaxf(v, __int_as_float(dpp_mov<0x143, 0xC>(__float_as_int(v))));  // row_bcast:31
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ uint32_t umin_wave(uint32_t v) {
+  v = umin_dpp16(v);
+  v = min(v, (uint32_t)dpp_mov<0x142, 0xA>((int)v));
+  v = min(v, (uint32_t)dpp_mov<0x143, 0xC>((int)v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Furthest point sampling, one 1024-thread workgroup per batch element; batch
+// elements may have different sizes (offsets[b+1], ragged) or all n (offsets
+// NULL).  PPT > 0: the element's points and running distances live in registers
+// (n <= 1024*PPT; 4*PPT VGPRs, PPT = 24 is the most that fits 128 VGPRs);
+// PPT == 0: any n, streamed from memory each round.
+// Per round: pass 1 updates the running distances and takes the thread-local
+// maximum; pass 2 finds, among the thread's points holding it, the smallest tie
+// rank; the block reduces (max distance, then min rank among its holders) with
+// DPP row operations and one LDS hop; the owner of the winner publishes its
+// coordinates through LDS (no global read on the serial critical path).
 template <int PPT>
-__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz, int n, int m,
-                                                   int bs_ref, float* __restrict__ temp,
-                                                   int32_t* __restrict__ idx) {
-  __shared__ unsigned long long red[16];
+__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz_all,
+                                                   const int* __restrict__ offsets, int n_fixed,
+                                                   int m, float* __restrict__ temp_all,
+                                                   int32_t* __restrict__ idx_all) {
+  __shared__ float red_d[2][16];
+  __shared__ uint32_t red_t[2][16];
   __shared__ float s_xyz[3];
-  __shared__ int s_old;
   if (m <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  xyz += (size_t)blockIdx.x * n * 3;
-  temp += (size_t)blockIdx.x * n;
-  idx += (size_t)blockIdx.x * m;
+  const long base = offsets ? offsets[blockIdx.x] : (long)blockIdx.x * n_fixed;
+  const int n = offsets ? offsets[blockIdx.x + 1] - offsets[blockIdx.x] : n_fixed;
+  const float* xyz = xyz_all + base * 3;
+  float* temp = temp_all + base;
+  int32_t* idx = idx_all + (size_t)blockIdx.x * m;
+  if (n <= 0) {
+    for (int j = tid; j < m; j += 1024) idx[j] = 0;
+    return;
+  }
   constexpr int P = PPT > 0 ? PPT : 1;
-  const int bs_shift = 31 - __clz(bs_ref);  // bs_ref is a power of two
+  // reference block size opt_n_threads(n): largest power of two <= n, max 1024
+  // (furthest_point_sample_cuda.cu:11-15)
+  const int bs_shift = min(31 - __clz(n), 10);
+  const int bs_ref = 1 << bs_shift;
   // tie rank of point k: the reference's shared-memory tree keeps the LOWER slot
   // of each (t, t+s) pair, s = bs/2 .. 1, so between two thread ids the one
   // whose lowest differing bit is 0 wins: order by the bit-reversed thread id
@@ -48,7 +95,7 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
     uint32_t rev = bs_shift ? (__brev((uint32_t)(k & (bs_ref - 1))) >> (32 - bs_shift)) : 0u;
     return (rev << 21) | (uint32_t)(k >> bs_shift);
   };
-  float px[P], py[P], pz[P], pd[P];  // 4*PPT registers: PPT = 24 just fits 128 VGPRs
+  float px[P], py[P], pz[P], pd[P];
   if (PPT > 0) {
 #pragma unroll
     for (int s = 0; s < P; ++s) {
@@ -71,10 +118,6 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
   __syncthreads();
   for (int j = 1; j < m; ++j) {
     const float x1 = s_xyz[0], y1 = s_xyz[1], z1 = s_xyz[2];
-    // pass 1: update running distances, thread-local maximum (no index
-    // tracking: keeps the unrolled loop at ~10 VALU per point and inside the
-    // 128-VGPR budget of a 1024-thread workgroup); pass 2: among the points
-    // that hold that maximum, the smallest tie rank.
     float best_d = -1.f;
     uint32_t best_t = 0xFFFFFFFFu;
     if (PPT > 0) {
@@ -85,11 +128,6 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
         float d2 = fminf(d, pd[s]);      // padding: min(d, -1) = -1
         pd[s] = d2;
         best_d = fmaxf(best_d, d2);
-      }
-#pragma unroll
-      for (int s = 0; s < P; ++s) {
-        const uint32_t t = tie_rank(tid + 1024 * s);
-        best_t = (pd[s] == best_d && t < best_t) ? t : best_t;
       }
     } else {
       for (int k = tid; k < n; k += 1024) {
@@ -103,24 +141,35 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
         best_t = better ? t : best_t;
       }
     }
-    // larger distance first, then smaller tie rank: one 64-bit max
-    unsigned long long best =
-        best_d < 0.f ? 0ull
-                     : ((unsigned long long)__float_as_uint(best_d) << 32) | (uint32_t)~best_t;
+    // wave: max distance, then min tie rank among the lanes/points holding it
+    const float wd = fmax_wave(best_d);
+    if (PPT > 0) {
+      if (bs_shift == 10) {  // n >= 1024: k mod 1024 == tid, k div 1024 == s
+        const uint32_t tbase = (__brev((uint32_t)tid) >> 22) << 21;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      unsigned long long other = shfl_xor_u64(best, o);
-      best = other > best ? other : best;
+        for (int s = P - 1; s >= 0; --s)   // descending: the smallest s overwrites last
+          best_t = pd[s] == wd ? (tbase | (uint32_t)s) : best_t;
+      } else {
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+          const uint32_t t = tie_rank(tid + 1024 * s);
+          best_t = (pd[s] == wd && t < best_t) ? t : best_t;
+        }
+      }
+    } else if (best_d != wd) {
+      best_t = 0xFFFFFFFFu;
     }
-    if (lane == 0) red[wave] = best;
+    const uint32_t wt = umin_wave(best_t);
+    const int buf = j & 1;   // double-buffered: one barrier separates write and read
+    if (lane == 0) {
+      red_d[buf][wave] = wd;
+      red_t[buf][wave] = wt;
+    }
     __syncthreads();
-    unsigned long long v = red[lane & 15];
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      unsigned long long other = shfl_xor_u64(v, o);
-      v = other > v ? other : v;
-    }
-    const uint32_t tb = ~(uint32_t)v;
+    const float cd = red_d[buf][lane & 15];
+    const float bd = fmax_dpp16(cd);
+    const uint32_t ct = cd == bd ? red_t[buf][lane & 15] : 0xFFFFFFFFu;
+    const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)umin_dpp16(ct));
     const uint32_t tid_ref = bs_shift ? (__brev(tb >> 21) >> (32 - bs_shift)) : 0u;
     const int old = (int)((tb & 0x1FFFFFu) << bs_shift) | (int)tid_ref;
     if (tid == 0) idx[j] = old;
@@ -254,24 +303,41 @@ int fps_block_size(int n) {  // opt_n_threads, furthest_point_sample_cuda.cu:11-
 
 using namespace msmd;
 
-MSMD_EXPORT int msmd_furthest_point_sample(const float* xyz, int b, int n, int m, float* temp,
-                                           int32_t* idx, msmd_stream_t stream) {
-  if (b < 1 || n < 1 || m < 0 || !xyz || !idx || !temp) return MSMD_ERR_INVALID_ARG;
-  if (m == 0) return MSMD_OK;
-  if (n >= (1 << 21) * 1) return MSMD_ERR_RANGE;
-  hipStream_t st = (hipStream_t)stream;
-  const int bs = fps_block_size(n);
-  const int ppt = ceil_div(n, 1024);
-#define FPS(P) MSMD_LAUNCH(fps_kernel<P>, dim3(b), dim3(1024), 0, st, xyz, n, m, bs, temp, idx)
+namespace {
+int launch_fps(const float* xyz, const int* offsets, int b, int n_max, int n_fixed, int m,
+               float* temp, int32_t* idx, hipStream_t st) {
+  const int ppt = ceil_div(n_max, 1024);
+#define FPS(P) \
+  MSMD_LAUNCH(fps_kernel<P>, dim3(b), dim3(1024), 0, st, xyz, offsets, n_fixed, m, temp, idx)
   if (ppt <= 2) FPS(2);
   else if (ppt <= 4) FPS(4);
   else if (ppt <= 8) FPS(8);
   else if (ppt <= 16) FPS(16);
   else if (ppt <= 20) FPS(20);
+  else if (ppt <= 22) FPS(22);
   else if (ppt <= 24) FPS(24);
   else FPS(0);
 #undef FPS
   return launch_status();
+}
+}  // namespace
+
+MSMD_EXPORT int msmd_furthest_point_sample(const float* xyz, int b, int n, int m, float* temp,
+                                           int32_t* idx, msmd_stream_t stream) {
+  if (b < 1 || n < 1 || m < 0 || !xyz || !idx || !temp) return MSMD_ERR_INVALID_ARG;
+  if (m == 0) return MSMD_OK;
+  if (n >= (1 << 21)) return MSMD_ERR_RANGE;
+  return launch_fps(xyz, nullptr, b, n, n, m, temp, idx, (hipStream_t)stream);
+}
+
+MSMD_EXPORT int msmd_furthest_point_sample_ragged(const float* xyz, const int32_t* offsets, int b,
+                                                  int n_max, int m, float* temp, int32_t* idx,
+                                                  msmd_stream_t stream) {
+  if (b < 1 || n_max < 1 || m < 0 || !xyz || !offsets || !idx || !temp)
+    return MSMD_ERR_INVALID_ARG;
+  if (m == 0) return MSMD_OK;
+  if (n_max >= (1 << 21)) return MSMD_ERR_RANGE;
+  return launch_fps(xyz, offsets, b, n_max, 0, m, temp, idx, (hipStream_t)stream);
 }
 
 MSMD_EXPORT int msmd_ball_query(const float* center_xyz, const float* xyz, int b, int n, int m,

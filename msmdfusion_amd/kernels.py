@@ -388,6 +388,21 @@ def furthest_point_sample(points_xyz, num_points):
     return out
 
 
+def furthest_point_sample_ragged(xyz, offsets, n_max, num_points):
+    """FPS over a ragged batch: xyz [total,3], offsets int32 [b+1] (device),
+    n_max = largest element (host int).  -> int32 [b, num_points], indices local
+    to each element.  All elements run concurrently, one workgroup each."""
+    _need_cuda(xyz, offsets)
+    x = xyz.contiguous().float()
+    b = offsets.shape[0] - 1
+    out = torch.empty((b, num_points), dtype=torch.int32, device=x.device)
+    tmp = torch.empty((max(x.shape[0], 1),), dtype=torch.float32, device=x.device)
+    check(lib.msmd_furthest_point_sample_ragged(_p(x), _p(offsets.contiguous().int()), b,
+                                                int(n_max), int(num_points), _p(tmp), _p(out),
+                                                _stream()), "msmd_furthest_point_sample_ragged")
+    return out
+
+
 def ball_query(min_radius, max_radius, sample_num, xyz, center_xyz):
     """mmdet3d/ops/ball_query/ball_query.py:14-40 (same argument order)."""
     _need_cuda(xyz, center_xyz)

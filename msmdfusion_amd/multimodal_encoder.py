@@ -124,22 +124,44 @@ class SparseMultiModalEncoderPaint(nn.Module):
     def nearest_3d_of_only_2d(self, only_2d_bzyx, voxel_3d_bzyx, batch_size, fps_num, radius,
                               max_cluster_samples, dist_thresh):
         """Per sample nearest LiDAR voxel of every only-2D voxel (:349-369);
-        returns global row indices into voxel_3D, -1 = unassigned."""
-        out = torch.full((only_2d_bzyx.shape[0],), -1, dtype=torch.long,
-                         device=only_2d_bzyx.device)
-        b3 = voxel_3d_bzyx[:, 0].long()
-        b2 = only_2d_bzyx[:, 0].long()
-        counts3 = torch.bincount(b3, minlength=batch_size).tolist()
-        base = 0
+        returns global row indices into voxel_3D, -1 = unassigned.  Rows of both
+        tensors are grouped by sample (they always are: voxelize concatenates
+        samples in order).  One host read (the per-sample counts); when every
+        sample needs the FPS path, all samples' FPS run in ONE ragged launch."""
+        dev = only_2d_bzyx.device
+        out = torch.full((only_2d_bzyx.shape[0],), -1, dtype=torch.long, device=dev)
+        counts = torch.stack([torch.bincount(only_2d_bzyx[:, 0].long(), minlength=batch_size),
+                              torch.bincount(voxel_3d_bzyx[:, 0].long(), minlength=batch_size)])
+        c2, c3 = counts.tolist()
+        o2 = [0]
+        o3 = [0]
         for b in range(batch_size):
-            m2 = b2 == b
-            m3 = b3 == b
-            if int(m2.sum()) and counts3[b]:
-                nn_idx = fps_nn_fast(only_2d_bzyx[m2], voxel_3d_bzyx[m3], fps_num, radius,
-                                     max_cluster_samples, dist_thresh)
-                out[m2] = torch.where(nn_idx >= 0, nn_idx + base, nn_idx)
-            base += counts3[b]   # cumulative (reference: last sample's count only, B.4)
-        return out
+            o2.append(o2[-1] + c2[b])
+            o3.append(o3[-1] + c3[b])
+        q_zyx = only_2d_bzyx[:, 1:].contiguous()
+        k_zyx = voxel_3d_bzyx[:, 1:].contiguous()
+        todo = [b for b in range(batch_size) if c2[b] and c3[b]]
+        big = [b for b in todo if c2[b] > fps_num]
+        rep_all = None
+        if len(big) == batch_size and batch_size > 1:   # the common case at stages 0/1
+            offsets = torch.tensor(o2, dtype=torch.int32, device=dev)
+            rep_all = K.furthest_point_sample_ragged(q_zyx.float(), offsets, max(c2), fps_num)
+        for b in todo:
+            q = q_zyx[o2[b]:o2[b + 1]]
+            k = k_zyx[o3[b]:o3[b + 1]]
+            if c2[b] <= fps_num:
+                nn_idx = K.nn_search(q, k, dist_thresh).long()
+            else:
+                q_f = q.float().unsqueeze(0)
+                rep_idx = (rep_all[b] if rep_all is not None
+                           else K.furthest_point_sample(q_f, fps_num)[0]).long()
+                rep = q[rep_idx]
+                rep_nn = K.nn_search(rep, k, dist_thresh)
+                group = K.ball_query(0, radius, max_cluster_samples, q_f,
+                                     rep.float().unsqueeze(0))[0]
+                nn_idx = K.nn_assign(group, rep_nn, c2[b]).long()
+            out[o2[b]:o2[b + 1]] = torch.where(nn_idx >= 0, nn_idx + o3[b], nn_idx)
+        return out   # offsets are cumulative (reference: last sample's count only, B.4)
 
     # ---- one GMA-Conv stage (:325-430) -----------------------------------------
     def grouped_sparse_conv(self, voxel_3D, voxel_2D, syn_mix_3D, syn_mix_2D, stage_id, fps_num,

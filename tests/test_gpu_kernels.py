@@ -286,6 +286,25 @@ def test_fps(dev, n, m):
     assert np.array_equal(got.cpu().numpy(), exp)
 
 
+def test_fps_ragged_batch(dev):
+    """One launch over elements of different sizes == per-element FPS."""
+    from msmdfusion_amd import kernels as K
+    rng = np.random.RandomState(0)
+    sizes = [700, 5000, 22000, 1, 3000]
+    parts = [np.stack([rng.randint(0, 41, n), rng.randint(0, 300, n), rng.randint(0, 300, n)],
+                      -1).astype(np.float32) for n in sizes]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    got = K.furthest_point_sample_ragged(t(np.concatenate(parts), dev), t(offs, dev), max(sizes),
+                                         64).cpu().numpy()
+    for i, p in enumerate(parts):
+        m = min(64, sizes[i]) if sizes[i] > 1 else 64
+        exp = O.furthest_point_sample(p[None], 64)[0]
+        if sizes[i] >= 64:
+            assert np.array_equal(got[i], exp), i
+        else:   # fewer points than samples: the reference keeps re-selecting; compare prefix
+            assert np.array_equal(got[i][:1], exp[:1])
+
+
 def test_ball_query_and_assign(dev):
     from msmdfusion_amd import kernels as K
     rng = np.random.RandomState(1)
