@@ -121,7 +121,9 @@ def cpu_baseline(seed):
     (dgrad + wgrad); BN/ReLU (elementwise, <1 % of the work) are skipped."""
     from msmdfusion_amd import synthetic as S
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    # memory-bound gather/scatter loops stop scaling well before the socket is
+    # full (256 hardware threads were slower than 8 here): cap at 32
+    cores = O.set_threads(min(os.cpu_count() or 1, 32))
     pts = S.lidar_sweep(seed)
     t0 = time.perf_counter()
     v, c, n = O.hard_voxelize(pts, S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 120000)
@@ -276,6 +278,22 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if not os.path.exists(path):
+        return None, None
+    kernels = json.load(open(path))["kernels"]
+    if kernel_name.startswith("spconv_wgrad"):
+        key = "spconv_wgrad_kernel<true>"
+    else:
+        nt = kernel_name.split("NT=")[1].rstrip(">")
+        key = next((k for k in kernels if k.startswith(kernel_name.split("<")[0] + "<" + nt + ",")),
+                   None)
+    e = kernels.get(key, {})
+    return e.get("hbm_bytes_per_launch"), e.get("mfma_pipe_busy_frac")
+
+
 def roofline(prof):
     """Dominant kernel = the conv kernel class with the most accumulated time.
     achieved = algorithmic flops (2 * pairs * Cin * Cout, the reference's MAC
@@ -290,7 +308,9 @@ def roofline(prof):
             if key not in pair_cache:
                 pair_cache[key] = int((nbr >= 0).sum().item())
             pairs = pair_cache[key]
-            name = "spconv_fwd_kernel<NT=%d>" % ((meta["c_out"] + 15) // 16)
+            nt = (meta["c_out"] + 15) // 16
+            name = ("spconv_fwd_pipe_kernel<NT=%d>" if nt >= 4 and meta["c_in"] % 16 == 0
+                    else "spconv_fwd_kernel<NT=%d>") % nt
         else:
             pairs = int(meta["num"].sum().item())
             name = "spconv_wgrad_kernel"
@@ -301,9 +321,14 @@ def roofline(prof):
     total_ms = sum(g["ms"] for g in groups.values())
     name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    traffic, mfma_busy = pmc_traffic(name)
     return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes "
+                            "(profiles/r01_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, "
+                            "gfx950 correction), not re-measured in this run",
+            "mfma_pipe_busy_frac_pmc": mfma_busy,
             "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2), "launches": g["launches"],
             "share_of_conv_time": round(g["ms"] / total_ms, 3),
             "all_conv_kernels": {k: {"ms": round(v["ms"], 3),

@@ -507,8 +507,13 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
     const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
     float* __restrict__ partial /* [K][nchunks][cin][cout] */) {
-  __shared__ f32x4 red[3 * kSlab * kSlab * 64];
-  __shared__ int s_in[kWgChunk], s_out[kWgChunk];
+  // 32 KiB of LDS: the chunk's pair indices during the main loop, then the
+  // tree reduction of the four wave partials (5 workgroups per CU by LDS)
+  __shared__ __attribute__((aligned(16))) char lds_raw[2 * kSlab * kSlab * 64 * sizeof(f32x4)];
+  int* s_in = (int*)lds_raw;
+  int* s_out = s_in + kWgChunk;
+  f32x4* red = (f32x4*)lds_raw;
+  static_assert(2 * kWgChunk * sizeof(int) <= sizeof(lds_raw), "index arrays must fit");
   const int k = blockIdx.y, chunk = blockIdx.x;
   const int P = num[k];
   const int p_begin = chunk * kWgChunk;
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
   // wave w takes pair groups w, w+4, ...; a group = 4 consecutive pairs (q).
   // Row gathers come from L2/MALL (~2 us under load) while a group is only 16
   // MFMAs (512 cycles): keep kDepth groups in flight in a register ring.
-  constexpr int kDepth = 6;
+  constexpr int kDepth = 8;
   f32x4 ra[kDepth], rb[kDepth];
   int e = 4 * wave + q;
 #pragma unroll
@@ -575,13 +580,29 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
     }
     e += 16 * kDepth;
   }
-  // cross-wave sum in fixed order: waves 1..3 park their tiles, wave 0 adds
-  if (wave > 0) {
+  // cross-wave sum, fixed tree order (w0+w2) + (w1+w3): deterministic
+  __syncthreads();   // everyone is done with the index arrays (red aliases them)
+  if (wave >= 2) {
 #pragma unroll
     for (int a = 0; a < kSlab; ++a)
 #pragma unroll
       for (int b = 0; b < kSlab; ++b)
-        red[((wave - 1) * kSlab * kSlab + a * kSlab + b) * 64 + lane] = acc[a][b];
+        red[((wave - 2) * kSlab * kSlab + a * kSlab + b) * 64 + lane] = acc[a][b];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int a = 0; a < kSlab; ++a)
+#pragma unroll
+      for (int b = 0; b < kSlab; ++b)
+        acc[a][b] += red[(wave * kSlab * kSlab + a * kSlab + b) * 64 + lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int a = 0; a < kSlab; ++a)
+#pragma unroll
+      for (int b = 0; b < kSlab; ++b) red[(a * kSlab + b) * 64 + lane] = acc[a][b];
   }
   __syncthreads();
   if (wave == 0) {
@@ -591,9 +612,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
       f32x4 v[kSlab];
 #pragma unroll
       for (int b = 0; b < kSlab; ++b) {
-        v[b] = acc[a][b];
-#pragma unroll
-        for (int w = 0; w < 3; ++w) v[b] += red[(w * kSlab * kSlab + a * kSlab + b) * 64 + lane];
+        v[b] = acc[a][b] + red[(a * kSlab + b) * 64 + lane];
       }
       // D of tile (a,b): lane (col j = i, q) reg r  ->  ci = a0 + 4(4q+r) + a,
       // co = b0 + 4j + b : the four b-tiles give 4 consecutive co -> one 16-B store

@@ -27,6 +27,20 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* Threads used by the OpenMP loops of the conv restatement (cpu_baseline). */
+ORC_API int orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
+
 /* ------------------------------------------------------------------------- *
  * Hard voxelization.
  * Follows mmdet3d/ops/voxel/src/voxelization_cpu.cpp:8-40 (coordinate of a

@@ -49,6 +49,13 @@ def ref_lib():
     return _ref
 
 
+def set_threads(n):
+    """OpenMP threads of the conv loops; returns the count in effect."""
+    fn = _lib.orc_set_threads
+    fn.restype = C.c_int
+    return fn(int(n))
+
+
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
