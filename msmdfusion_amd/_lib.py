@@ -26,6 +26,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_i64 = C.c_int64
 _ip = C.POINTER(C.c_int)
 _fp = C.POINTER(C.c_float)
 
@@ -52,6 +53,13 @@ SIGNATURES = {
     "msmd_rulebook_row_masks": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "msmd_spconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "msmd_spconv_wgrad_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "msmd_split_planes_bytes": (_sz, [_i64, _i, _i]),
+    "msmd_split_planes_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
+    "msmd_spconv_packed_split_bytes": (_sz, [_i, _i, _i, _i]),
+    "msmd_spconv_pack_weight_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "msmd_spconv_fwd_split_supported": (_i, [_i, _i, _i]),
+    "msmd_spconv_fwd_split": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "msmd_rulebook_permute_cols": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "msmd_bn_workspace_bytes": (_sz, [_i, _i]),
     "msmd_bn_act_fwd_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "msmd_bn_act_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

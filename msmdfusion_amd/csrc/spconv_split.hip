@@ -1,0 +1,654 @@
+// spconv_split.hip -- the sparse convolution arithmetic at bf16 MFMA rate with
+// fp32-equivalent results (error-free operand splitting).
+//
+// The fp32 matrix instruction (v_mfma_f32_16x16x4_f32, spconv.hip) runs at 1/16
+// of the bf16 rate on gfx950.  Every fp32 value is the exact sum of three bf16
+// values  x = h + m + l  (h = rn_bf16(x), m = rn_bf16(x - h), l = x - h - m: the
+// residuals are exact in fp32 and l has <= 8 significant bits), so
+//
+//   a * b = ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm)  + O(2^-24 |ab|)
+//
+// -- six bf16 products (each exact: 8 x 8 significant bits), accumulated in the
+// MFMA's fp32 accumulator.  The dropped terms (am*bl, al*bm, al*bl) are below
+// fp32's own rounding of the product, so the result is fp32-equivalent
+// (measured against fp64 in tests/test_gpu_kernels.py: same error as the fmaf
+// chain), at 6 x v_mfma_f32_16x16x32_bf16 (96 cycles) per 8 x
+// v_mfma_f32_16x16x4_f32 (256 cycles) for the same 16x16x32 block.
+// NP (number of planes) = 3 is that mode; NP = 2 keeps the three leading
+// products (relative error ~2^-17, still 50x tighter than TF32, which is what
+// spconv-2.x runs on Ampere by default); NP = 1 is plain bf16 operands.
+//
+// Data: features are split ONCE per tensor (split_planes_kernel) into
+//   planes[row][c/8][NP][8] bf16   (+ one all-zero row at index n: the target
+//   of "no neighbour", so the gather needs no predication)
+// and used twice (forward + wgrad, or dgrad + wgrad).  Weights are split while
+// being packed into MFMA fragment order.
+//
+// Forward / dgrad: same output-stationary pipelined implicit GEMM as
+// spconv_fwd_pipe_kernel (LDS-staged neighbour slice, active-offset list,
+// LDS-DMA double-buffered weights, ping-pong gathers straight into operand
+// registers, persistent LPT tile scheduler), with 32 rows per wave so every
+// weight fragment read from LDS feeds two row groups.
+#include "common.hpp"
+
+#include <stdlib.h>
+
+namespace msmd {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+constexpr int kMaxK = 32;
+
+int env_int2(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+// Split 8 fp32 values into NP bf16 planes (round-to-nearest-even at every level).
+template <int NP>
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&p)[NP]) {
+  float r[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) r[t] = x[t];
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x2 v = {r[2 * t], r[2 * t + 1]};
+      const bf16x2 h = __builtin_convertvector(v, bf16x2);
+      p[pl][t] = __builtin_bit_cast(unsigned int, h);
+      if (pl + 1 < NP) {
+        const f32x2 back = __builtin_convertvector(h, f32x2);
+        r[2 * t] = v[0] - back[0];      // exact (Sterbenz-style: same binade or below)
+        r[2 * t + 1] = v[1] - back[1];
+      }
+    }
+  }
+}
+
+// in [n][8*c8] fp32 -> planes [(n+1)][c8][NP] x 16 bytes; row n is zero.
+template <int NP>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, long n,
+                                                           int c8, u32x4* __restrict__ planes) {
+  const long total = (n + 1) * c8;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e < n * c8) {
+      const f32x4 a = ((const f32x4*)in)[2 * e], b = ((const f32x4*)in)[2 * e + 1];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) x[t] = a[t], x[4 + t] = b[t];
+    }
+    u32x4 p[NP];
+    split8<NP>(x, p);
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) planes[e * NP + pl] = p[pl];
+  }
+}
+
+// packed[(((k*KB + kb)*NP + p)*NT + mt)*64 + lane] (16 B) = plane p of
+//   W[k][c = 32kb + 8(lane>>4) + s][d = 16mt + (lane&15)],  s = 0..7
+// (zero outside c_in x c_out); flags as msmd_spconv_pack_weight.
+template <int NP>
+__global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __restrict__ w,
+                                                                int kvol, int cin, int cout,
+                                                                int flags,
+                                                                u32x4* __restrict__ packed) {
+  const int transpose = flags & 1, krsc = flags & 2;
+  const int ci = transpose ? cout : cin, co = transpose ? cin : cout;
+  const int KB = (ci + 31) / 32, NT = (co + 15) / 16;
+  const long total = (long)kvol * KB * NT * 64;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int lane = e & 63;
+    long t = e >> 6;
+    const int mt = t % NT;
+    t /= NT;
+    const int kb = t % KB;
+    const int k = t / KB;
+    const int d = 16 * mt + (lane & 15);
+    float x[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int c = 32 * kb + 8 * (lane >> 4) + s;
+      float v = 0.f;
+      if (c < ci && d < co) {
+        const int wi = transpose ? d : c, wo = transpose ? c : d;
+        v = krsc ? w[((size_t)wo * kvol + k) * cin + wi] : w[((size_t)k * cin + wi) * cout + wo];
+      }
+      x[s] = v;
+    }
+    u32x4 p[NP];
+    split8<NP>(x, p);
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+      packed[((((size_t)k * KB + kb) * NP + pl) * NT + mt) * 64 + lane] = p[pl];
+  }
+}
+
+// The products kept for NP planes, as (weight plane, activation plane).
+template <int NP>
+struct Products;
+template <>
+struct Products<1> {
+  static constexpr int n = 1;
+  static constexpr int a[1] = {0};
+  static constexpr int b[1] = {0};
+};
+template <>
+struct Products<2> {
+  static constexpr int n = 3;
+  static constexpr int a[3] = {1, 0, 0};
+  static constexpr int b[3] = {0, 1, 0};
+};
+template <>
+struct Products<3> {  // smallest terms first
+  static constexpr int n = 6;
+  static constexpr int a[6] = {2, 0, 1, 1, 0, 0};
+  static constexpr int b[6] = {0, 2, 1, 0, 1, 0};
+};
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer descriptor (stride 0, num_records bytes): loads whose byte offset
+// is out of range return 0 without touching memory -- "no neighbour" costs no
+// traffic and needs no predication or zeroing.
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+constexpr unsigned kOobOffset = 0xffffff00u;
+
+// The gathers are issued from inline asm: hipcc drains the whole VM queue
+// (vmcnt(0)) at the first use of an ordinary load's result while an LDS-DMA is
+// in flight, and at every __syncthreads(); hidden from it, the queue is
+// counted by hand (all waits below are "allow the N newest ops").
+template <int NP>
+__device__ __forceinline__ void gather_planes(u32x4 (&b)[NP], unsigned off, i32x4 rs) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(b[0]) : "v"(off), "s"(rs));
+  if (NP > 1)
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16"
+                 : "=v"(b[NP > 1 ? 1 : 0])
+                 : "v"(off), "s"(rs));
+  if (NP > 2)
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:32"
+                 : "=v"(b[NP > 2 ? 2 : 0])
+                 : "v"(off), "s"(rs));
+}
+// s_waitcnt vmcnt(N) that the operand registers depend on (so no MFMA reading
+// them can be scheduled above it).
+template <int N, int NP>
+__device__ __forceinline__ void wait_planes(u32x4 (&b)[2][NP]) {
+  if (NP == 3)
+    asm volatile("s_waitcnt vmcnt(%6)"
+                 : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][NP > 2 ? 2 : 0]), "+v"(b[1][0]),
+                   "+v"(b[1][1]), "+v"(b[1][NP > 2 ? 2 : 0])
+                 : "n"(N));
+  else if (NP == 2)
+    asm volatile("s_waitcnt vmcnt(%4)"
+                 : "+v"(b[0][0]), "+v"(b[0][NP > 1 ? 1 : 0]), "+v"(b[1][0]),
+                   "+v"(b[1][NP > 1 ? 1 : 0])
+                 : "n"(N));
+  else
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0][0]), "+v"(b[1][0]) : "n"(N));
+}
+
+// ------------------------------------------------------- forward / dgrad --
+// One workgroup = 4 waves x 32 output rows (two 16-row MFMA groups per wave) x
+// all of c_out; persistent, drawing 128-row tiles from a global counter.
+//
+// Work decomposition of a tile: UNITS = (active kernel offset k, 32-channel
+// k-block kb) in ascending order, enumerated on the scalar unit from the tile's
+// 27-bit offset mask (no LDS lists, no divisions); an ITEM = UB consecutive
+// units = one weight buffer fill + one barrier (UB * NT = 8: 24 KiB at NP = 3).
+//
+// Pipeline (everything below overlaps the MFMAs of the current unit):
+//   * weights of item i+1: LDS-DMA (global_load_lds, lane-linear packed image);
+//   * gathered rows of unit g+2: 16-byte buffer loads straight into MFMA operand
+//     registers (3-deep ring), out-of-range offset for "no neighbour" (returns
+//     0, no traffic), from row indices fetched from LDS one unit earlier;
+//   * weight fragments of the next 32 output channels: LDS -> registers,
+//     double-buffered, issued a third of the way into the current MFMA block;
+//   * the NEXT tile's slice of the neighbour table + its output rows: LDS-DMA
+//     into the other table buffer during item 1 (tile id from an atomic issued
+//     at tile start) -- a tile switch costs one barrier, not 3 round trips.
+// All barriers are raw s_barrier and all VM waits are counted by hand (see
+// gather_planes): __syncthreads() would drain the queue at every item.
+// `nbr` must be in TILE order when `order` is given: column p of the table
+// belongs to output row order[p] (msmd_rulebook_permute_cols), so a tile's
+// slice is 512 contiguous bytes per offset.
+template <int NT, int UB, int NP>
+__global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
+    const u32x4* __restrict__ planes, int n_in, int cin, const u32x4* __restrict__ wp,
+    const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
+    const int32_t* __restrict__ order, int* __restrict__ tile_counter, float* __restrict__ out,
+    int cout, int dbg) {
+  constexpr int R = 2, kRows = 4 * R * 16;
+  constexpr int kUnitU = NP * NT * 64;  // 16-byte units of one unit's weights
+  constexpr int kWU = UB * kUnitU;
+  constexpr int kGu = R * NP;           // gather loads per unit per lane
+  constexpr int kWp = (UB * NP * NT + 3) / 4;  // weight DMA ops per item per wave
+  constexpr int NS = NT / 2;            // fragment steps (pairs of 16-channel tiles) per unit
+  static_assert(NT % 2 == 0, "pairs of output tiles");
+  using P = Products<NP>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* wl = (u32x4*)smem;                       // [2][kWU]
+  int* nbt = (int*)(wl + 2 * kWU);                // [2][kvol + 1][kRows]; row kvol = output rows
+  const int tstride = (kvol + 1) * kRows;
+  int* ctl = nbt + 2 * tstride;                   // [0],[1]: offset masks; [2]: next tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int c8 = cin >> 3, kbt = cin >> 5;
+  const int n_tiles = (n_out + kRows - 1) / kRows;
+  int lr[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) lr[r] = (wave * R + r) * 16 + j;
+  const i32x4 rs = make_rsrc(planes, (unsigned)((size_t)(n_in + 1) * c8 * NP * 16));
+  const unsigned row_bytes = (unsigned)(c8 * NP * 16);
+
+  // table slice of tile T -> buffer b, by LDS-DMA (4 bytes per lane).  Positions
+  // past n_out are clamped: their results are computed and dropped.
+  auto stage_table = [&](int T, int b) {
+    int* dst = nbt + b * tstride;
+    const int n_e = (kvol + (order ? 1 : 0)) * kRows;
+    for (int e0 = wave * 64; e0 < n_e; e0 += 256) {
+      const int e = e0 + lane, k = e >> 7;
+      int p = T * kRows + (e & (kRows - 1));
+      p = p < n_out ? p : n_out - 1;
+      const int32_t* src = k < kvol ? nbr + (size_t)k * ld + p : order + p;
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + e0), 4, 0, 0);
+    }
+  };
+
+  int tb = 0;
+  if (tid == 0) {
+    ctl[0] = 0;
+    ctl[1] = 0;
+    ctl[2] = atomicAdd(tile_counter, 1);
+  }
+  __syncthreads();   // nothing in flight yet: the fence costs nothing here
+  int tile = __builtin_amdgcn_readfirstlane(ctl[2]);
+  if (tile >= n_tiles) return;
+  stage_table(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (;;) {
+    int nxt_v = 0;
+    if (tid == 0) nxt_v = atomicAdd(tile_counter, 1);  // consumed during item 1
+    const int* tab = nbt + tb * tstride;
+    {  // offsets any row of this tile is connected through
+      unsigned m = 0;
+      for (int k = wave; k < kvol; k += 4) {
+        const int v0 = tab[k * kRows + lane], v1 = tab[k * kRows + 64 + lane];
+        if (__any((v0 & v1) >= 0)) m |= 1u << k;   // v0 >= 0 || v1 >= 0
+      }
+      if (lane == 0 && m) atomicOr((unsigned*)&ctl[tb], m);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned mask = __builtin_amdgcn_readfirstlane(ctl[tb]);
+    const int n_units = __builtin_popcount(mask) * kbt;
+    const int n_items = (n_units + UB - 1) / UB;
+
+    f32x4 acc[R][NT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // unit cursors (scalar): remaining-offset mask + k-block
+    unsigned mw = mask, mg = mask, ms = mask;
+    int kbw = 0, kbg = 0, kbs = 0;
+#define MSMD_ADV(M, KB)          \
+  if (++(KB) == kbt) {           \
+    (KB) = 0;                    \
+    (M) &= (M)-1;                \
+  }
+    int s_next[R];
+    auto load_src = [&]() {  // row indices of cursor `s`, then advance it
+      const int k = ms ? __builtin_ctz(ms) : 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) s_next[r] = ms ? tab[k * kRows + lr[r]] : -1;
+      MSMD_ADV(ms, kbs);
+    };
+    auto issue_g = [&](u32x4 (&b)[R][NP], int& valid) {  // cursor `g`, rows s_next
+      valid = -1;
+      const unsigned col = (unsigned)((kbg * 4 + q) * NP * 16);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int src = s_next[r];
+        valid = src > valid ? src : valid;
+        const unsigned off =
+            (src < 0 || (dbg & 2)) ? kOobOffset : (unsigned)src * row_bytes + col;
+        gather_planes<NP>(b[r], off, rs);
+      }
+      MSMD_ADV(mg, kbg);
+    };
+    auto issue_w = [&](int it) {  // UB units at cursor `w` -> buffer it&1
+      u32x4* wb = wl + (it & 1) * kWU;
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int k = mw ? __builtin_ctz(mw) : 0;
+        const int kw = flip ? kvol - 1 - k : k;
+        const u32x4* g = wp + ((size_t)kw * kbt + kbw) * kUnitU;
+        // every wave issues the same number of ops (a short last round repeats
+        // piece 0: same bytes to the same place) so the queue counts are static
+#pragma unroll
+        for (int pp = 0; pp < (NP * NT + 3) / 4; ++pp) {
+          int piece = wave + 4 * pp;
+          if ((NP * NT) % 4 != 0 && piece >= NP * NT) piece = 0;
+          __builtin_amdgcn_global_load_lds((glb_void*)(g + piece * 64 + lane),
+                                           (lds_void*)(wb + u * kUnitU + piece * 64), 16, 0, 0);
+        }
+        MSMD_ADV(mw, kbw);
+      }
+    };
+    auto compute = [&](int it, int u, u32x4 (&b)[R][NP], int valid) {
+      // rows of this unit: at most the two later units' gathers (and, for the
+      // first two units of an item, the weight DMA issued at its top) are newer
+      if (UB > 1) {
+        if (u < 2)
+          wait_planes<2 * kGu + kWp, NP>(b);
+        else
+          wait_planes<2 * kGu, NP>(b);
+      } else {
+        wait_planes<2 * kGu + 2 * kWp, NP>(b);   // already satisfied by the item-top wait
+      }
+      if (!__any(valid >= 0) || (dbg & 4)) return;
+      const u32x4* wb = wl + (it & 1) * kWU + u * kUnitU + lane;
+      u32x4 a[2][2][NP];
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) a[0][nn][p] = wb[(p * NT + nn) * 64];
+      // The next step's fragments are requested a third of the way into this
+      // step's MFMAs: when the first MFMA of the next step waits for them
+      // (lgkmcnt(0): nothing newer is outstanding) they have had 16 MFMAs to land.
+      constexpr int kHead = P::n >= 3 ? P::n / 3 : 0;
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < kHead; ++t)
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              acc[r][2 * st + nn] =
+                  mfma_bf16(a[st & 1][nn][P::a[t]], b[r][P::b[t]], acc[r][2 * st + nn]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < NS) {
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+              a[(st + 1) & 1][nn][p] = wb[(p * NT + 2 * (st + 1) + nn) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = kHead; t < P::n; ++t)
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              acc[r][2 * st + nn] =
+                  mfma_bf16(a[st & 1][nn][P::a[t]], b[r][P::b[t]], acc[r][2 * st + nn]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    u32x4 ring0[R][NP], ring1[R][NP], ring2[R][NP];
+    int vr0 = -1, vr1 = -1, vr2 = -1;
+    bool staged = false;
+    int nxt = n_tiles;
+    // ---- prologue: weights of item 0, rows of units 0 and 1, indices of unit 2
+    issue_w(0);
+    load_src();
+    issue_g(ring0, vr0);
+    load_src();
+    issue_g(ring1, vr1);
+    load_src();
+    // One unit: start the gathers two units ahead, fetch the indices three ahead,
+    // multiply the current one.
+#define MSMD_UNIT(IT, U, BC, VC, BF, VF) \
+  {                                      \
+    issue_g(BF, VF);                     \
+    load_src();                          \
+    compute((IT), (U), BC, VC);          \
+  }
+    // One item.  Memory ops retire in order; at the top of item `it` the newest
+    // UB*kGu ops are gathers, everything older -- including weights(it) -- has
+    // landed once vmcnt drops to that count (item 0: drain = pipeline fill).
+#define MSMD_ITEM(IT, PH)                                                              \
+  {                                                                                    \
+    if ((IT) == 1 && tid == 0) {                                                       \
+      ctl[2] = nxt_v;                                                                  \
+      ctl[tb ^ 1] = 0;                                                                 \
+    }                                                                                  \
+    if ((IT) == 0)                                                                     \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                      \
+    else                                                                               \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(UB * kGu) : "memory");       \
+    __builtin_amdgcn_s_barrier();                                                      \
+    if ((IT) == 1) {                                                                   \
+      nxt = __builtin_amdgcn_readfirstlane(ctl[2]);                                    \
+      if (nxt < n_tiles) stage_table(nxt, tb ^ 1);                                     \
+      staged = true;                                                                   \
+    }                                                                                  \
+    issue_w((IT) + 1);                                                                 \
+    MSMD_ITEM_UNITS(IT, PH)                                                            \
+  }
+// ring slot of unit g = it*UB + u is g % 3 = (PH*UB + u) % 3 with PH = it % 3
+#define MSMD_RING_UNIT(IT, U, S)                                        \
+  if ((S) % 3 == 0) MSMD_UNIT(IT, U, ring0, vr0, ring2, vr2)            \
+  else if ((S) % 3 == 1) MSMD_UNIT(IT, U, ring1, vr1, ring0, vr0)       \
+  else MSMD_UNIT(IT, U, ring2, vr2, ring1, vr1)
+#define MSMD_ITEM_UNITS(IT, PH)                                   \
+  MSMD_RING_UNIT(IT, 0, (PH)*UB + 0)                              \
+  if (UB > 1) { MSMD_RING_UNIT(IT, 1, (PH)*UB + 1) }              \
+  if (UB > 2) { MSMD_RING_UNIT(IT, 2, (PH)*UB + 2) }              \
+  if (UB > 3) { MSMD_RING_UNIT(IT, 3, (PH)*UB + 3) }
+    for (int it = 0; it < n_items; it += 3) {
+      MSMD_ITEM(it, 0);
+      if (it + 1 < n_items) MSMD_ITEM(it + 1, 1);
+      if (it + 2 < n_items) MSMD_ITEM(it + 2, 2);
+    }
+#undef MSMD_ITEM
+#undef MSMD_ITEM_UNITS
+#undef MSMD_RING_UNIT
+#undef MSMD_UNIT
+#undef MSMD_ADV
+    // ---- epilogue: lane (j,q) holds out[row j][16n + 4q .. +3] ----
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int p = tile * kRows + lr[r];
+      if (p >= n_out) continue;
+      const int row = order ? tab[kvol * kRows + lr[r]] : p;
+      float* o = out + (size_t)row * cout + 4 * q;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) *(f32x4*)(o + 16 * n) = acc[r][n];
+    }
+    // ---- next tile ----
+    if (!staged) {
+      if (tid == 0) {
+        ctl[2] = nxt_v;
+        ctl[tb ^ 1] = 0;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      nxt = __builtin_amdgcn_readfirstlane(ctl[2]);
+      if (nxt < n_tiles) stage_table(nxt, tb ^ 1);
+    }
+    // drains the trailing (null-unit) gathers and weight DMA, lands the table
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (nxt >= n_tiles) break;
+    __builtin_amdgcn_s_barrier();
+    tile = nxt;
+    tb ^= 1;
+  }
+}
+
+int split_slots_per_cu() {
+  static const int v = env_int2("MSMD_SPLIT_SLOTS", 2);
+  return v;
+}
+
+template <int NT, int UB, int NP>
+int launch_fwd_split(const void* planes, int n_in, int cin, const void* wp, const int32_t* nbr,
+                     int ld, int n_out, int kvol, int flip, const int32_t* order,
+                     int* tile_counter, float* out, int cout, hipStream_t st) {
+  constexpr int kRows = 128;
+  const size_t smem = sizeof(u32x4) * 2 * UB * NP * NT * 64 +
+                      sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 8);
+  const int n_tiles = ceil_div(n_out, kRows);
+  int nblk = n_tiles;
+  hipMemsetAsync(tile_counter, 0, sizeof(int), st);
+  const int slots = 256 * split_slots_per_cu();
+  if (nblk > slots) nblk = slots;
+  auto kern = spconv_fwd_split_kernel<NT, UB, NP>;
+  static size_t attr_smem = 0;  // per instantiation
+  if (smem > attr_smem) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_smem = smem;
+  }
+  MSMD_LAUNCH(kern, dim3(nblk), dim3(256), smem, st, (const u32x4*)planes, n_in, cin,
+              (const u32x4*)wp, nbr, ld, n_out, kvol, flip, order, tile_counter, out, cout,
+              env_int2("MSMD_DBG", 0));
+  return launch_status();
+}
+
+template <int NP>
+int dispatch_fwd_split(const void* planes, int n_in, int cin, const void* wp, const int32_t* nbr,
+                       int ld, int n_out, int kvol, int flip, const int32_t* order,
+                       int* tile_counter, float* out, int cout, hipStream_t st) {
+#define MSMD_GO(NT_, UB_)                                                                      \
+  return launch_fwd_split<NT_, UB_, NP>(planes, n_in, cin, wp, nbr, ld, n_out, kvol, flip,    \
+                                        order, tile_counter, out, cout, st)
+  switch (cout / 16) {
+    case 8: MSMD_GO(8, 1);
+    case 6: MSMD_GO(6, 1);
+    case 4: MSMD_GO(4, 2);
+    case 2: MSMD_GO(2, 4);
+    default: return MSMD_ERR_UNSUPPORTED;
+  }
+#undef MSMD_GO
+}
+
+// out[k][p] = nbr[k][order[p]]: the neighbour table in tile order.
+__global__ __launch_bounds__(256) void permute_cols_kernel(const int32_t* __restrict__ nbr,
+                                                           int kvol, int ld, int n,
+                                                           const int32_t* __restrict__ order,
+                                                           int32_t* __restrict__ out) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const int row = order[p];
+  for (int k = 0; k < kvol; ++k) out[(size_t)k * n + p] = nbr[(size_t)k * ld + row];
+}
+
+}  // namespace
+}  // namespace msmd
+
+using namespace msmd;
+
+MSMD_EXPORT size_t msmd_split_planes_bytes(int64_t n, int c, int np) {
+  if (n < 0 || c <= 0 || (c & 7) || np < 1 || np > 3) return 0;
+  return (size_t)(n + 1) * c * np * 2;
+}
+
+MSMD_EXPORT int msmd_split_planes_f32(const float* in, int64_t n, int c, int np, void* planes,
+                                      hipStream_t st) {
+  if (n < 0 || c <= 0 || (c & 7) || np < 1 || np > 3) return MSMD_ERR_INVALID_ARG;
+  const int c8 = c >> 3;
+  const long total = (long)(n + 1) * c8;
+  int nblk = (int)((total + 255) / 256);
+  if (nblk > 256 * 16) nblk = 256 * 16;
+  if (np == 3)
+    MSMD_LAUNCH(split_planes_kernel<3>, dim3(nblk), dim3(256), 0, st, in, (long)n, c8,
+                (u32x4*)planes);
+  else if (np == 2)
+    MSMD_LAUNCH(split_planes_kernel<2>, dim3(nblk), dim3(256), 0, st, in, (long)n, c8,
+                (u32x4*)planes);
+  else
+    MSMD_LAUNCH(split_planes_kernel<1>, dim3(nblk), dim3(256), 0, st, in, (long)n, c8,
+                (u32x4*)planes);
+  return launch_status();
+}
+
+MSMD_EXPORT size_t msmd_spconv_packed_split_bytes(int kvol, int cin, int cout, int np) {
+  return (size_t)kvol * ((cin + 31) / 32) * ((cout + 15) / 16) * np * 1024;
+}
+
+// `cin`/`cout` are the weight's own dims; with flags bit0 the packed image is of
+// W[k]^T (contraction over c_out): its size is msmd_spconv_packed_split_bytes(K,
+// cout, cin, np).
+MSMD_EXPORT int msmd_spconv_pack_weight_split(const float* w, int kvol, int cin, int cout,
+                                              int flags, int np, void* packed, hipStream_t st) {
+  if (kvol <= 0 || cin <= 0 || cout <= 0 || np < 1 || np > 3) return MSMD_ERR_INVALID_ARG;
+  const int ci = (flags & 1) ? cout : cin, co = (flags & 1) ? cin : cout;
+  const long total = (long)kvol * ((ci + 31) / 32) * ((co + 15) / 16) * 64;
+  int nblk = (int)((total + 255) / 256);
+  if (nblk > 4096) nblk = 4096;
+  if (np == 3)
+    MSMD_LAUNCH(pack_weight_split_kernel<3>, dim3(nblk), dim3(256), 0, st, w, kvol, cin, cout,
+                flags, (u32x4*)packed);
+  else if (np == 2)
+    MSMD_LAUNCH(pack_weight_split_kernel<2>, dim3(nblk), dim3(256), 0, st, w, kvol, cin, cout,
+                flags, (u32x4*)packed);
+  else
+    MSMD_LAUNCH(pack_weight_split_kernel<1>, dim3(nblk), dim3(256), 0, st, w, kvol, cin, cout,
+                flags, (u32x4*)packed);
+  return launch_status();
+}
+
+MSMD_EXPORT int msmd_spconv_fwd_split_supported(int cin, int cout, int kvol) {
+  const int nt = cout / 16;
+  return cin > 0 && (cin & 31) == 0 && (cout & 15) == 0 && kvol <= kMaxK &&
+         (nt == 8 || nt == 6 || nt == 4 || nt == 2);
+}
+
+MSMD_EXPORT int msmd_spconv_fwd_split(const void* planes, int n_in, int cin, const void* packed,
+                                      const int32_t* nbr, int ld, int n_out, int kvol,
+                                      int weight_flip, const int32_t* row_order,
+                                      int32_t* tile_counter, float* out, int cout, int np,
+                                      hipStream_t st) {
+  if (!msmd_spconv_fwd_split_supported(cin, cout, kvol) || np < 1 || np > 3)
+    return MSMD_ERR_UNSUPPORTED;
+  if (!tile_counter) return MSMD_ERR_INVALID_ARG;
+  if (n_out <= 0) return MSMD_OK;
+  if (np == 3)
+    return dispatch_fwd_split<3>(planes, n_in, cin, packed, nbr, ld, n_out, kvol, weight_flip,
+                                 row_order, tile_counter, out, cout, st);
+  if (np == 2)
+    return dispatch_fwd_split<2>(planes, n_in, cin, packed, nbr, ld, n_out, kvol, weight_flip,
+                                 row_order, tile_counter, out, cout, st);
+  return dispatch_fwd_split<1>(planes, n_in, cin, packed, nbr, ld, n_out, kvol, weight_flip,
+                               row_order, tile_counter, out, cout, st);
+}
+
+MSMD_EXPORT int msmd_rulebook_permute_cols(const int32_t* nbr, int kvol, int ld, int n,
+                                           const int32_t* order, int32_t* out, hipStream_t st) {
+  if (kvol <= 0 || n < 0 || ld < n) return MSMD_ERR_INVALID_ARG;
+  if (n == 0) return MSMD_OK;
+  MSMD_LAUNCH(permute_cols_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, nbr, kvol, ld, n,
+              order, out);
+  return launch_status();
+}

@@ -247,6 +247,72 @@ def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False, row_
     return out
 
 
+# ---------------------------------------------- split-bf16 ("fp32-equivalent") conv path
+def split_supported(c_in, c_out, kvol=27):
+    """Does the bf16-split implicit GEMM cover (contraction c_in, outputs c_out)?"""
+    return bool(lib.msmd_spconv_fwd_split_supported(int(c_in), int(c_out), int(kvol)))
+
+
+def split_planes(feat, planes=3):
+    """fp32 [n,c] -> bf16 planes [(n+1), c/8, planes, 8]: x = h + m + l exactly
+    (planes=3); row n is all zero (the gather target of "no neighbour")."""
+    _need_cuda(feat)
+    f = feat.contiguous().float()
+    n, c = f.shape
+    out = torch.empty((n + 1, c // 8, planes, 8), dtype=torch.bfloat16, device=f.device)
+    check(lib.msmd_split_planes_f32(_p(f), n, c, planes, _p(out), _stream()),
+          "msmd_split_planes_f32")
+    return out
+
+
+def pack_weight_split(weight, planes=3, transpose=False, krsc=False):
+    """weight -> split bf16 planes in MFMA 16x16x32 fragment order."""
+    _need_cuda(weight)
+    w = weight.contiguous().float()
+    if krsc:
+        cout, cin = w.shape[0], w.shape[-1]
+        kvol = w.numel() // (cout * cin)
+    else:
+        kvol, cin, cout = w.shape
+    ci, co = (cout, cin) if transpose else (cin, cout)
+    packed = torch.empty((lib.msmd_spconv_packed_split_bytes(kvol, ci, co, planes),),
+                         dtype=torch.uint8, device=w.device)
+    check(lib.msmd_spconv_pack_weight_split(_p(w), kvol, cin, cout,
+                                            int(bool(transpose)) | (2 if krsc else 0), planes,
+                                            _p(packed), _stream()),
+          "msmd_spconv_pack_weight_split")
+    return packed
+
+
+def permute_cols(nbr, order):
+    """nbr[K,n] -> the table in tile order: out[k][p] = nbr[k][order[p]]."""
+    _need_cuda(nbr, order)
+    kvol, n = nbr.shape
+    out = torch.empty_like(nbr)
+    check(lib.msmd_rulebook_permute_cols(_p(nbr), kvol, n, n, _p(order), _p(out), _stream()),
+          "msmd_rulebook_permute_cols")
+    return out
+
+
+def conv_forward_split(planes_t, packed_weight, nbr, n_out, c_out, weight_flip=False,
+                       row_order=None):
+    """conv_forward on pre-split operands (split_planes / pack_weight_split).
+    With row_order, `nbr` must already be in tile order (permute_cols)."""
+    _need_cuda(planes_t, packed_weight, nbr)
+    n_in, c_in, np_ = planes_t.shape[0] - 1, planes_t.shape[1] * 8, planes_t.shape[2]
+    kvol, ld = nbr.shape
+    out = torch.empty((n_out, c_out), dtype=torch.float32, device=planes_t.device)
+    counter = torch.empty((1,), dtype=torch.int32, device=planes_t.device)
+    ev = _prof_begin()
+    check(lib.msmd_spconv_fwd_split(_p(planes_t), n_in, c_in, _p(packed_weight), _p(nbr), ld,
+                                    int(n_out), kvol, int(bool(weight_flip)), _p(row_order),
+                                    _p(counter), _p(out), int(c_out), np_, _stream()),
+          "msmd_spconv_fwd_split")
+    _prof_end("spconv_fwd_split", ev, nbr=nbr, c_in=c_in, c_out=int(c_out), n_in=n_in,
+              n_out=int(n_out))
+    return out
+
+
 def conv_wgrad(feat, d_out, pairs, num, krsc_shape=None):
     """dW from the compact pair lists: [K,Cin,Cout], or laid out as the KRSC
     parameter when krsc_shape (= weight.shape) is given."""

@@ -1,0 +1,16 @@
+# PMC passes over the split-bf16 conv microbench (one counter group per pass)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/pmc_split
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
+           "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
+           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/pmc_split/g$i -o s -- python $R/tools/split_bench.py --planes 3 > $R/gpurun_out/pmc_split/g$i.log 2>&1
+  f=$(find $R/gpurun_out/pmc_split/g$i -name "*counter_collection.csv" | head -1)
+  echo "== $grp"; [ -n "$f" ] && python $R/tools/pmc_summary.py $f spconv_fwd_split | cut -c1-400 || tail -3 $R/gpurun_out/pmc_split/g$i.log
+done
