@@ -27,6 +27,7 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_BF16_MFMA_TFLOPS = 2516.6   # 256 CUs x 4096 flop/clk x 2.4 GHz, dense
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 SAMPLES_PER_GPU = 4            # configs/transfusion_nusc_voxel_L.py:116
 
@@ -302,15 +303,18 @@ def roofline(prof):
     groups = {}
     for kind, s, e, meta in prof:
         ms = s.elapsed_time(e)
-        if kind == "spconv_fwd":
+        if kind in ("spconv_fwd", "spconv_fwd_split"):
             nbr = meta["nbr"]
             key = (nbr.data_ptr(), nbr.shape[1])
             if key not in pair_cache:
                 pair_cache[key] = int((nbr >= 0).sum().item())
             pairs = pair_cache[key]
             nt = (meta["c_out"] + 15) // 16
-            name = ("spconv_fwd_pipe_kernel<NT=%d>" if nt >= 4 and meta["c_in"] % 16 == 0
-                    else "spconv_fwd_kernel<NT=%d>") % nt
+            if kind == "spconv_fwd_split":
+                name = "spconv_fwd_split_kernel<NT=%d>" % nt
+            else:
+                name = ("spconv_fwd_pipe_kernel<NT=%d>" if nt >= 4 and meta["c_in"] % 16 == 0
+                        else "spconv_fwd_kernel<NT=%d>") % nt
         else:
             pairs = int(meta["num"].sum().item())
             name = "spconv_wgrad_kernel"
@@ -322,9 +326,17 @@ def roofline(prof):
     name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
     traffic, mfma_busy = pmc_traffic(name)
+    peak, peak_note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA (v_mfma_f32_16x16x4_f32)"
+    if name.startswith("spconv_fwd_split"):
+        from msmdfusion_amd.spconv.functional import conv_planes
+        products = {3: 6, 2: 3, 1: 1}[conv_planes()]
+        peak = round(PEAK_BF16_MFMA_TFLOPS / products, 1)
+        peak_note = ("dense bf16 MFMA peak %.0f TF / %d bf16 products per fp32-equivalent product "
+                     "(operands split into %d bf16 planes, fp32 accumulate)"
+                     % (PEAK_BF16_MFMA_TFLOPS, products, conv_planes()))
     return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3),
-            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic,
             "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes "
                             "(profiles/r01_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, "
                             "gfx950 correction), not re-measured in this run",

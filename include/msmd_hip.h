@@ -184,6 +184,39 @@ int msmd_spconv_fwd_f32(const float* in_feat /* [n_in,c_in] */, int n_in,
  * workgroups draw row tiles from *tile_counter (zeroed by the call) -- with a
  * heaviest-first row_order this balances the very uneven per-tile cost. */
 
+/* ---- the same convolution at bf16 MFMA rate, fp32-equivalent results -------
+ * Every fp32 operand is the exact sum of three bf16 values (h + m + l); six
+ * bf16 products accumulated in fp32 reproduce the fp32 product to ~2^-23 (the
+ * dropped cross terms are below fp32's own rounding), at 2.7x fewer matrix-core
+ * cycles than the fp32 MFMA.  `planes` = 3 is that mode; 2 keeps three products
+ * (relative error ~2^-17); 1 is plain bf16 operands.  Features are read as fp32
+ * and split in registers; weights are split by the pack call.
+ * Covers c_in % 32 == 0, c_out in {32, 64, 96, 128}, K <= 32 (ask
+ * msmd_spconv_fwd_split_supported); other layers use msmd_spconv_fwd_f32.
+ * With `row_order`, `nbr` must be in TILE order: nbr[k][p] refers to output row
+ * row_order[p] (msmd_rulebook_permute_cols).  `tile_counter` is required.      */
+int msmd_spconv_fwd_split_supported(int c_in, int c_out, int kernel_volume);
+
+size_t msmd_spconv_packed_split_bytes(int kernel_volume, int c_in /* contraction */,
+                                      int c_out /* outputs */, int planes);
+
+int msmd_spconv_pack_weight_split(const float* weight, int kernel_volume, int c_in,
+                                  int c_out, int flags /* as msmd_spconv_pack_weight */,
+                                  int planes, void* packed, msmd_stream_t stream);
+
+int msmd_spconv_fwd_split(const float* in_feat /* [n_in,c_in] */, int n_in, int c_in,
+                          const void* packed_weight, const int32_t* nbr /* [K,ld] */,
+                          int ld, int n_out, int kernel_volume, int weight_flip,
+                          const int32_t* row_order /* [n_out] or NULL */,
+                          int32_t* tile_counter /* [1] scratch */,
+                          float* out_feat /* [n_out,c_out] */, int c_out, int planes,
+                          msmd_stream_t stream);
+
+/* out[k][p] = nbr[k][order[p]] for p < n: the neighbour table in tile order. */
+int msmd_rulebook_permute_cols(const int32_t* nbr, int kernel_volume, int ld, int n,
+                               const int32_t* order, int32_t* out /* [K,n] */,
+                               msmd_stream_t stream);
+
 /* masks[o] = bitset over k of (nbr[k][o] >= 0); sort_keys[o] orders rows
  * heaviest mask first with equal masks adjacent.  Either output may be NULL.
  * kernel_volume <= 64. */

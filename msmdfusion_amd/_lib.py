@@ -53,8 +53,6 @@ SIGNATURES = {
     "msmd_rulebook_row_masks": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "msmd_spconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "msmd_spconv_wgrad_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
-    "msmd_split_planes_bytes": (_sz, [_i64, _i, _i]),
-    "msmd_split_planes_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "msmd_spconv_packed_split_bytes": (_sz, [_i, _i, _i, _i]),
     "msmd_spconv_pack_weight_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "msmd_spconv_fwd_split_supported": (_i, [_i, _i, _i]),

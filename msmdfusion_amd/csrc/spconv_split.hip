@@ -18,17 +18,12 @@
 // products (relative error ~2^-17, still 50x tighter than TF32, which is what
 // spconv-2.x runs on Ampere by default); NP = 1 is plain bf16 operands.
 //
-// Data: features are split ONCE per tensor (split_planes_kernel) into
-//   planes[row][c/8][NP][8] bf16   (+ one all-zero row at index n: the target
-//   of "no neighbour", so the gather needs no predication)
-// and used twice (forward + wgrad, or dgrad + wgrad).  Weights are split while
-// being packed into MFMA fragment order.
+// Data: the features stay fp32 in HBM (the module's own tensor); a gathered row
+// piece is split into planes in registers, between the MFMAs of the previous
+// unit (44 VALU ops per 8 channels, amortised over all of c_out).  Weights are
+// split once per call while being packed into MFMA fragment order.
 //
-// Forward / dgrad: same output-stationary pipelined implicit GEMM as
-// spconv_fwd_pipe_kernel (LDS-staged neighbour slice, active-offset list,
-// LDS-DMA double-buffered weights, ping-pong gathers straight into operand
-// registers, persistent LPT tile scheduler), with 32 rows per wave so every
-// weight fragment read from LDS feeds two row groups.
+// Forward / dgrad: output-stationary pipelined implicit GEMM (see the kernel).
 #include "common.hpp"
 
 #include <stdlib.h>
@@ -72,25 +67,6 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&p)[NP]) {
         r[2 * t + 1] = v[1] - back[1];
       }
     }
-  }
-}
-
-// in [n][8*c8] fp32 -> planes [(n+1)][c8][NP] x 16 bytes; row n is zero.
-template <int NP>
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, long n,
-                                                           int c8, u32x4* __restrict__ planes) {
-  const long total = (n + 1) * c8;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (e < n * c8) {
-      const f32x4 a = ((const f32x4*)in)[2 * e], b = ((const f32x4*)in)[2 * e + 1];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) x[t] = a[t], x[4 + t] = b[t];
-    }
-    u32x4 p[NP];
-    split8<NP>(x, p);
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl) planes[e * NP + pl] = p[pl];
   }
 }
 
@@ -180,34 +156,41 @@ constexpr unsigned kOobOffset = 0xffffff00u;
 // (vmcnt(0)) at the first use of an ordinary load's result while an LDS-DMA is
 // in flight, and at every __syncthreads(); hidden from it, the queue is
 // counted by hand (all waits below are "allow the N newest ops").
-template <int NP>
-__device__ __forceinline__ void gather_planes(u32x4 (&b)[NP], unsigned off, i32x4 rs) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(b[0]) : "v"(off), "s"(rs));
-  if (NP > 1)
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16"
-                 : "=v"(b[NP > 1 ? 1 : 0])
-                 : "v"(off), "s"(rs));
-  if (NP > 2)
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:32"
-                 : "=v"(b[NP > 2 ? 2 : 0])
-                 : "v"(off), "s"(rs));
+// One gathered row piece = 8 fp32 channels = 2 x 16 bytes.  (s_nop: the
+// descriptor may have been written by v_readfirstlane and the hazard recognizer
+// does not look inside asm -- VALU-written SGPR -> VMEM needs 5 wait states.)
+__device__ __forceinline__ void gather_row8(u32x4 (&raw)[2], unsigned off, i32x4 rs) {
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen"
+               : "=v"(raw[0])
+               : "v"(off), "s"(rs));
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:16"
+               : "=v"(raw[1])
+               : "v"(off), "s"(rs));
 }
-// s_waitcnt vmcnt(N) that the operand registers depend on (so no MFMA reading
-// them can be scheduled above it).
-template <int N, int NP>
-__device__ __forceinline__ void wait_planes(u32x4 (&b)[2][NP]) {
-  if (NP == 3)
-    asm volatile("s_waitcnt vmcnt(%6)"
-                 : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][NP > 2 ? 2 : 0]), "+v"(b[1][0]),
-                   "+v"(b[1][1]), "+v"(b[1][NP > 2 ? 2 : 0])
-                 : "n"(N));
-  else if (NP == 2)
-    asm volatile("s_waitcnt vmcnt(%4)"
-                 : "+v"(b[0][0]), "+v"(b[0][NP > 1 ? 1 : 0]), "+v"(b[1][0]),
-                   "+v"(b[1][NP > 1 ? 1 : 0])
-                 : "n"(N));
-  else
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0][0]), "+v"(b[1][0]) : "n"(N));
+// s_waitcnt vmcnt(N) that the raw registers depend on (so nothing reading them
+// can be scheduled above it).
+template <int N>
+__device__ __forceinline__ void wait_rows(u32x4 (&raw)[2][2]) {
+  asm volatile("s_waitcnt vmcnt(%4)"
+               : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1])
+               : "n"(N));
+}
+// 4 fp32 (one 16-byte piece) -> dwords [2h, 2h+1] of each bf16 plane.
+template <int NP>
+__device__ __forceinline__ void split_quarter(const u32x4& piece, int h, u32x4 (&planes)[NP]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    // (copy the elements out first: __builtin_bit_cast applied directly to a vector
+    // element lvalue reads element 0 whatever the index -- clang 20)
+    const unsigned e0 = piece[2 * t], e1 = piece[2 * t + 1];
+    f32x2 v = {__builtin_bit_cast(float, e0), __builtin_bit_cast(float, e1)};
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+      const bf16x2 hi = __builtin_convertvector(v, bf16x2);
+      planes[pl][2 * h + t] = __builtin_bit_cast(unsigned int, hi);
+      if (pl + 1 < NP) v = v - __builtin_convertvector(hi, f32x2);   // exact
+    }
+  }
 }
 
 // ------------------------------------------------------- forward / dgrad --
@@ -219,32 +202,35 @@ __device__ __forceinline__ void wait_planes(u32x4 (&b)[2][NP]) {
 // 27-bit offset mask (no LDS lists, no divisions); an ITEM = UB consecutive
 // units = one weight buffer fill + one barrier (UB * NT = 8: 24 KiB at NP = 3).
 //
-// Pipeline (everything below overlaps the MFMAs of the current unit):
+// Pipeline (everything below overlaps the MFMAs of the current unit g):
 //   * weights of item i+1: LDS-DMA (global_load_lds, lane-linear packed image);
-//   * gathered rows of unit g+2: 16-byte buffer loads straight into MFMA operand
-//     registers (3-deep ring), out-of-range offset for "no neighbour" (returns
-//     0, no traffic), from row indices fetched from LDS one unit earlier;
+//   * rows of unit g+2: 16-byte buffer loads of the fp32 features (the module's
+//     own tensor: no split copy in HBM), out-of-range offset for "no neighbour"
+//     (returns 0, no traffic), from row indices fetched from LDS a unit earlier;
+//   * rows of unit g+1: fp32 -> bf16 planes in registers (cvt_pk / pk_add),
+//     interleaved between the MFMAs;
 //   * weight fragments of the next 32 output channels: LDS -> registers,
 //     double-buffered, issued a third of the way into the current MFMA block;
 //   * the NEXT tile's slice of the neighbour table + its output rows: LDS-DMA
 //     into the other table buffer during item 1 (tile id from an atomic issued
 //     at tile start) -- a tile switch costs one barrier, not 3 round trips.
-// All barriers are raw s_barrier and all VM waits are counted by hand (see
-// gather_planes): __syncthreads() would drain the queue at every item.
+// All barriers are raw s_barrier and all VM waits are counted by hand:
+// __syncthreads() would drain the queue at every item.
 // `nbr` must be in TILE order when `order` is given: column p of the table
 // belongs to output row order[p] (msmd_rulebook_permute_cols), so a tile's
 // slice is 512 contiguous bytes per offset.
 template <int NT, int UB, int NP>
 __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
-    const u32x4* __restrict__ planes, int n_in, int cin, const u32x4* __restrict__ wp,
+    const float* __restrict__ in, int n_in, int cin, const u32x4* __restrict__ wp,
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
     const int32_t* __restrict__ order, int* __restrict__ tile_counter, float* __restrict__ out,
     int cout, int dbg) {
   constexpr int R = 2, kRows = 4 * R * 16;
   constexpr int kUnitU = NP * NT * 64;  // 16-byte units of one unit's weights
   constexpr int kWU = UB * kUnitU;
-  constexpr int kGu = R * NP;           // gather loads per unit per lane
-  constexpr int kWp = (UB * NP * NT + 3) / 4;  // weight DMA ops per item per wave
+  constexpr int kGr = R * 2;            // gather loads per unit per lane
+  constexpr int kPw = (NP * NT + 3) / 4;  // weight DMA ops per unit per wave
+  constexpr int kWp = UB * kPw;           // ... per item per wave
   constexpr int NS = NT / 2;            // fragment steps (pairs of 16-channel tiles) per unit
   static_assert(NT % 2 == 0, "pairs of output tiles");
   using P = Products<NP>;
@@ -256,13 +242,13 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
-  const int c8 = cin >> 3, kbt = cin >> 5;
+  const int kbt = cin >> 5;
   const int n_tiles = (n_out + kRows - 1) / kRows;
   int lr[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) lr[r] = (wave * R + r) * 16 + j;
-  const i32x4 rs = make_rsrc(planes, (unsigned)((size_t)(n_in + 1) * c8 * NP * 16));
-  const unsigned row_bytes = (unsigned)(c8 * NP * 16);
+  const i32x4 rs = make_rsrc(in, (unsigned)((size_t)n_in * cin * 4));
+  const unsigned row_bytes = (unsigned)cin * 4u;
 
   // table slice of tile T -> buffer b, by LDS-DMA (4 bytes per lane).  Positions
   // past n_out are clamped: their results are computed and dropped.
@@ -303,7 +289,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
       }
       if (lane == 0 && m) atomicOr((unsigned*)&ctl[tb], m);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the tile-id atomic too)
     __builtin_amdgcn_s_barrier();
     const unsigned mask = __builtin_amdgcn_readfirstlane(ctl[tb]);
     const int n_units = __builtin_popcount(mask) * kbt;
@@ -330,16 +316,16 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
       for (int r = 0; r < R; ++r) s_next[r] = ms ? tab[k * kRows + lr[r]] : -1;
       MSMD_ADV(ms, kbs);
     };
-    auto issue_g = [&](u32x4 (&b)[R][NP], int& valid) {  // cursor `g`, rows s_next
+    auto issue_g = [&](u32x4 (&raw)[R][2], int& valid) {  // cursor `g`, rows s_next
       valid = -1;
-      const unsigned col = (unsigned)((kbg * 4 + q) * NP * 16);
+      const unsigned col = (unsigned)(kbg * 128 + q * 32);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int src = s_next[r];
         valid = src > valid ? src : valid;
         const unsigned off =
             (src < 0 || (dbg & 2)) ? kOobOffset : (unsigned)src * row_bytes + col;
-        gather_planes<NP>(b[r], off, rs);
+        gather_row8(raw[r], off, rs);
       }
       MSMD_ADV(mg, kbg);
     };
@@ -353,7 +339,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
         // every wave issues the same number of ops (a short last round repeats
         // piece 0: same bytes to the same place) so the queue counts are static
 #pragma unroll
-        for (int pp = 0; pp < (NP * NT + 3) / 4; ++pp) {
+        for (int pp = 0; pp < kPw; ++pp) {
           int piece = wave + 4 * pp;
           if ((NP * NT) % 4 != 0 && piece >= NP * NT) piece = 0;
           __builtin_amdgcn_global_load_lds((glb_void*)(g + piece * 64 + lane),
@@ -362,18 +348,21 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
         MSMD_ADV(mw, kbw);
       }
     };
-    auto compute = [&](int it, int u, u32x4 (&b)[R][NP], int valid) {
-      // rows of this unit: at most the two later units' gathers (and, for the
-      // first two units of an item, the weight DMA issued at its top) are newer
-      if (UB > 1) {
-        if (u < 2)
-          wait_planes<2 * kGu + kWp, NP>(b);
-        else
-          wait_planes<2 * kGu, NP>(b);
-      } else {
-        wait_planes<2 * kGu + 2 * kWp, NP>(b);   // already satisfied by the item-top wait
+    auto split_all = [&](const u32x4 (&raw)[R][2], u32x4 (&cv)[R][NP]) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) split_quarter<NP>(raw[r][h], h, cv[r]);
+    };
+    // Multiply unit (it, u) from its converted rows `b`; meanwhile convert the
+    // next unit's rows raw_n -> b_n, a quarter (4 channels of one row group) per
+    // fragment step, interleaved with the MFMAs.
+    auto compute = [&](int it, int u, const u32x4 (&b)[R][NP], int valid,
+                       const u32x4 (&raw_n)[R][2], u32x4 (&b_n)[R][NP]) {
+      if (!__any(valid >= 0) || (dbg & 4)) {
+        split_all(raw_n, b_n);
+        return;
       }
-      if (!__any(valid >= 0) || (dbg & 4)) return;
       const u32x4* wb = wl + (it & 1) * kWU + u * kUnitU + lane;
       u32x4 a[2][2][NP];
 #pragma unroll
@@ -405,6 +394,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
+        for (int qi = st * 4 / NS; qi < (st + 1) * 4 / NS; ++qi)
+          split_quarter<NP>(raw_n[qi >> 1][qi & 1], qi & 1, b_n[qi >> 1]);
+#pragma unroll
         for (int t = kHead; t < P::n; ++t)
 #pragma unroll
           for (int nn = 0; nn < 2; ++nn)
@@ -412,42 +404,59 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
             for (int r = 0; r < R; ++r)
               acc[r][2 * st + nn] =
                   mfma_bf16(a[st & 1][nn][P::a[t]], b[r][P::b[t]], acc[r][2 * st + nn]);
+        // one MFMA, then up to three conversion VALU ops in its shadow
+#pragma unroll
+        for (int i = 0; i < (P::n - kHead) * 2 * R; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     };
 
-    u32x4 ring0[R][NP], ring1[R][NP], ring2[R][NP];
-    int vr0 = -1, vr1 = -1, vr2 = -1;
+    u32x4 raw0[R][2], raw1[R][2];     // fp32 rows in flight (units g+1, g+2)
+    u32x4 cv0[R][NP], cv1[R][NP];     // bf16 planes (units g, g+1)
+    int vr0 = -1, vr1 = -1;
     bool staged = false;
     int nxt = n_tiles;
-    // ---- prologue: weights of item 0, rows of units 0 and 1, indices of unit 2
+    // ---- prologue: weights of item 0, rows of units 0 and 1, indices of unit 2,
+    // planes of unit 0
     issue_w(0);
     load_src();
-    issue_g(ring0, vr0);
+    issue_g(raw0, vr0);
     load_src();
-    issue_g(ring1, vr1);
+    issue_g(raw1, vr1);
     load_src();
-    // One unit: start the gathers two units ahead, fetch the indices three ahead,
-    // multiply the current one.
-#define MSMD_UNIT(IT, U, BC, VC, BF, VF) \
-  {                                      \
-    issue_g(BF, VF);                     \
-    load_src();                          \
-    compute((IT), (U), BC, VC);          \
+    wait_rows<kGr>(raw0);
+    split_all(raw0, cv0);
+    // One unit g (slot S = g % 2): start the gathers of g+2 into the raw slot g
+    // vacated, fetch the indices of g+3, wait for the rows of g+1 (newer ops: the
+    // gathers just issued and, for the first unit of an item, the weight DMA of
+    // its top), multiply g while converting g+1.
+#define MSMD_UNIT(IT, U, RAW_C, V_C, CV_C, RAW_N, V_N, CV_N)            \
+  {                                                                     \
+    const int v_cur = V_C;                                              \
+    issue_g(RAW_C, V_C);                                                \
+    load_src();                                                         \
+    if ((U) == 0)                                                       \
+      wait_rows<kGr + kWp>(RAW_N);                                      \
+    else                                                                \
+      wait_rows<kGr>(RAW_N);                                            \
+    compute((IT), (U), CV_C, v_cur, RAW_N, CV_N);                       \
   }
-    // One item.  Memory ops retire in order; at the top of item `it` the newest
-    // UB*kGu ops are gathers, everything older -- including weights(it) -- has
-    // landed once vmcnt drops to that count (item 0: drain = pipeline fill).
+#define MSMD_SLOT_UNIT(IT, U, S)                                        \
+  if ((S) % 2 == 0) MSMD_UNIT(IT, U, raw0, vr0, cv0, raw1, vr1, cv1)    \
+  else MSMD_UNIT(IT, U, raw1, vr1, cv1, raw0, vr0, cv0)
+    // One item.  Memory ops retire in order; at its top the newest UB*kGr ops are
+    // the previous item's gathers, everything older -- including weights(it) --
+    // has landed once vmcnt drops to that count.
 #define MSMD_ITEM(IT, PH)                                                              \
   {                                                                                    \
     if ((IT) == 1 && tid == 0) {                                                       \
       ctl[2] = nxt_v;                                                                  \
       ctl[tb ^ 1] = 0;                                                                 \
     }                                                                                  \
-    if ((IT) == 0)                                                                     \
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                      \
-    else                                                                               \
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(UB * kGu) : "memory");       \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(UB * kGr) : "memory");         \
     __builtin_amdgcn_s_barrier();                                                      \
     if ((IT) == 1) {                                                                   \
       nxt = __builtin_amdgcn_readfirstlane(ctl[2]);                                    \
@@ -455,26 +464,17 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
       staged = true;                                                                   \
     }                                                                                  \
     issue_w((IT) + 1);                                                                 \
-    MSMD_ITEM_UNITS(IT, PH)                                                            \
+    MSMD_SLOT_UNIT(IT, 0, (PH)*UB + 0)                                                 \
+    if (UB > 1) { MSMD_SLOT_UNIT(IT, 1, (PH)*UB + 1) }                                 \
+    if (UB > 2) { MSMD_SLOT_UNIT(IT, 2, (PH)*UB + 2) }                                 \
+    if (UB > 3) { MSMD_SLOT_UNIT(IT, 3, (PH)*UB + 3) }                                 \
   }
-// ring slot of unit g = it*UB + u is g % 3 = (PH*UB + u) % 3 with PH = it % 3
-#define MSMD_RING_UNIT(IT, U, S)                                        \
-  if ((S) % 3 == 0) MSMD_UNIT(IT, U, ring0, vr0, ring2, vr2)            \
-  else if ((S) % 3 == 1) MSMD_UNIT(IT, U, ring1, vr1, ring0, vr0)       \
-  else MSMD_UNIT(IT, U, ring2, vr2, ring1, vr1)
-#define MSMD_ITEM_UNITS(IT, PH)                                   \
-  MSMD_RING_UNIT(IT, 0, (PH)*UB + 0)                              \
-  if (UB > 1) { MSMD_RING_UNIT(IT, 1, (PH)*UB + 1) }              \
-  if (UB > 2) { MSMD_RING_UNIT(IT, 2, (PH)*UB + 2) }              \
-  if (UB > 3) { MSMD_RING_UNIT(IT, 3, (PH)*UB + 3) }
-    for (int it = 0; it < n_items; it += 3) {
+    for (int it = 0; it < n_items; it += 2) {
       MSMD_ITEM(it, 0);
       if (it + 1 < n_items) MSMD_ITEM(it + 1, 1);
-      if (it + 2 < n_items) MSMD_ITEM(it + 2, 2);
     }
 #undef MSMD_ITEM
-#undef MSMD_ITEM_UNITS
-#undef MSMD_RING_UNIT
+#undef MSMD_SLOT_UNIT
 #undef MSMD_UNIT
 #undef MSMD_ADV
     // ---- epilogue: lane (j,q) holds out[row j][16n + 4q .. +3] ----
@@ -513,7 +513,7 @@ int split_slots_per_cu() {
 }
 
 template <int NT, int UB, int NP>
-int launch_fwd_split(const void* planes, int n_in, int cin, const void* wp, const int32_t* nbr,
+int launch_fwd_split(const float* planes, int n_in, int cin, const void* wp, const int32_t* nbr,
                      int ld, int n_out, int kvol, int flip, const int32_t* order,
                      int* tile_counter, float* out, int cout, hipStream_t st) {
   constexpr int kRows = 128;
@@ -530,14 +530,14 @@ int launch_fwd_split(const void* planes, int n_in, int cin, const void* wp, cons
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_smem = smem;
   }
-  MSMD_LAUNCH(kern, dim3(nblk), dim3(256), smem, st, (const u32x4*)planes, n_in, cin,
+  MSMD_LAUNCH(kern, dim3(nblk), dim3(256), smem, st, planes, n_in, cin,
               (const u32x4*)wp, nbr, ld, n_out, kvol, flip, order, tile_counter, out, cout,
               env_int2("MSMD_DBG", 0));
   return launch_status();
 }
 
 template <int NP>
-int dispatch_fwd_split(const void* planes, int n_in, int cin, const void* wp, const int32_t* nbr,
+int dispatch_fwd_split(const float* planes, int n_in, int cin, const void* wp, const int32_t* nbr,
                        int ld, int n_out, int kvol, int flip, const int32_t* order,
                        int* tile_counter, float* out, int cout, hipStream_t st) {
 #define MSMD_GO(NT_, UB_)                                                                      \
@@ -569,30 +569,6 @@ __global__ __launch_bounds__(256) void permute_cols_kernel(const int32_t* __rest
 
 using namespace msmd;
 
-MSMD_EXPORT size_t msmd_split_planes_bytes(int64_t n, int c, int np) {
-  if (n < 0 || c <= 0 || (c & 7) || np < 1 || np > 3) return 0;
-  return (size_t)(n + 1) * c * np * 2;
-}
-
-MSMD_EXPORT int msmd_split_planes_f32(const float* in, int64_t n, int c, int np, void* planes,
-                                      hipStream_t st) {
-  if (n < 0 || c <= 0 || (c & 7) || np < 1 || np > 3) return MSMD_ERR_INVALID_ARG;
-  const int c8 = c >> 3;
-  const long total = (long)(n + 1) * c8;
-  int nblk = (int)((total + 255) / 256);
-  if (nblk > 256 * 16) nblk = 256 * 16;
-  if (np == 3)
-    MSMD_LAUNCH(split_planes_kernel<3>, dim3(nblk), dim3(256), 0, st, in, (long)n, c8,
-                (u32x4*)planes);
-  else if (np == 2)
-    MSMD_LAUNCH(split_planes_kernel<2>, dim3(nblk), dim3(256), 0, st, in, (long)n, c8,
-                (u32x4*)planes);
-  else
-    MSMD_LAUNCH(split_planes_kernel<1>, dim3(nblk), dim3(256), 0, st, in, (long)n, c8,
-                (u32x4*)planes);
-  return launch_status();
-}
-
 MSMD_EXPORT size_t msmd_spconv_packed_split_bytes(int kvol, int cin, int cout, int np) {
   return (size_t)kvol * ((cin + 31) / 32) * ((cout + 15) / 16) * np * 1024;
 }
@@ -601,7 +577,8 @@ MSMD_EXPORT size_t msmd_spconv_packed_split_bytes(int kvol, int cin, int cout, i
 // W[k]^T (contraction over c_out): its size is msmd_spconv_packed_split_bytes(K,
 // cout, cin, np).
 MSMD_EXPORT int msmd_spconv_pack_weight_split(const float* w, int kvol, int cin, int cout,
-                                              int flags, int np, void* packed, hipStream_t st) {
+                                              int flags, int np, void* packed, msmd_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
   if (kvol <= 0 || cin <= 0 || cout <= 0 || np < 1 || np > 3) return MSMD_ERR_INVALID_ARG;
   const int ci = (flags & 1) ? cout : cin, co = (flags & 1) ? cin : cout;
   const long total = (long)kvol * ((ci + 31) / 32) * ((co + 15) / 16) * 64;
@@ -625,11 +602,12 @@ MSMD_EXPORT int msmd_spconv_fwd_split_supported(int cin, int cout, int kvol) {
          (nt == 8 || nt == 6 || nt == 4 || nt == 2);
 }
 
-MSMD_EXPORT int msmd_spconv_fwd_split(const void* planes, int n_in, int cin, const void* packed,
+MSMD_EXPORT int msmd_spconv_fwd_split(const float* planes, int n_in, int cin, const void* packed,
                                       const int32_t* nbr, int ld, int n_out, int kvol,
                                       int weight_flip, const int32_t* row_order,
                                       int32_t* tile_counter, float* out, int cout, int np,
-                                      hipStream_t st) {
+                                      msmd_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
   if (!msmd_spconv_fwd_split_supported(cin, cout, kvol) || np < 1 || np > 3)
     return MSMD_ERR_UNSUPPORTED;
   if (!tile_counter) return MSMD_ERR_INVALID_ARG;
@@ -645,7 +623,8 @@ MSMD_EXPORT int msmd_spconv_fwd_split(const void* planes, int n_in, int cin, con
 }
 
 MSMD_EXPORT int msmd_rulebook_permute_cols(const int32_t* nbr, int kvol, int ld, int n,
-                                           const int32_t* order, int32_t* out, hipStream_t st) {
+                                           const int32_t* order, int32_t* out, msmd_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
   if (kvol <= 0 || n < 0 || ld < n) return MSMD_ERR_INVALID_ARG;
   if (n == 0) return MSMD_OK;
   MSMD_LAUNCH(permute_cols_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, nbr, kvol, ld, n,

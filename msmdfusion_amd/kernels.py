@@ -253,18 +253,6 @@ def split_supported(c_in, c_out, kvol=27):
     return bool(lib.msmd_spconv_fwd_split_supported(int(c_in), int(c_out), int(kvol)))
 
 
-def split_planes(feat, planes=3):
-    """fp32 [n,c] -> bf16 planes [(n+1), c/8, planes, 8]: x = h + m + l exactly
-    (planes=3); row n is all zero (the gather target of "no neighbour")."""
-    _need_cuda(feat)
-    f = feat.contiguous().float()
-    n, c = f.shape
-    out = torch.empty((n + 1, c // 8, planes, 8), dtype=torch.bfloat16, device=f.device)
-    check(lib.msmd_split_planes_f32(_p(f), n, c, planes, _p(out), _stream()),
-          "msmd_split_planes_f32")
-    return out
-
-
 def pack_weight_split(weight, planes=3, transpose=False, krsc=False):
     """weight -> split bf16 planes in MFMA 16x16x32 fragment order."""
     _need_cuda(weight)
@@ -294,19 +282,21 @@ def permute_cols(nbr, order):
     return out
 
 
-def conv_forward_split(planes_t, packed_weight, nbr, n_out, c_out, weight_flip=False,
+def conv_forward_split(feat, packed_weight, nbr, n_out, c_out, planes=3, weight_flip=False,
                        row_order=None):
-    """conv_forward on pre-split operands (split_planes / pack_weight_split).
-    With row_order, `nbr` must already be in tile order (permute_cols)."""
-    _need_cuda(planes_t, packed_weight, nbr)
-    n_in, c_in, np_ = planes_t.shape[0] - 1, planes_t.shape[1] * 8, planes_t.shape[2]
+    """conv_forward at bf16 MFMA rate with fp32-equivalent results: fp32 features
+    are split into `planes` bf16 planes in registers, weights are pre-split
+    (pack_weight_split).  With row_order, `nbr` must be in tile order (permute_cols)."""
+    _need_cuda(feat, packed_weight, nbr)
+    f = feat.contiguous().float()
+    n_in, c_in = f.shape
     kvol, ld = nbr.shape
-    out = torch.empty((n_out, c_out), dtype=torch.float32, device=planes_t.device)
-    counter = torch.empty((1,), dtype=torch.int32, device=planes_t.device)
+    out = torch.empty((n_out, c_out), dtype=torch.float32, device=f.device)
+    counter = torch.empty((1,), dtype=torch.int32, device=f.device)
     ev = _prof_begin()
-    check(lib.msmd_spconv_fwd_split(_p(planes_t), n_in, c_in, _p(packed_weight), _p(nbr), ld,
+    check(lib.msmd_spconv_fwd_split(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld,
                                     int(n_out), kvol, int(bool(weight_flip)), _p(row_order),
-                                    _p(counter), _p(out), int(c_out), np_, _stream()),
+                                    _p(counter), _p(out), int(c_out), int(planes), _stream()),
           "msmd_spconv_fwd_split")
     _prof_end("spconv_fwd_split", ev, nbr=nbr, c_in=c_in, c_out=int(c_out), n_in=n_in,
               n_out=int(n_out))

@@ -33,6 +33,8 @@ class IndiceData:
         self._pairs = None
         self._order_fwd = None
         self._order_bwd = None
+        self._tiled_fwd = None
+        self._tiled_bwd = None
 
     @property
     def n_in(self):
@@ -69,6 +71,24 @@ class IndiceData:
         if self._order_bwd is None:
             self._order_bwd = (K.row_mask_order(self.nbr_bwd),)
         return self._order_bwd[0]
+
+    def tiled_fwd(self):
+        """The forward table with its columns in tiling order (column p belongs
+        to output row order_fwd()[p]): what the split-bf16 kernel stages per tile."""
+        if self._tiled_fwd is None:
+            order = self.order_fwd()
+            self._tiled_fwd = (K.permute_cols(self.nbr_fwd, order) if order is not None
+                               else self.nbr_fwd,)
+        return self._tiled_fwd[0]
+
+    def tiled_bwd(self):
+        if self.is_subm:
+            return self.tiled_fwd()
+        if self._tiled_bwd is None:
+            order = self.order_bwd()
+            self._tiled_bwd = (K.permute_cols(self.nbr_bwd, order) if order is not None
+                               else self.nbr_bwd,)
+        return self._tiled_bwd[0]
 
 
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,

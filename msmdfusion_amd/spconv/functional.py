@@ -5,10 +5,28 @@ Weights arrive as [K, Cin, Cout] (the layout indiceConv contracts with,
 spconv_ops.h:299); modules keep their parameter in spconv-2.x's KRSC layout
 and hand a permuted view in, so autograd maps the gradient back.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
 from .. import kernels as K
+
+
+def conv_planes():
+    """Arithmetic of the sparse convolutions' forward and dgrad:
+    3 (default) -- operands split into three bf16 planes, six products on the
+                   bf16 matrix cores, fp32 accumulate: fp32-equivalent results
+                   (csrc/spconv_split.hip) at 2.7x fewer MFMA cycles;
+    2           -- two planes, three products (relative error ~2^-17);
+    0           -- the fp32 matrix instruction (csrc/spconv.hip).
+    Layers the split kernel does not cover (c_in % 32 != 0, c_out not in
+    {32, 64, 96, 128}) always use the fp32 kernel."""
+    return int(os.environ.get("MSMD_CONV_PLANES", "3"))
+
+
+def _use_split(c_in, c_out, kvol):
+    return conv_planes() in (1, 2, 3) and K.split_supported(c_in, c_out, kvol)
 
 
 def _wants_order(c_in, c_out):
@@ -25,8 +43,13 @@ class _SparseConvFunction(Function):
     def forward(ctx, features, weight, rb, krsc):
         ctx.rb, ctx.krsc = rb, krsc
         ctx.save_for_backward(features, weight)
-        packed = K.pack_weight(weight, krsc=krsc)
         c_in, c_out = (weight.shape[-1], weight.shape[0]) if krsc else weight.shape[1:]
+        if _use_split(c_in, c_out, rb.nbr_fwd.shape[0]):
+            np_ = conv_planes()
+            packed = K.pack_weight_split(weight, np_, krsc=krsc)
+            return K.conv_forward_split(features, packed, rb.tiled_fwd(), rb.n_out, c_out, np_,
+                                        row_order=rb.order_fwd())
+        packed = K.pack_weight(weight, krsc=krsc)
         return K.conv_forward(features, packed, rb.nbr_fwd, rb.n_out, c_out,
                               row_order=rb.order_fwd() if _wants_order(c_in, c_out) else None)
 
@@ -37,7 +60,13 @@ class _SparseConvFunction(Function):
         c_in, c_out = (weight.shape[-1], weight.shape[0]) if krsc else weight.shape[1:]
         grad_out = grad_out.contiguous()
         d_feat = d_w = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and _use_split(c_out, c_in, rb.nbr_fwd.shape[0]):
+            np_ = conv_planes()
+            packed_t = K.pack_weight_split(weight, np_, transpose=True, krsc=krsc)
+            # SubM: forward table + flipped weights == backward table
+            d_feat = K.conv_forward_split(grad_out, packed_t, rb.tiled_bwd(), rb.n_in, c_in, np_,
+                                          weight_flip=rb.is_subm, row_order=rb.order_bwd())
+        elif ctx.needs_input_grad[0]:
             packed_t = K.pack_weight(weight, transpose=True, krsc=krsc)
             order = rb.order_bwd() if _wants_order(c_out, c_in) else None
             if rb.is_subm:   # forward table + flipped weights == backward table

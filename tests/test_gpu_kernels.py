@@ -219,6 +219,112 @@ def test_strided_conv_fwd_bwd(dev, ks, st, pd, cin, cout):
     np.testing.assert_allclose(dw.cpu().numpy(), edw, rtol=TOL, atol=TOL * 5)
 
 
+# --------------------------------------------- split-bf16 ("fp32-equivalent") convolution
+SPLIT_CHANNELS = [(32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (96, 96), (64, 32),
+                  (128, 64), (128, 96)]
+
+
+@pytest.mark.parametrize("planes", [3, 2])
+@pytest.mark.parametrize("cin,cout", SPLIT_CHANNELS)
+def test_split_conv_subm(dev, cin, cout, planes):
+    """msmd_spconv_fwd_split (forward and dgrad) against the oracle; planes=3 must
+    be as close to an fp64 evaluation as the fp32 MFMA kernel is."""
+    from msmdfusion_amd import kernels as K
+    assert K.split_supported(cin, cout) and K.split_supported(cout, cin)
+    shape = [11, 64, 64]
+    idx = S.random_voxel_indices(1500, 2, shape, seed=cin + cout)
+    n = idx.shape[0]
+    rng = np.random.RandomState(cin * 1000 + cout)
+    f = rng.randn(n, cin).astype(np.float32)
+    w = (rng.randn(27, cin, cout) / np.sqrt(27 * cin)).astype(np.float32)
+    g = rng.randn(n, cout).astype(np.float32)
+    oi, pr, nm, _ = O.get_indice_pairs(idx, 2, shape, 3, 1, 1, 1, True)
+    exp = O.indice_conv_fwd(f, w, pr, nm, n, subm=True)
+    edin, _ = O.indice_conv_bwd(f, w, g, pr, nm, subm=True)
+    tol = TOL if planes == 3 else 2 * TOL
+
+    nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
+    wd, fd = t(w, dev), t(f, dev)
+    ws = K.pack_weight_split(wd, planes)
+    out = K.conv_forward_split(fd, ws, nbr, n, cout, planes)
+    np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=tol, atol=tol)
+    # any tiling order gives bit-identical results; the table travels in tile order
+    for order in (K.row_mask_order(nbr), torch.randperm(n, device=dev).int()):
+        out_o = K.conv_forward_split(fd, ws, K.permute_cols(nbr, order), n, cout, planes,
+                                     row_order=order)
+        assert torch.equal(out, out_o)
+    # KRSC weights pack to the same image
+    w_krsc = wd.permute(2, 0, 1).contiguous().view(cout, 3, 3, 3, cin)
+    assert torch.equal(ws, K.pack_weight_split(w_krsc, planes, krsc=True))
+    # dgrad: forward table read with flipped weights and W^T
+    din = K.conv_forward_split(t(g, dev), K.pack_weight_split(wd, planes, transpose=True), nbr,
+                               n, cin, planes, weight_flip=True)
+    np.testing.assert_allclose(din.cpu().numpy(), edin, rtol=tol, atol=tol)
+    if planes == 3:   # fp32-equivalent: error against fp64 no worse than the fp32 kernel's
+        ref = np.zeros((n, cout))
+        nb = nbr.cpu().numpy()
+        for k in range(27):
+            m = nb[k] >= 0
+            ref[m] += f[nb[k][m]].astype(np.float64) @ w[k].astype(np.float64)
+        e_split = np.abs(out.cpu().numpy() - ref).max()
+        e_fp32 = np.abs(K.conv_forward(fd, K.pack_weight(wd), nbr, n, cout).cpu().numpy()
+                        - ref).max()
+        assert e_split <= 2.0 * e_fp32 + 1e-7, (e_split, e_fp32)
+
+
+@pytest.mark.parametrize("ks,st,pd", [(3, 2, 1), (3, 2, [0, 1, 1]), ([3, 1, 1], [2, 1, 1], 0)])
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 128), (128, 128)])
+def test_split_conv_strided(dev, ks, st, pd, cin, cout):
+    from msmdfusion_amd import kernels as K
+    shape = [11, 64, 64]
+    idx = S.random_voxel_indices(1500, 2, shape, seed=11)
+    n = idx.shape[0]
+    rng = np.random.RandomState(7)
+    f = rng.randn(n, cin).astype(np.float32)
+    kvol = int(np.prod(O.expand3(ks)))
+    w = (rng.randn(kvol, cin, cout) / np.sqrt(kvol * cin)).astype(np.float32)
+    oi, pr, nm, osz = O.get_indice_pairs(idx, 2, shape, ks, st, pd, 1, False)
+    m = oi.shape[0]
+    g = rng.randn(m, cout).astype(np.float32)
+    exp = O.indice_conv_fwd(f, w, pr, nm, m)
+    edin, _ = O.indice_conv_bwd(f, w, g, pr, nm)
+    _, _, perm = O.canonical_rulebook(oi, pr, nm, osz)
+
+    _, nbr_fwd, nbr_bwd, _ = K.rulebook_conv(t(idx, dev), 2, shape, ks, st, pd)
+    wd = t(w, dev)
+    of = K.row_mask_order(nbr_fwd)
+    out = K.conv_forward_split(t(f, dev), K.pack_weight_split(wd, 3), K.permute_cols(nbr_fwd, of),
+                               m, cout, 3, row_order=of)
+    np.testing.assert_allclose(out.cpu().numpy(), exp[perm], rtol=TOL, atol=TOL)
+    ob = K.row_mask_order(nbr_bwd)
+    din = K.conv_forward_split(t(g[perm], dev), K.pack_weight_split(wd, 3, transpose=True),
+                               K.permute_cols(nbr_bwd, ob), n, cin, 3, row_order=ob)
+    np.testing.assert_allclose(din.cpu().numpy(), edin, rtol=TOL, atol=TOL)
+
+
+def test_split_conv_edges(dev):
+    """Empty and tiny inputs, a single tile with padding rows, unsupported shapes."""
+    from msmdfusion_amd import kernels as K
+    from msmdfusion_amd._lib import MsmdError
+    assert not K.split_supported(16, 16) and not K.split_supported(5, 16)
+    assert not K.split_supported(32, 48) and not K.split_supported(48, 64)
+    w = torch.randn(27, 32, 64, device=dev)
+    ws = K.pack_weight_split(w, 3)
+    for n in (0, 1, 3, 129):
+        f = torch.randn(n, 32, device=dev)
+        nbr = torch.full((27, n), -1, dtype=torch.int32, device=dev)
+        if n:
+            nbr[13] = torch.arange(n, dtype=torch.int32, device=dev)
+        out = K.conv_forward_split(f, ws, nbr, n, 64, 3)
+        ref = f.double() @ w[13].double()
+        assert out.shape == (n, 64)
+        if n:
+            np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    with pytest.raises(MsmdError):
+        K.conv_forward_split(torch.randn(4, 16, device=dev), ws,
+                             torch.zeros((27, 4), dtype=torch.int32, device=dev), 4, 16, 3)
+
+
 # ------------------------------------------------------------------ dense / sets
 @pytest.mark.parametrize("c", [1, 5, 128, 192])
 def test_dense_scatter_gather(dev, c):

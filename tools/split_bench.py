@@ -76,17 +76,16 @@ def main():
             cin, cout, n, pairs_n, t32, flops / t32 / 1e6)
         if K.split_supported(cin, cout):
             ws = K.pack_weight_split(w, args.planes)
-            tsp = timed(lambda: K.split_planes(f, args.planes))
-            pl = K.split_planes(f, args.planes)
             nbr_t = K.permute_cols(nbr, order)
-            ts = timed(lambda: K.conv_forward_split(pl, ws, nbr_t, n, cout, row_order=order))
-            line += " | split%d %.0f us %.1f TF (+split pass %.0f us)" % (
-                args.planes, ts, flops / ts / 1e6, tsp)
+            ts = timed(lambda: K.conv_forward_split(f, ws, nbr_t, n, cout, args.planes,
+                                                    row_order=order))
+            line += " | split%d %.0f us %.1f TF" % (args.planes, ts, flops / ts / 1e6)
             if args.check:
                 r = ref64(f, w, nbr)
                 o32 = K.conv_forward(f, wp, nbr, n, cout, row_order=order).double()
-                osp = K.conv_forward_split(pl, ws, nbr_t, n, cout, row_order=order).double()
-                onat = K.conv_forward_split(pl, ws, nbr, n, cout).double()
+                osp = K.conv_forward_split(f, ws, nbr_t, n, cout, args.planes,
+                                           row_order=order).double()
+                onat = K.conv_forward_split(f, ws, nbr, n, cout, args.planes).double()
                 assert torch.equal(onat, osp), "tile order changed the result"
                 sc = r.abs().max().item()
                 line += " | max|err|/max|out|: fp32 %.2e split %.2e" % (
