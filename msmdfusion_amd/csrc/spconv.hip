@@ -487,41 +487,73 @@ __global__ __launch_bounds__(256) void row_mask_kernel(const int32_t* __restrict
 // ------------------------------------------------------------------ wgrad --
 // dW[k] = sum_p in[i_p,:]^T (x) dout[o_p,:] over the compact pairs of offset k.
 // MFMA 16x16x4 with the pair index as the contraction: A[ci][p], B[p][co], four
-// pairs per instruction.  A workgroup = (2048-pair chunk, offset k, 64x64 channel
-// slab); its 4 waves take interleaved groups of 4 pairs.
+// pairs per instruction.  A workgroup = (CHUNK-pair chunk, offset k, slab of
+// 16*SA x 16*SB channels); its 4 waves take interleaved groups of 4 pairs.
 //   * the chunk's (in,out) row indices are staged in LDS once (coalesced);
-//   * operands are ONE float4 per lane per side: lane (i,q) loads channels
-//     4i..4i+3 of pair q's row, and the slab's 16x16 tiles are defined over the
-//     permuted channel order  tile a, row i <-> channel 4i+a  so element a of
-//     that float4 IS the lane's A operand of tile a (same for B): 2 x 16-byte
-//     loads (256 B contiguous per row) feed 16 MFMAs, no LDS for activations;
-//   * the next group's operands are fetched before the current MFMAs issue;
+//   * operands are ONE load of SA (SB) consecutive floats per lane per side:
+//     lane (i,q) loads channels SA*i .. SA*i+SA-1 of pair q's row, and the slab's
+//     16x16 tiles are defined over the permuted channel order
+//         tile a, row i  <->  channel SA*i + a
+//     so element a of that load IS the lane's A operand of tile a (same for B):
+//     for 64-channel sides (SA = 4) 2 x 16-byte loads (256 B contiguous per row)
+//     feed 16 MFMAs, no LDS for activations; narrow layers take SA/SB = 2 or 1
+//     (8-/4-byte loads) so no matrix work is spent on channels that do not exist;
+//   * the next groups' operands are fetched before the current MFMAs issue;
 //   * the 4 wave partials are summed through LDS in fixed order and written to
 //     a per-(k,chunk) partial; a second kernel reduces the partials in fixed
 //     order (deterministic, no float atomics).
-constexpr int kWgChunk = 2048;  // pairs per workgroup
-constexpr int kSlab = 4;        // 16-channel tiles per slab side (64 channels)
+// CHUNK: 2048 pairs for the wide layers; 512 for the narrow ones, whose
+// full-resolution voxel sets have few pairs per offset (a 2048-pair chunking
+// left half the CUs without a workgroup).
+template <int S>
+struct VecOf;
+template <>
+struct VecOf<1> { typedef float type; };
+template <>
+struct VecOf<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <>
+struct VecOf<4> { typedef float type __attribute__((ext_vector_type(4))); };
 
-template <bool VEC>  // VEC: c_in % 4 == 0 && c_out % 4 == 0
+template <int S, bool VEC>
+__device__ __forceinline__ void load_side(const float* row, int c0, int c, float (&v)[S]) {
+  if (VEC) {
+    if (c0 < c) {
+      const typename VecOf<S>::type t = *(const typename VecOf<S>::type*)(row + c0);
+      if constexpr (S == 1) {
+        v[0] = t;
+      } else {
+#pragma unroll
+        for (int s = 0; s < S; ++s) v[s] = t[s];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      if (c0 + s < c) v[s] = row[c0 + s];
+  }
+}
+
+template <int SA, int SB, int CHUNK, bool VEC>  // VEC: c_in % SA == 0 && c_out % SB == 0
 __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
     const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
     float* __restrict__ partial /* [K][nchunks][cin][cout] */) {
-  // 32 KiB of LDS: the chunk's pair indices during the main loop, then the
-  // tree reduction of the four wave partials (5 workgroups per CU by LDS)
-  __shared__ __attribute__((aligned(16))) char lds_raw[2 * kSlab * kSlab * 64 * sizeof(f32x4)];
+  // LDS: the chunk's pair indices during the main loop, then the tree reduction
+  // of the four wave partials (aliased)
+  constexpr int kRedBytes = 2 * SA * SB * 64 * (int)sizeof(f32x4);
+  constexpr int kIdxBytes = 2 * CHUNK * (int)sizeof(int);
+  __shared__ __attribute__((aligned(16))) char lds_raw[kRedBytes > kIdxBytes ? kRedBytes : kIdxBytes];
   int* s_in = (int*)lds_raw;
-  int* s_out = s_in + kWgChunk;
+  int* s_out = s_in + CHUNK;
   f32x4* red = (f32x4*)lds_raw;
-  static_assert(2 * kWgChunk * sizeof(int) <= sizeof(lds_raw), "index arrays must fit");
   const int k = blockIdx.y, chunk = blockIdx.x;
   const int P = num[k];
-  const int p_begin = chunk * kWgChunk;
+  const int p_begin = chunk * CHUNK;
   if (p_begin >= P) return;
-  const int cnt = (P - p_begin) < kWgChunk ? (P - p_begin) : kWgChunk;
-  const int NTs = (cout + 16 * kSlab - 1) / (16 * kSlab);  // slabs along c_out
+  const int cnt = (P - p_begin) < CHUNK ? (P - p_begin) : CHUNK;
+  const int NTs = (cout + 16 * SB - 1) / (16 * SB);  // slabs along c_out
   const int sa = blockIdx.z / NTs, sb = blockIdx.z % NTs;
-  const int a0 = sa * kSlab * 16, b0 = sb * kSlab * 16;   // first channel of the slab
+  const int a0 = sa * SA * 16, b0 = sb * SB * 16;   // first channel of the slab
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   {
@@ -534,48 +566,44 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
   }
   __syncthreads();
 
-  f32x4 acc[kSlab][kSlab];
+  f32x4 acc[SA][SB];
 #pragma unroll
-  for (int a = 0; a < kSlab; ++a)
+  for (int a = 0; a < SA; ++a)
 #pragma unroll
-    for (int b = 0; b < kSlab; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < SB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int ca = a0 + 4 * i, cb = b0 + 4 * i;  // this lane's 4 channels on each side
-  auto fetch = [&](int e, f32x4& av, f32x4& bv) {
-    av = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (e < cnt) {
-      const float* pa = in + (size_t)s_in[e] * cin + ca;
-      const float* pb = dout + (size_t)s_out[e] * cout + cb;
-      if (VEC) {
-        if (ca < cin) av = *(const f32x4*)pa;
-        if (cb < cout) bv = *(const f32x4*)pb;
-      } else {
+  const int ca = a0 + SA * i, cb = b0 + SB * i;  // this lane's channels on each side
+  auto fetch = [&](int e, float (&av)[SA], float (&bv)[SB]) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          if (ca + s < cin) av[s] = pa[s];
-          if (cb + s < cout) bv[s] = pb[s];
-        }
-      }
+    for (int s = 0; s < SA; ++s) av[s] = 0.f;
+#pragma unroll
+    for (int s = 0; s < SB; ++s) bv[s] = 0.f;
+    if (e < cnt) {
+      load_side<SA, VEC>(in + (size_t)s_in[e] * cin, ca, cin, av);
+      load_side<SB, VEC>(dout + (size_t)s_out[e] * cout, cb, cout, bv);
     }
   };
   // wave w takes pair groups w, w+4, ...; a group = 4 consecutive pairs (q).
-  // Row gathers come from L2/MALL (~2 us under load) while a group is only 16
+  // Row gathers come from L2/MALL (~2 us under load) while a group is at most 16
   // MFMAs (512 cycles): keep kDepth groups in flight in a register ring.
   constexpr int kDepth = 8;
-  f32x4 ra[kDepth], rb[kDepth];
+  float ra[kDepth][SA], rb[kDepth][SB];
   int e = 4 * wave + q;
 #pragma unroll
   for (int d = 0; d < kDepth; ++d) fetch(e + 16 * d, ra[d], rb[d]);
   for (int g = 4 * wave; g < cnt; g += 16 * kDepth) {
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) {
-      const f32x4 av = ra[d], bv = rb[d];
+      float av[SA], bv[SB];
+#pragma unroll
+      for (int s = 0; s < SA; ++s) av[s] = ra[d][s];
+#pragma unroll
+      for (int s = 0; s < SB; ++s) bv[s] = rb[d][s];
       fetch(e + 16 * (d + kDepth), ra[d], rb[d]);
 #pragma unroll
-      for (int a = 0; a < kSlab; ++a)
+      for (int a = 0; a < SA; ++a)
 #pragma unroll
-        for (int b = 0; b < kSlab; ++b)
+        for (int b = 0; b < SB; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
     e += 16 * kDepth;
@@ -584,48 +612,55 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
   __syncthreads();   // everyone is done with the index arrays (red aliases them)
   if (wave >= 2) {
 #pragma unroll
-    for (int a = 0; a < kSlab; ++a)
+    for (int a = 0; a < SA; ++a)
 #pragma unroll
-      for (int b = 0; b < kSlab; ++b)
-        red[((wave - 2) * kSlab * kSlab + a * kSlab + b) * 64 + lane] = acc[a][b];
+      for (int b = 0; b < SB; ++b)
+        red[((wave - 2) * SA * SB + a * SB + b) * 64 + lane] = acc[a][b];
   }
   __syncthreads();
   if (wave < 2) {
 #pragma unroll
-    for (int a = 0; a < kSlab; ++a)
+    for (int a = 0; a < SA; ++a)
 #pragma unroll
-      for (int b = 0; b < kSlab; ++b)
-        acc[a][b] += red[(wave * kSlab * kSlab + a * kSlab + b) * 64 + lane];
+      for (int b = 0; b < SB; ++b)
+        acc[a][b] += red[(wave * SA * SB + a * SB + b) * 64 + lane];
   }
   __syncthreads();
   if (wave == 1) {
 #pragma unroll
-    for (int a = 0; a < kSlab; ++a)
+    for (int a = 0; a < SA; ++a)
 #pragma unroll
-      for (int b = 0; b < kSlab; ++b) red[(a * kSlab + b) * 64 + lane] = acc[a][b];
+      for (int b = 0; b < SB; ++b) red[(a * SB + b) * 64 + lane] = acc[a][b];
   }
   __syncthreads();
   if (wave == 0) {
     float* dst = partial + ((size_t)k * nchunks + chunk) * cin * cout;
 #pragma unroll
-    for (int a = 0; a < kSlab; ++a) {
-      f32x4 v[kSlab];
+    for (int a = 0; a < SA; ++a) {
+      f32x4 v[SB];
 #pragma unroll
-      for (int b = 0; b < kSlab; ++b) {
-        v[b] = acc[a][b] + red[(a * kSlab + b) * 64 + lane];
-      }
-      // D of tile (a,b): lane (col j = i, q) reg r  ->  ci = a0 + 4(4q+r) + a,
-      // co = b0 + 4j + b : the four b-tiles give 4 consecutive co -> one 16-B store
+      for (int b = 0; b < SB; ++b) v[b] = acc[a][b] + red[(a * SB + b) * 64 + lane];
+      // D of tile (a,b): lane (col j = i, q) reg r  ->  ci = a0 + SA(4q+r) + a,
+      // co = b0 + SB j + b : the SB b-tiles give SB consecutive co -> one store
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ci = a0 + 4 * (4 * q + r) + a;
+        const int ci = a0 + SA * (4 * q + r) + a;
         if (ci >= cin) continue;
         float* o = dst + (size_t)ci * cout + cb;
         if (VEC) {
-          if (cb < cout) *(f32x4*)o = (f32x4){v[0][r], v[1][r], v[2][r], v[3][r]};
+          if (cb < cout) {
+            typename VecOf<SB>::type t;
+            if constexpr (SB == 1) {
+              t = v[0][r];
+            } else {
+#pragma unroll
+              for (int b = 0; b < SB; ++b) t[b] = v[b][r];
+            }
+            *(typename VecOf<SB>::type*)o = t;
+          }
         } else {
 #pragma unroll
-          for (int b = 0; b < kSlab; ++b)
+          for (int b = 0; b < SB; ++b)
             if (cb + b < cout) o[b] = v[b][r];
         }
       }
@@ -633,14 +668,20 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
   }
 }
 
+// Tiles per slab side for a channel count: 64-channel slabs for the wide layers,
+// 32 / 16 for the narrow ones.
+inline int wgrad_side(int c) { return c > 32 ? 4 : (c > 16 ? 2 : 1); }
+inline int wgrad_chunk(int cin, int cout) { return cin * cout <= 32 * 64 ? 512 : 2048; }
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const int32_t* __restrict__ num,
                                                            int nchunks, int per_k, int cin,
                                                            int cout, int kvol, int krsc,
+                                                           int chunk_pairs,
                                                            float* __restrict__ dw) {
   const int k = blockIdx.y;
   const int P = num[k];
-  const int used = (P + kWgChunk - 1) / kWgChunk;
+  const int used = (P + chunk_pairs - 1) / chunk_pairs;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < per_k; e += gridDim.x * 256) {
     float s = 0.f;
     for (int c = 0; c < used; ++c) s += partial[((size_t)k * nchunks + c) * per_k + e];
@@ -721,9 +762,28 @@ MSMD_EXPORT int msmd_spconv_fwd_f32(const float* in_feat, int n_in, int c_in,
 
 MSMD_EXPORT size_t msmd_spconv_wgrad_workspace_bytes(int kernel_volume, int ld, int c_in,
                                                      int c_out) {
-  size_t nchunks = (size_t)ceil_div(ld > 0 ? ld : 1, kWgChunk);
+  size_t nchunks = (size_t)ceil_div(ld > 0 ? ld : 1, wgrad_chunk(c_in, c_out));
   return align_up(sizeof(float) * kernel_volume * nchunks * c_in * c_out);
 }
+
+namespace {
+template <int SA, int SB>
+void launch_wgrad(int chunk, dim3 grid, hipStream_t st, const float* in_feat, int c_in,
+                  const float* d_out, int c_out, const int32_t* pairs, const int32_t* num, int ld,
+                  int nchunks, float* ws) {
+  // vector loads need every row 4*S-byte aligned on both sides
+  const bool vec = c_in % SA == 0 && c_out % SB == 0;
+#define MSMD_GOW(C_, V_)                                                                      \
+  MSMD_LAUNCH((spconv_wgrad_kernel<SA, SB, C_, V_>), grid, dim3(256), 0, st, in_feat, c_in,   \
+              d_out, c_out, pairs, num, ld, nchunks, ws)
+  if (chunk == 512) {
+    if (vec) MSMD_GOW(512, true); else MSMD_GOW(512, false);
+  } else {
+    if (vec) MSMD_GOW(2048, true); else MSMD_GOW(2048, false);
+  }
+#undef MSMD_GOW
+}
+}  // namespace
 
 MSMD_EXPORT int msmd_spconv_wgrad_f32(const float* in_feat, int c_in, const float* d_out,
                                       int c_out, const int32_t* indice_pairs,
@@ -739,23 +799,24 @@ MSMD_EXPORT int msmd_spconv_wgrad_f32(const float* in_feat, int c_in, const floa
     return launch_status();
   }
   if (!in_feat || !d_out || !indice_pairs) return MSMD_ERR_INVALID_ARG;
-  const int nchunks = ceil_div(ld, kWgChunk);
+  const int chunk = wgrad_chunk(c_in, c_out);
+  const int nchunks = ceil_div(ld, chunk);
   if (workspace_bytes < sizeof(float) * (size_t)kernel_volume * nchunks * per_k ||
       ((uintptr_t)workspace & 255))
     return MSMD_ERR_WORKSPACE;
-  const int slabs = ceil_div(c_in, 16 * kSlab) * ceil_div(c_out, 16 * kSlab);
-  if ((c_in & 3) == 0 && (c_out & 3) == 0)
-    MSMD_LAUNCH(spconv_wgrad_kernel<true>, dim3(nchunks, kernel_volume, slabs), dim3(256), 0, st,
-                in_feat, c_in, d_out, c_out, indice_pairs, indice_num, ld, nchunks,
-                (float*)workspace);
-  else
-    MSMD_LAUNCH(spconv_wgrad_kernel<false>, dim3(nchunks, kernel_volume, slabs), dim3(256), 0, st,
-                in_feat, c_in, d_out, c_out, indice_pairs, indice_num, ld, nchunks,
-                (float*)workspace);
+  const int SA = wgrad_side(c_in), SB = wgrad_side(c_out);
+  const dim3 grid(nchunks, kernel_volume, ceil_div(c_in, 16 * SA) * ceil_div(c_out, 16 * SB));
+#define MSMD_WG(A_, B_)                                                                        \
+  if (SA == A_ && SB == B_)                                                                    \
+    launch_wgrad<A_, B_>(chunk, grid, st, in_feat, c_in, d_out, c_out, indice_pairs,           \
+                         indice_num, ld, nchunks, (float*)workspace);
+  MSMD_WG(1, 1) MSMD_WG(1, 2) MSMD_WG(1, 4) MSMD_WG(2, 1) MSMD_WG(2, 2) MSMD_WG(2, 4)
+  MSMD_WG(4, 1) MSMD_WG(4, 2) MSMD_WG(4, 4)
+#undef MSMD_WG
   int rb = ceil_div(per_k, 256);
   if (rb > 64) rb = 64;
   MSMD_LAUNCH(wgrad_reduce_kernel, dim3(rb, kernel_volume), dim3(256), 0, st,
               (const float*)workspace, indice_num, nchunks, per_k, c_in, c_out, kernel_volume,
-              krsc_out, d_weight);
+              krsc_out, chunk, d_weight);
   return launch_status();
 }
