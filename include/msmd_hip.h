@@ -181,8 +181,10 @@ int msmd_spconv_fwd_f32(const float* in_feat /* [n_in,c_in] */, int n_in,
                         float* out_feat /* [n_out,c_out] */, int c_out,
                         msmd_stream_t stream);
 /* tile_counter != NULL selects the persistent form: a fixed number of resident
- * workgroups draw row tiles from *tile_counter (zeroed by the call) -- with a
- * heaviest-first row_order this balances the very uneven per-tile cost. */
+ * workgroups draw row tiles from *tile_counter -- with a heaviest-first
+ * row_order this balances the very uneven per-tile cost.  *tile_counter must
+ * be 0 on entry; the kernel's last draw puts it back to 0, so one zeroed word
+ * per stream serves every launch (no memset between launches). */
 
 /* ---- the same convolution at bf16 MFMA rate, fp32-equivalent results -------
  * Every fp32 operand is the exact sum of three bf16 values (h + m + l); six

@@ -90,7 +90,15 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
   // simply draw more (a static grid left the MFMA pipes idle ~45 % of the time
   // on the 128-channel layers because tile cost varies 3x with the mask).
   for (;;) {
-    if (threadIdx.x == 0) s_tile = tile_counter ? atomicAdd(tile_counter, 1) : (int)blockIdx.x;
+    if (threadIdx.x == 0) {
+      int t = (int)blockIdx.x;
+      if (tile_counter) {
+        t = atomicAdd(tile_counter, 1);
+        // n_tiles + gridDim.x draws in total: the last one re-arms the counter
+        if (t == n_tiles + (int)gridDim.x - 1) *tile_counter = 0;
+      }
+      s_tile = t;
+    }
     __syncthreads();
     const int tile = s_tile;
     if (tile >= n_tiles) break;
@@ -259,7 +267,15 @@ __global__ __launch_bounds__(256) void spconv_fwd_pipe_kernel(
   const size_t chunk_f4 = (size_t)kWF4;          // packed weights: [k][chunk][kWF4]
 
   for (;;) {
-    if (tid == 0) sctl[0] = tile_counter ? atomicAdd(tile_counter, 1) : (int)blockIdx.x;
+    if (tid == 0) {
+      int t = (int)blockIdx.x;
+      if (tile_counter) {
+        t = atomicAdd(tile_counter, 1);
+        // n_tiles + gridDim.x draws in total: the last one re-arms the counter
+        if (t == n_tiles + (int)gridDim.x - 1) *tile_counter = 0;
+      }
+      sctl[0] = t;
+    }
     if (tid < kMaxK) act[tid] = 0;
     __syncthreads();
     const int tile = sctl[0];
@@ -402,7 +418,6 @@ int launch_fwd_pipe(const float* in, int cin, const float* wp, const int32_t* nb
   const int n_tiles = ceil_div(n_out, kRows);
   int nblk = n_tiles;
   if (tile_counter) {
-    hipMemsetAsync(tile_counter, 0, sizeof(int), st);
     const int slots = 256 * fwd_slots_per_cu();
     if (nblk > slots) nblk = slots;
   }
@@ -452,7 +467,6 @@ int launch_fwd(const float* in, int cin, const float* wp, const int32_t* nbr, in
   const int n_tiles = ceil_div(n_out, rows_per_block);
   int nblk = n_tiles;
   if (tile_counter) {
-    hipMemsetAsync(tile_counter, 0, sizeof(int), st);
     const int slots = 256 * fwd_slots_per_cu();
     if (nblk > slots) nblk = slots;
   }
@@ -502,9 +516,15 @@ __global__ __launch_bounds__(256) void row_mask_kernel(const int32_t* __restrict
 //   * the 4 wave partials are summed through LDS in fixed order and written to
 //     a per-(k,chunk) partial; a second kernel reduces the partials in fixed
 //     order (deterministic, no float atomics).
-// CHUNK: 2048 pairs for the wide layers; 512 for the narrow ones, whose
+// CHUNK: 2048 pairs for the wide layers, 1024 / 512 for the narrow ones, whose
 // full-resolution voxel sets have few pairs per offset (a 2048-pair chunking
 // left half the CUs without a workgroup).
+// Pairs per workgroup for an offset with `pairs` pairs.  (Doubling the chunk for
+// pair-rich offsets halves the partials of the second pass but was measured
+// slower overall: 558 us against 516 us on the 128x128 layers -- fewer, longer
+// workgroups leave a longer tail.)
+__host__ __device__ inline int wgrad_span(int pairs, int chunk) { return chunk; }
+
 template <int S>
 struct VecOf;
 template <>
@@ -513,6 +533,7 @@ template <>
 struct VecOf<2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <>
 struct VecOf<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
 
 template <int S, bool VEC>
 __device__ __forceinline__ void load_side(const float* row, int c0, int c, float (&v)[S]) {
@@ -533,7 +554,11 @@ __device__ __forceinline__ void load_side(const float* row, int c0, int c, float
   }
 }
 
-template <int SA, int SB, int CHUNK, bool VEC>  // VEC: c_in % SA == 0 && c_out % SB == 0
+// WPS = waves per slab: 4 -- the workgroup owns one slab, its waves split the
+// pairs; 2 / 1 -- it owns 2 / 4 slabs (same c_in rows first), every pair group is
+// multiplied by 2 / 4 waves into different slabs: the second wave's gather of a
+// row hits L1, so the L2 traffic of a 128x128 layer halves.
+template <int SA, int SB, int CHUNK, bool VEC, int WPS>  // VEC: c_in % SA == 0 && c_out % SB == 0
 __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
     const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
@@ -541,20 +566,22 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
   // LDS: the chunk's pair indices during the main loop, then the tree reduction
   // of the four wave partials (aliased)
   constexpr int kRedBytes = 2 * SA * SB * 64 * (int)sizeof(f32x4);
-  constexpr int kIdxBytes = 2 * CHUNK * (int)sizeof(int);
+  constexpr int kIdxBytes = 2 * (2 * CHUNK) * (int)sizeof(int);   // chunks may be doubled
   __shared__ __attribute__((aligned(16))) char lds_raw[kRedBytes > kIdxBytes ? kRedBytes : kIdxBytes];
   int* s_in = (int*)lds_raw;
-  int* s_out = s_in + CHUNK;
+  int* s_out = s_in + 2 * CHUNK;
   f32x4* red = (f32x4*)lds_raw;
   const int k = blockIdx.y, chunk = blockIdx.x;
   const int P = num[k];
-  const int p_begin = chunk * CHUNK;
+  const int span = wgrad_span(P, CHUNK);   // pairs per workgroup for this offset
+  const int p_begin = chunk * span;
   if (p_begin >= P) return;
-  const int cnt = (P - p_begin) < CHUNK ? (P - p_begin) : CHUNK;
+  const int cnt = (P - p_begin) < span ? (P - p_begin) : span;
   const int NTs = (cout + 16 * SB - 1) / (16 * SB);  // slabs along c_out
-  const int sa = blockIdx.z / NTs, sb = blockIdx.z % NTs;
-  const int a0 = sa * SA * 16, b0 = sb * SB * 16;   // first channel of the slab
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slab = blockIdx.z * (4 / WPS) + wave / WPS, rank = wave % WPS;
+  const int sa = slab / NTs, sb = slab % NTs;
+  const int a0 = sa * SA * 16, b0 = sb * SB * 16;   // first channel of the slab
   const int i = lane & 15, q = lane >> 4;
   {
     const int32_t* pin = pairs + ((size_t)k * 2 + 0) * ld + p_begin;
@@ -583,15 +610,17 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
       load_side<SB, VEC>(dout + (size_t)s_out[e] * cout, cb, cout, bv);
     }
   };
-  // wave w takes pair groups w, w+4, ...; a group = 4 consecutive pairs (q).
+  // the WPS waves of a slab take pair groups rank, rank+WPS, ...; a group = 4
+  // consecutive pairs (q).
   // Row gathers come from L2/MALL (~2 us under load) while a group is at most 16
   // MFMAs (512 cycles): keep kDepth groups in flight in a register ring.
-  constexpr int kDepth = 8;
+  constexpr int kDepth = SA * SB >= 32 ? 4 : 8;   // (same MFMA time in flight either way)
   float ra[kDepth][SA], rb[kDepth][SB];
-  int e = 4 * wave + q;
+  constexpr int kStep = 4 * WPS;   // pairs between a wave's consecutive groups
+  int e = 4 * rank + q;
 #pragma unroll
-  for (int d = 0; d < kDepth; ++d) fetch(e + 16 * d, ra[d], rb[d]);
-  for (int g = 4 * wave; g < cnt; g += 16 * kDepth) {
+  for (int d = 0; d < kDepth; ++d) fetch(e + kStep * d, ra[d], rb[d]);
+  for (int g = 4 * rank; g < cnt; g += kStep * kDepth) {
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) {
       float av[SA], bv[SB];
@@ -599,47 +628,55 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
       for (int s = 0; s < SA; ++s) av[s] = ra[d][s];
 #pragma unroll
       for (int s = 0; s < SB; ++s) bv[s] = rb[d][s];
-      fetch(e + 16 * (d + kDepth), ra[d], rb[d]);
+      fetch(e + kStep * (d + kDepth), ra[d], rb[d]);
 #pragma unroll
       for (int a = 0; a < SA; ++a)
 #pragma unroll
         for (int b = 0; b < SB; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
-    e += 16 * kDepth;
+    e += kStep * kDepth;
   }
-  // cross-wave sum, fixed tree order (w0+w2) + (w1+w3): deterministic
+  // cross-wave sum within a slab, fixed order: deterministic
   __syncthreads();   // everyone is done with the index arrays (red aliases them)
-  if (wave >= 2) {
+  if (WPS == 4) {    // (w0+w2) + (w1+w3)
+    if (wave >= 2) {
 #pragma unroll
-    for (int a = 0; a < SA; ++a)
+      for (int a = 0; a < SA; ++a)
 #pragma unroll
-      for (int b = 0; b < SB; ++b)
-        red[((wave - 2) * SA * SB + a * SB + b) * 64 + lane] = acc[a][b];
+        for (int b = 0; b < SB; ++b)
+          red[((wave - 2) * SA * SB + a * SB + b) * 64 + lane] = acc[a][b];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+      for (int a = 0; a < SA; ++a)
+#pragma unroll
+        for (int b = 0; b < SB; ++b)
+          acc[a][b] += red[(wave * SA * SB + a * SB + b) * 64 + lane];
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (wave < 2) {
+  if (WPS >= 2) {    // odd wave of each slab -> its even wave
+    if (rank == 1) {
 #pragma unroll
-    for (int a = 0; a < SA; ++a)
+      for (int a = 0; a < SA; ++a)
 #pragma unroll
-      for (int b = 0; b < SB; ++b)
-        acc[a][b] += red[(wave * SA * SB + a * SB + b) * 64 + lane];
+        for (int b = 0; b < SB; ++b)
+          red[((wave / WPS) * SA * SB + a * SB + b) * 64 + lane] = acc[a][b];
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (wave == 1) {
-#pragma unroll
-    for (int a = 0; a < SA; ++a)
-#pragma unroll
-      for (int b = 0; b < SB; ++b) red[(a * SB + b) * 64 + lane] = acc[a][b];
-  }
-  __syncthreads();
-  if (wave == 0) {
+  if (rank == 0) {
     float* dst = partial + ((size_t)k * nchunks + chunk) * cin * cout;
 #pragma unroll
     for (int a = 0; a < SA; ++a) {
       f32x4 v[SB];
 #pragma unroll
-      for (int b = 0; b < SB; ++b) v[b] = acc[a][b] + red[(a * SB + b) * 64 + lane];
+      for (int b = 0; b < SB; ++b) {
+        v[b] = acc[a][b];
+        if (WPS >= 2) v[b] += red[((wave / WPS) * SA * SB + a * SB + b) * 64 + lane];
+      }
       // D of tile (a,b): lane (col j = i, q) reg r  ->  ci = a0 + SA(4q+r) + a,
       // co = b0 + SB j + b : the SB b-tiles give SB consecutive co -> one store
 #pragma unroll
@@ -671,7 +708,12 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
 // Tiles per slab side for a channel count: 64-channel slabs for the wide layers,
 // 32 / 16 for the narrow ones.
 inline int wgrad_side(int c) { return c > 32 ? 4 : (c > 16 ? 2 : 1); }
-inline int wgrad_chunk(int cin, int cout) { return cin * cout <= 32 * 64 ? 512 : 2048; }
+// (128-channel slabs on the c_in side -- each dout row gathered half as often --
+// need 288 registers per lane: one wave per SIMD, 714 us against 516 us.)
+inline int wgrad_side_a(int c) { return wgrad_side(c); }
+inline int wgrad_chunk(int cin, int cout) {
+  return cin * cout <= 16 * 32 ? 512 : (cin * cout <= 32 * 64 ? 1024 : 2048);
+}
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                            const int32_t* __restrict__ num,
@@ -681,7 +723,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            float* __restrict__ dw) {
   const int k = blockIdx.y;
   const int P = num[k];
-  const int used = (P + chunk_pairs - 1) / chunk_pairs;
+  const int span = wgrad_span(P, chunk_pairs);
+  const int used = (P + span - 1) / span;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < per_k; e += gridDim.x * 256) {
     float s = 0.f;
     for (int c = 0; c < used; ++c) s += partial[((size_t)k * nchunks + c) * per_k + e];
@@ -773,14 +816,27 @@ void launch_wgrad(int chunk, dim3 grid, hipStream_t st, const float* in_feat, in
                   int nchunks, float* ws) {
   // vector loads need every row 4*S-byte aligned on both sides
   const bool vec = c_in % SA == 0 && c_out % SB == 0;
-#define MSMD_GOW(C_, V_)                                                                      \
-  MSMD_LAUNCH((spconv_wgrad_kernel<SA, SB, C_, V_>), grid, dim3(256), 0, st, in_feat, c_in,   \
-              d_out, c_out, pairs, num, ld, nchunks, ws)
+  // slabs per workgroup: 4 when the slab grid allows it (and 2x2 of them share
+  // rows), else 2 along c_out, else 1
+  // (measured on the 128x128 layers: 4 slabs per workgroup = 4x longer, 4x fewer
+  // workgroups -- 671 us against 516 us for one slab each; kept for experiments)
+  const int n_slabs = (int)grid.z, nb = ceil_div(c_out, 16 * SB);
+  static const int multi = env_int("MSMD_WGRAD_MULTISLAB", 0);
+  const int spw = !multi ? 1 : ((n_slabs % 4 == 0 && nb % 2 == 0) ? 4 : (nb % 2 == 0 ? 2 : 1));
+  grid.z = n_slabs / spw;
+#define MSMD_GOW(C_, V_, W_)                                                                  \
+  MSMD_LAUNCH((spconv_wgrad_kernel<SA, SB, C_, V_, W_>), grid, dim3(256), 0, st, in_feat,     \
+              c_in, d_out, c_out, pairs, num, ld, nchunks, ws)
+#define MSMD_GOV(C_, W_)                                                                      \
+  if (vec) MSMD_GOW(C_, true, W_); else MSMD_GOW(C_, false, W_)
   if (chunk == 512) {
-    if (vec) MSMD_GOW(512, true); else MSMD_GOW(512, false);
+    if (spw == 4) { MSMD_GOV(512, 1); } else if (spw == 2) { MSMD_GOV(512, 2); } else { MSMD_GOV(512, 4); }
+  } else if (chunk == 1024) {
+    if (spw == 4) { MSMD_GOV(1024, 1); } else if (spw == 2) { MSMD_GOV(1024, 2); } else { MSMD_GOV(1024, 4); }
   } else {
-    if (vec) MSMD_GOW(2048, true); else MSMD_GOW(2048, false);
+    if (spw == 4) { MSMD_GOV(2048, 1); } else if (spw == 2) { MSMD_GOV(2048, 2); } else { MSMD_GOV(2048, 4); }
   }
+#undef MSMD_GOV
 #undef MSMD_GOW
 }
 }  // namespace
@@ -804,7 +860,7 @@ MSMD_EXPORT int msmd_spconv_wgrad_f32(const float* in_feat, int c_in, const floa
   if (workspace_bytes < sizeof(float) * (size_t)kernel_volume * nchunks * per_k ||
       ((uintptr_t)workspace & 255))
     return MSMD_ERR_WORKSPACE;
-  const int SA = wgrad_side(c_in), SB = wgrad_side(c_out);
+  const int SA = wgrad_side_a(c_in), SB = wgrad_side(c_out);
   const dim3 grid(nchunks, kernel_volume, ceil_div(c_in, 16 * SA) * ceil_div(c_out, 16 * SB));
 #define MSMD_WG(A_, B_)                                                                        \
   if (SA == A_ && SB == B_)                                                                    \

@@ -244,6 +244,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
   const int j = lane & 15, q = lane >> 4;
   const int kbt = cin >> 5;
   const int n_tiles = (n_out + kRows - 1) / kRows;
+  // every workgroup draws 1 + (tiles it processed) tickets: the draw that returns
+  // this value is the last one of the launch and puts the counter back to 0
+  const int last_ticket = n_tiles + (int)gridDim.x - 1;
   int lr[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) lr[r] = (wave * R + r) * 16 + j;
@@ -455,6 +458,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     if ((IT) == 1 && tid == 0) {                                                       \
       ctl[2] = nxt_v;                                                                  \
       ctl[tb ^ 1] = 0;                                                                 \
+      if (nxt_v == last_ticket) *tile_counter = 0;                                     \
     }                                                                                  \
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(UB * kGr) : "memory");         \
     __builtin_amdgcn_s_barrier();                                                      \
@@ -492,6 +496,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
       if (tid == 0) {
         ctl[2] = nxt_v;
         ctl[tb ^ 1] = 0;
+        if (nxt_v == last_ticket) *tile_counter = 0;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -521,7 +526,6 @@ int launch_fwd_split(const float* planes, int n_in, int cin, const void* wp, con
                       sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 8);
   const int n_tiles = ceil_div(n_out, kRows);
   int nblk = n_tiles;
-  hipMemsetAsync(tile_counter, 0, sizeof(int), st);
   const int slots = 256 * split_slots_per_cu();
   if (nblk > slots) nblk = slots;
   auto kern = spconv_fwd_split_kernel<NT, UB, NP>;

@@ -228,6 +228,19 @@ def row_mask_order(nbr):
     return torch.sort(keys, stable=False)[1].int()
 
 
+_TILE_COUNTERS = {}
+
+
+def _tile_counter(device):
+    """One zeroed int32 per (device, stream): the persistent conv kernels draw
+    tiles from it and leave it at 0 again (see msmd_spconv_fwd_f32)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    c = _TILE_COUNTERS.get(key)
+    if c is None:
+        c = _TILE_COUNTERS[key] = torch.zeros((1,), dtype=torch.int32, device=device)
+    return c
+
+
 def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False, row_order=None):
     """out[o] = sum_k feat[nbr[k,o]] @ W[k]  (implicit GEMM on MFMA)."""
     _need_cuda(feat, packed_weight, nbr)
@@ -236,8 +249,7 @@ def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False, row_
     kvol, ld = nbr.shape
     out = torch.empty((n_out, c_out), dtype=torch.float32, device=f.device)
     # persistent tile scheduler whenever a (heaviest-first) order is supplied
-    counter = torch.empty((1,), dtype=torch.int32, device=f.device) \
-        if row_order is not None else None
+    counter = _tile_counter(f.device) if row_order is not None else None
     ev = _prof_begin()
     check(lib.msmd_spconv_fwd_f32(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld, int(n_out),
                                   kvol, int(bool(weight_flip)), _p(row_order), _p(counter),
@@ -292,7 +304,7 @@ def conv_forward_split(feat, packed_weight, nbr, n_out, c_out, planes=3, weight_
     n_in, c_in = f.shape
     kvol, ld = nbr.shape
     out = torch.empty((n_out, c_out), dtype=torch.float32, device=f.device)
-    counter = torch.empty((1,), dtype=torch.int32, device=f.device)
+    counter = _tile_counter(f.device)
     ev = _prof_begin()
     check(lib.msmd_spconv_fwd_split(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld,
                                     int(n_out), kvol, int(bool(weight_flip)), _p(row_order),
