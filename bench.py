@@ -317,7 +317,8 @@ def roofline(prof):
                         else "spconv_fwd_kernel<NT=%d>") % nt
         else:
             pairs = int(meta["num"].sum().item())
-            name = "spconv_wgrad_kernel"
+            name = "spconv_wgrad_split_kernel" if kind == "spconv_wgrad_split" \
+                else "spconv_wgrad_kernel"
         g = groups.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
         g["ms"] += ms
         g["flops"] += 2.0 * pairs * meta["c_in"] * meta["c_out"]
@@ -327,7 +328,7 @@ def roofline(prof):
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
     traffic, mfma_busy = pmc_traffic(name)
     peak, peak_note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA (v_mfma_f32_16x16x4_f32)"
-    if name.startswith("spconv_fwd_split"):
+    if name.startswith("spconv_fwd_split") or name.startswith("spconv_wgrad_split"):
         from msmdfusion_amd.spconv.functional import conv_planes
         products = {3: 6, 2: 3, 1: 1}[conv_planes()]
         peak = round(PEAK_BF16_MFMA_TFLOPS / products, 1)
@@ -336,7 +337,9 @@ def roofline(prof):
                      % (PEAK_BF16_MFMA_TFLOPS, products, conv_planes()))
     return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3),
             "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
+            "frac": round(achieved / peak, 4),
+            "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": traffic,
             "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes "
                             "(profiles/r01_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, "
                             "gfx950 correction), not re-measured in this run",

@@ -214,6 +214,19 @@ int msmd_spconv_fwd_split(const float* in_feat /* [n_in,c_in] */, int n_in, int 
                           float* out_feat /* [n_out,c_out] */, int c_out, int planes,
                           msmd_stream_t stream);
 
+/* wgrad with the same operand splitting (both operands are read as fp32 and
+ * split in registers); c_in and c_out multiples of 64.  Workspace as
+ * msmd_spconv_wgrad_workspace_bytes. */
+int msmd_spconv_wgrad_split_supported(int c_in, int c_out);
+
+int msmd_spconv_wgrad_split(const float* in_feat, int c_in, const float* d_out, int c_out,
+                            const int32_t* indice_pairs /* [K,2,ld] */,
+                            const int32_t* indice_num /* [K] device */, int ld,
+                            int kernel_volume, int planes,
+                            float* d_weight /* [K,c_in,c_out] */,
+                            int krsc_out /* != 0: d_weight is [c_out,K,c_in] */,
+                            void* workspace, size_t workspace_bytes, msmd_stream_t stream);
+
 /* out[k][p] = nbr[k][order[p]] for p < n: the neighbour table in tile order. */
 int msmd_rulebook_permute_cols(const int32_t* nbr, int kernel_volume, int ld, int n,
                                const int32_t* order, int32_t* out /* [K,n] */,

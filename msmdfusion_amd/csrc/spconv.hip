@@ -876,3 +876,45 @@ MSMD_EXPORT int msmd_spconv_wgrad_f32(const float* in_feat, int c_in, const floa
               krsc_out, chunk, d_weight);
   return launch_status();
 }
+
+namespace msmd {
+int wgrad_split_partials(const float* in_feat, int c_in, const float* d_out, int c_out,
+                         const int32_t* pairs, const int32_t* num, int ld, int kvol, int np,
+                         int nchunks, float* ws, hipStream_t st);
+}
+
+MSMD_EXPORT int msmd_spconv_wgrad_split_supported(int c_in, int c_out) {
+  return c_in > 0 && c_out > 0 && c_in % 64 == 0 && c_out % 64 == 0;
+}
+
+MSMD_EXPORT int msmd_spconv_wgrad_split(const float* in_feat, int c_in, const float* d_out,
+                                        int c_out, const int32_t* indice_pairs,
+                                        const int32_t* indice_num, int ld, int kernel_volume,
+                                        int planes, float* d_weight, int krsc_out,
+                                        void* workspace, size_t workspace_bytes,
+                                        msmd_stream_t stream) {
+  if (!msmd_spconv_wgrad_split_supported(c_in, c_out) || planes < 1 || planes > 3)
+    return MSMD_ERR_UNSUPPORTED;
+  if (kernel_volume < 1 || ld < 0 || !d_weight || !indice_num) return MSMD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int per_k = c_in * c_out;
+  if (ld == 0) {
+    hipMemsetAsync(d_weight, 0, sizeof(float) * (size_t)kernel_volume * per_k, st);
+    return launch_status();
+  }
+  if (!in_feat || !d_out || !indice_pairs) return MSMD_ERR_INVALID_ARG;
+  const int chunk = 2048;   // = wgrad_chunk() for every supported shape
+  const int nchunks = ceil_div(ld, chunk);
+  if (workspace_bytes < sizeof(float) * (size_t)kernel_volume * nchunks * per_k ||
+      ((uintptr_t)workspace & 255))
+    return MSMD_ERR_WORKSPACE;
+  int rc = wgrad_split_partials(in_feat, c_in, d_out, c_out, indice_pairs, indice_num, ld,
+                                kernel_volume, planes, nchunks, (float*)workspace, st);
+  if (rc != MSMD_OK) return rc;
+  int rb = ceil_div(per_k, 256);
+  if (rb > 64) rb = 64;
+  MSMD_LAUNCH(wgrad_reduce_kernel, dim3(rb, kernel_volume), dim3(256), 0, st,
+              (const float*)workspace, indice_num, nchunks, per_k, c_in, c_out, kernel_volume,
+              krsc_out, chunk, d_weight);
+  return launch_status();
+}

@@ -568,6 +568,148 @@ __global__ __launch_bounds__(256) void permute_cols_kernel(const int32_t* __rest
   for (int k = 0; k < kvol; ++k) out[(size_t)k * n + p] = nbr[(size_t)k * ld + row];
 }
 
+// ------------------------------------------------------------------ wgrad --
+// dW[k] = sum_p in[i_p,:]^T (x) dout[o_p,:] with the pair index as the MFMA's
+// contraction (32 pairs per v_mfma_f32_16x16x32_bf16).  Same decomposition as
+// spconv_wgrad_kernel (spconv.hip): workgroup = (2048-pair chunk, offset k,
+// 64x64 channel slab), its 4 waves take interleaved 32-pair steps, partials are
+// reduced by wgrad_reduce in fixed order.
+//
+// Operands: lane (i, g) covers pairs 8g .. 8g+7 of the step and, on each side,
+// channels 4i .. 4i+3 of the slab: ONE 16-byte load per pair per side.  The
+// MFMA wants 8 consecutive contraction slots of ONE channel per lane -- i.e. the
+// 8x4 block the lane just loaded, transposed -- and v_cvt_pk_bf16_f32 takes its
+// two inputs from two registers: converting (pair 2t, pair 2t+1) of channel a
+// together yields dword t of tile a's operand directly (tile a, row i <->
+// channel 4i + a, as in the fp32 kernel).  The transposition is free; the split
+// into planes costs 9 VALU ops per operand dword.
+template <int NP>
+__global__ __launch_bounds__(256, 2) void spconv_wgrad_split_kernel(
+    const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
+    const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
+    float* __restrict__ partial /* [K][nchunks][cin][cout] */) {
+  constexpr int CHUNK = 2048, S = 4;
+  using P = Products<NP>;
+  __shared__ __attribute__((aligned(16))) char lds_raw[2 * S * S * 64 * sizeof(f32x4)];
+  int* s_in = (int*)lds_raw;
+  int* s_out = s_in + CHUNK;
+  f32x4* red = (f32x4*)lds_raw;
+  static_assert(2 * CHUNK * sizeof(int) <= sizeof(lds_raw), "index arrays must fit");
+  const int k = blockIdx.y, chunk = blockIdx.x;
+  const int Pk = num[k];
+  const int p_begin = chunk * CHUNK;
+  if (p_begin >= Pk) return;
+  const int cnt = (Pk - p_begin) < CHUNK ? (Pk - p_begin) : CHUNK;
+  const int NTs = cout / 64;
+  const int sa = blockIdx.z / NTs, sb = blockIdx.z % NTs;
+  const int a0 = sa * 64, b0 = sb * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  {
+    const int32_t* pin = pairs + ((size_t)k * 2 + 0) * ld + p_begin;
+    const int32_t* pout = pairs + ((size_t)k * 2 + 1) * ld + p_begin;
+    for (int e = threadIdx.x; e < CHUNK; e += 256) {   // pad with -1: "no pair"
+      s_in[e] = e < cnt ? pin[e] : -1;
+      s_out[e] = e < cnt ? pout[e] : -1;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[S][S];
+#pragma unroll
+  for (int a = 0; a < S; ++a)
+#pragma unroll
+    for (int b = 0; b < S; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float* pa = in + a0 + 4 * i;
+  const float* pb = dout + b0 + 4 * i;
+  f32x4 ra[8], rb[8];   // this lane's 8 pairs x 4 channels, both sides
+  auto fetch = [&](int step) {
+    const int e0 = 32 * step + 8 * g;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const i32x4 ia = *(const i32x4*)(s_in + e0 + 4 * h), ib = *(const i32x4*)(s_out + e0 + 4 * h);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        ra[4 * h + s] = ia[s] >= 0 ? *(const f32x4*)(pa + (size_t)ia[s] * cin)
+                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
+        rb[4 * h + s] = ib[s] >= 0 ? *(const f32x4*)(pb + (size_t)ib[s] * cout)
+                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  // raw [8 pairs][4 channels] -> op[tile = channel][plane] (8 slots each)
+  auto split_side = [&](const f32x4 (&r)[8], u32x4 (&op)[S][NP]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int a = 0; a < S; ++a) {
+        const f32x4 lo4 = r[2 * t], hi4 = r[2 * t + 1];
+        f32x2 v = {lo4[a], hi4[a]};
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+          const bf16x2 hi = __builtin_convertvector(v, bf16x2);
+          op[a][pl][t] = __builtin_bit_cast(unsigned int, hi);
+          if (pl + 1 < NP) v = v - __builtin_convertvector(hi, f32x2);   // exact
+        }
+      }
+  };
+  const int n_steps = (cnt + 31) / 32;
+  if (wave < n_steps) fetch(wave);
+  for (int step = wave; step < n_steps; step += 4) {
+    u32x4 oa[S][NP], ob[S][NP];
+    split_side(ra, oa);
+    split_side(rb, ob);
+    if (step + 4 < n_steps) fetch(step + 4);   // in flight under the MFMAs below
+#pragma unroll
+    for (int t = 0; t < P::n; ++t)
+#pragma unroll
+      for (int a = 0; a < S; ++a)
+#pragma unroll
+        for (int b = 0; b < S; ++b)
+          acc[a][b] = mfma_bf16(oa[a][P::a[t]], ob[b][P::b[t]], acc[a][b]);
+  }
+  // cross-wave sum, fixed tree order (w0+w2) + (w1+w3): deterministic
+  __syncthreads();   // everyone is done with the index arrays (red aliases them)
+  if (wave >= 2) {
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+      for (int b = 0; b < S; ++b) red[((wave - 2) * S * S + a * S + b) * 64 + lane] = acc[a][b];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+      for (int b = 0; b < S; ++b) acc[a][b] += red[(wave * S * S + a * S + b) * 64 + lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+      for (int b = 0; b < S; ++b) red[(a * S + b) * 64 + lane] = acc[a][b];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* dst = partial + ((size_t)k * nchunks + chunk) * cin * cout;
+    const int cb = b0 + 4 * i;
+#pragma unroll
+    for (int a = 0; a < S; ++a) {
+      f32x4 v[S];
+#pragma unroll
+      for (int b = 0; b < S; ++b) v[b] = acc[a][b] + red[(a * S + b) * 64 + lane];
+      // D of tile (a,b): lane (col n = i, g) reg r -> ci = a0 + 4(4g+r) + a, co = b0 + 4n + b
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = a0 + 4 * (4 * g + r) + a;
+        *(f32x4*)(dst + (size_t)ci * cout + cb) = (f32x4){v[0][r], v[1][r], v[2][r], v[3][r]};
+      }
+    }
+  }
+}
+
 }  // namespace
 }  // namespace msmd
 
@@ -635,3 +777,25 @@ MSMD_EXPORT int msmd_rulebook_permute_cols(const int32_t* nbr, int kvol, int ld,
               order, out);
   return launch_status();
 }
+
+// wgrad at bf16 MFMA rate (64x64 slabs: c_in and c_out multiples of 64).  Writes
+// the per-(k, chunk) partials in msmd_spconv_wgrad_f32's workspace layout; the
+// caller finishes with that entry point's reduction (see msmd_spconv_wgrad_split
+// in spconv.hip).
+namespace msmd {
+int wgrad_split_partials(const float* in_feat, int c_in, const float* d_out, int c_out,
+                         const int32_t* pairs, const int32_t* num, int ld, int kvol, int np,
+                         int nchunks, float* ws, hipStream_t st) {
+  const dim3 grid(nchunks, kvol, (c_in / 64) * (c_out / 64));
+  if (np == 3)
+    MSMD_LAUNCH(spconv_wgrad_split_kernel<3>, grid, dim3(256), 0, st, in_feat, c_in, d_out,
+                c_out, pairs, num, ld, nchunks, ws);
+  else if (np == 2)
+    MSMD_LAUNCH(spconv_wgrad_split_kernel<2>, grid, dim3(256), 0, st, in_feat, c_in, d_out,
+                c_out, pairs, num, ld, nchunks, ws);
+  else
+    MSMD_LAUNCH(spconv_wgrad_split_kernel<1>, grid, dim3(256), 0, st, in_feat, c_in, d_out,
+                c_out, pairs, num, ld, nchunks, ws);
+  return launch_status();
+}
+}  // namespace msmd

@@ -334,6 +334,29 @@ def conv_wgrad(feat, d_out, pairs, num, krsc_shape=None):
     return dw
 
 
+def wgrad_split_supported(c_in, c_out):
+    return bool(lib.msmd_spconv_wgrad_split_supported(int(c_in), int(c_out)))
+
+
+def conv_wgrad_split(feat, d_out, pairs, num, planes=3, krsc_shape=None):
+    """conv_wgrad at bf16 MFMA rate (operands split into `planes` bf16 planes in
+    registers; planes=3 is fp32-equivalent).  c_in, c_out multiples of 64."""
+    _need_cuda(feat, d_out, pairs, num)
+    f, g = feat.contiguous().float(), d_out.contiguous().float()
+    kvol, _, ld = pairs.shape
+    c_in, c_out = f.shape[1], g.shape[1]
+    dw = torch.empty((kvol, c_in, c_out) if krsc_shape is None else tuple(krsc_shape),
+                     dtype=torch.float32, device=f.device)
+    nbytes = lib.msmd_spconv_wgrad_workspace_bytes(kvol, ld, c_in, c_out)
+    ws = _ws(nbytes, f.device)
+    ev = _prof_begin()
+    check(lib.msmd_spconv_wgrad_split(_p(f), c_in, _p(g), c_out, _p(pairs), _p(num), ld, kvol,
+                                      int(planes), _p(dw), int(krsc_shape is not None), _p(ws),
+                                      nbytes, _stream()), "msmd_spconv_wgrad_split")
+    _prof_end("spconv_wgrad_split", ev, num=num, c_in=c_in, c_out=c_out)
+    return dw
+
+
 # ------------------------------------------------------------------ BN (+residual)(+ReLU)
 def bn_act_forward(x, residual, gamma, beta, running_mean, running_var, training, momentum, eps,
                    relu):

@@ -14,7 +14,8 @@ from .. import kernels as K
 
 
 def conv_planes():
-    """Arithmetic of the sparse convolutions' forward and dgrad:
+    """Arithmetic of the sparse convolutions (forward, dgrad and, for channel
+    counts that are multiples of 64, wgrad):
     3 (default) -- operands split into three bf16 planes, six products on the
                    bf16 matrix cores, fp32 accumulate: fp32-equivalent results
                    (csrc/spconv_split.hip) at 2.7x fewer MFMA cycles;
@@ -77,8 +78,12 @@ class _SparseConvFunction(Function):
                                         row_order=order)
         if ctx.needs_input_grad[1]:
             pairs, num = rb.pairs()
-            d_w = K.conv_wgrad(features, grad_out, pairs, num,
-                               krsc_shape=weight.shape if krsc else None)
+            if conv_planes() in (1, 2, 3) and K.wgrad_split_supported(c_in, c_out):
+                d_w = K.conv_wgrad_split(features, grad_out, pairs, num, conv_planes(),
+                                         krsc_shape=weight.shape if krsc else None)
+            else:
+                d_w = K.conv_wgrad(features, grad_out, pairs, num,
+                                   krsc_shape=weight.shape if krsc else None)
         return d_feat, d_w, None, None
 
 

@@ -302,6 +302,45 @@ def test_split_conv_strided(dev, ks, st, pd, cin, cout):
     np.testing.assert_allclose(din.cpu().numpy(), edin, rtol=TOL, atol=TOL)
 
 
+@pytest.mark.parametrize("planes", [3, 2])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128), (128, 64), (128, 128), (192, 64)])
+def test_split_wgrad(dev, cin, cout, planes):
+    """msmd_spconv_wgrad_split against the oracle (SubM and strided pair lists,
+    ragged chunk tails, [K,Cin,Cout] and KRSC outputs)."""
+    from msmdfusion_amd import kernels as K
+    assert K.wgrad_split_supported(cin, cout) and not K.wgrad_split_supported(32, 64)
+    shape = [11, 64, 64]
+    idx = S.random_voxel_indices(2500, 2, shape, seed=cin + cout)
+    n = idx.shape[0]
+    rng = np.random.RandomState(cin + 7 * cout)
+    f = rng.randn(n, cin).astype(np.float32)
+    g = rng.randn(n, cout).astype(np.float32)
+    w = np.zeros((27, cin, cout), np.float32)
+    oi, pr, nm, _ = O.get_indice_pairs(idx, 2, shape, 3, 1, 1, 1, True)
+    _, edw = O.indice_conv_bwd(f, w, g, pr, nm, subm=True)
+    tol = TOL if planes == 3 else 2 * TOL
+    nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
+    pairs, num = K.rulebook_pairs(nbr)
+    dw = K.conv_wgrad_split(t(f, dev), t(g, dev), pairs, num, planes)
+    np.testing.assert_allclose(dw.cpu().numpy(), edw, rtol=tol, atol=5 * tol)
+    dwk = K.conv_wgrad_split(t(f, dev), t(g, dev), pairs, num, planes,
+                             krsc_shape=(cout, 3, 3, 3, cin))
+    assert torch.equal(dwk.view(cout, 27, cin).permute(1, 2, 0), dw)
+    if planes == 3:   # as close to the oracle as the fp32 MFMA kernel
+        d32 = K.conv_wgrad(t(f, dev), t(g, dev), pairs, num).cpu().numpy()
+        assert np.abs(dw.cpu().numpy() - edw).max() <= 2 * np.abs(d32 - edw).max() + 1e-6
+    # strided conv: compact lists of very different lengths, ld > pairs
+    oi, pr, nm, osz = O.get_indice_pairs(idx, 2, shape, 3, 2, 1, 1, False)
+    m = oi.shape[0]
+    g2 = rng.randn(m, cout).astype(np.float32)
+    _, edw2 = O.indice_conv_bwd(f, w, g2, pr, nm)
+    _, _, perm = O.canonical_rulebook(oi, pr, nm, osz)
+    _, nbr_fwd, _, _ = K.rulebook_conv(t(idx, dev), 2, shape, 3, 2, 1)
+    pairs2, num2 = K.rulebook_pairs(nbr_fwd, ld=max(n, m))
+    dw2 = K.conv_wgrad_split(t(f, dev), t(g2[perm], dev), pairs2, num2, planes)
+    np.testing.assert_allclose(dw2.cpu().numpy(), edw2, rtol=tol, atol=5 * tol)
+
+
 def test_split_conv_edges(dev):
     """Empty and tiny inputs, a single tile with padding rows, unsupported shapes."""
     from msmdfusion_amd import kernels as K

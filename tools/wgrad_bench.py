@@ -33,8 +33,18 @@ for si, cin, cout, cnt in [(0, 5, 16, 1), (0, 16, 16, 4), (1, 32, 32, 4), (2, 64
     P = int(num.sum())
     f, g = torch.randn(n, cin, device=dev), torch.randn(n, cout, device=dev)
     t = timed(lambda: K.conv_wgrad(f, g, pairs, num))
+    extra = ""
+    if K.wgrad_split_supported(cin, cout):
+        for np_ in (3, 2):
+            ts = timed(lambda: K.conv_wgrad_split(f, g, pairs, num, np_))
+            d32, dsp = K.conv_wgrad(f, g, pairs, num), K.conv_wgrad_split(f, g, pairs, num, np_)
+            extra += " | split%d %.0f us %.1f TF maxdiff/max %.1e" % (
+                np_, ts, 2.0 * P * cin * cout / ts / 1e6,
+                (d32 - dsp).abs().max().item() / d32.abs().max().item())
+            if np_ == 3:
+                t = min(t, ts)
     tot += t * cnt
-    print("subm %3d->%3d n=%6d pairs=%7d  %6.0f us  %5.1f TF  x%d" % (cin, cout, n, P, t, 2.0 * P * cin * cout / t / 1e6, cnt), flush=True)
+    print("subm %3d->%3d n=%6d pairs=%7d  %6.0f us  %5.1f TF  x%d%s" % (cin, cout, n, P, t, 2.0 * P * cin * cout / t / 1e6, cnt, extra), flush=True)
 for li, (cin, cout) in enumerate([(16, 32), (32, 64), (64, 128)]):
     n_in, n_out, nf = strided[li]
     pairs, num = K.rulebook_pairs(nf, ld=max(n_in, n_out))
