@@ -726,8 +726,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int span = wgrad_span(P, chunk_pairs);
   const int used = (P + span - 1) / span;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < per_k; e += gridDim.x * 256) {
+    // fixed summation order (deterministic); 8 loads in flight per thread
+    const float* src = partial + (size_t)k * nchunks * per_k + e;
     float s = 0.f;
-    for (int c = 0; c < used; ++c) s += partial[((size_t)k * nchunks + c) * per_k + e];
+    int c = 0;
+    for (; c + 8 <= used; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(c + u) * per_k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < used; ++c) s += src[(size_t)c * per_k];
     if (krsc) {  // d_weight is [c_out][K][c_in] (the module's parameter layout)
       const int ci = e / cout, co = e - ci * cout;
       dw[((size_t)co * kvol + k) * cin + ci] = s;
