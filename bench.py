@@ -285,12 +285,13 @@ def pmc_traffic(kernel_name):
     if not os.path.exists(path):
         return None, None
     kernels = json.load(open(path))["kernels"]
-    if kernel_name.startswith("spconv_wgrad"):
-        key = "spconv_wgrad_kernel<true>"
-    else:
+    if "NT=" in kernel_name:    # "spconv_fwd_split_kernel<NT=8>" -> "spconv_fwd_split_kernel<8, ..."
         nt = kernel_name.split("NT=")[1].rstrip(">")
-        key = next((k for k in kernels if k.startswith(kernel_name.split("<")[0] + "<" + nt + ",")),
-                   None)
+        prefix = kernel_name.split("<")[0] + "<" + nt + ","
+    else:                       # wgrad: the widest instantiation present
+        prefix = kernel_name + "<"
+    cands = sorted(k for k in kernels if k.startswith(prefix))
+    key = cands[-1] if cands else None
     e = kernels.get(key, {})
     return e.get("hbm_bytes_per_launch"), e.get("mfma_pipe_busy_frac")
 
