@@ -29,14 +29,11 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_MFMA_TFLOPS = 2516.6   # 256 CUs x 4096 flop/clk x 2.4 GHz, dense
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
-SAMPLES_PER_GPU = 4            # configs/transfusion_nusc_voxel_L.py:116
 
-ENCODER_CFG = dict(             # configs/transfusion_nusc_voxel_L.py:161-169
-    type="SparseEncoder", in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128,
-    order=("conv", "norm", "act"),
-    encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
-    encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
-    block_type="basicblock")
+from msmdfusion_amd.configs import MSMDFUSION_LC, TRANSFUSION_L  # noqa: E402
+
+ENCODER_CFG = TRANSFUSION_L["model"]["pts_middle_encoder"]   # transfusion_nusc_voxel_L.py:161-169
+SAMPLES_PER_GPU = TRANSFUSION_L["samples_per_gpu"]           # :116
 
 
 def parse():
@@ -98,11 +95,7 @@ class FusionBackbone(torch.nn.Module):
         from msmdfusion_amd.voxelize import Voxelization
         vox = Voxelization(S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, S.MAX_NUM_POINTS, S.MAX_VOXELS)
         enc = build_middle_encoder(ENCODER_CFG)
-        mm = build_middle_encoder(dict(
-            type="SparseMultiModalEncoderPaint", in_channels_3D=(16, 32, 64, 128),
-            in_channels_2D=(64, 64, 64, 64), out_channels=(32, 64, 128, 128),
-            padding=(1, 1, [0, 1, 1], 0), order=("conv", "norm", "act"),
-            norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01)))
+        mm = build_middle_encoder(MSMDFUSION_LC["model"]["multimodal_middle_encoder"])
         for p in enc.parameters():
             p.requires_grad = False
         for m in enc.modules():

@@ -1,0 +1,70 @@
+"""The hot-path sections of the two target model configs, restated.
+
+Reference: configs/MSMDFusion_nusc_voxel_LC.py:141-190 and
+configs/transfusion_nusc_voxel_L.py:150-169 (values are facts; equality with the
+reference dicts is pinned by tests/golden/reference_configs.json).  Only the
+keys this path consumes are kept: the image branch, dense BEV backbone/neck and
+the detection head are out of scope.
+
+    from msmdfusion_amd.configs import MSMDFUSION_LC, build_hot_path
+    vox, vfe, enc, mm = build_hot_path(MSMDFUSION_LC)
+"""
+POINT_CLOUD_RANGE = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]
+VOXEL_SIZE = [0.075, 0.075, 0.2]
+
+_PTS_VOXEL_LAYER = dict(max_num_points=10, voxel_size=VOXEL_SIZE, max_voxels=(120000, 160000),
+                        point_cloud_range=POINT_CLOUD_RANGE)
+_PTS_VOXEL_ENCODER = dict(type="HardSimpleVFE", num_features=5)
+_PTS_MIDDLE_ENCODER = dict(
+    type="SparseEncoder", in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=128,
+    order=("conv", "norm", "act"),
+    encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+    encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
+    block_type="basicblock")
+
+TRANSFUSION_L = dict(
+    model=dict(type="TransFusionDetector", pts_voxel_layer=_PTS_VOXEL_LAYER,
+               pts_voxel_encoder=_PTS_VOXEL_ENCODER, pts_middle_encoder=_PTS_MIDDLE_ENCODER),
+    samples_per_gpu=4, point_cloud_range=POINT_CLOUD_RANGE, voxel_size=VOXEL_SIZE,
+    optimizer=dict(type="AdamW", lr=0.0002, weight_decay=0.01),
+    freeze_lidar_components=False)
+
+MSMDFUSION_LC = dict(
+    model=dict(
+        type="MSMDFusionDetector",
+        spatial_shapes=[[41, 1440, 1440], [21, 720, 720], [11, 360, 360], [5, 180, 180]],
+        downscale_factors=[1, 2, 4, 8],
+        fps_num_list=[2048] * 4,
+        radius_list=[6, 3, 2, 1],
+        max_cluster_samples_list=[200, 100, 50, 25],
+        dist_thresh_list=[13.3, 6.6, 3.3, 1.6],
+        pts_voxel_layer=_PTS_VOXEL_LAYER,
+        pts_voxel_encoder=_PTS_VOXEL_ENCODER,
+        pts_middle_encoder=_PTS_MIDDLE_ENCODER,
+        multimodal_middle_encoder=dict(
+            type="SparseMultiModalEncoderPaint", in_channels_3D=(16, 32, 64, 128),
+            in_channels_2D=(64, 64, 64, 64), out_channels=(32, 64, 128, 128),
+            padding=(1, 1, [0, 1, 1], 0), order=("conv", "norm", "act"),
+            norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01))),
+    samples_per_gpu=2, point_cloud_range=POINT_CLOUD_RANGE, voxel_size=VOXEL_SIZE,
+    optimizer=dict(type="AdamW", lr=0.0001, betas=(0.9, 0.999), weight_decay=0.05,
+                   paramwise_cfg=dict(custom_keys={
+                       "absolute_pos_embed": dict(decay_mult=0.),
+                       "relative_position_bias_table": dict(decay_mult=0.),
+                       "norm": dict(decay_mult=0.)})),
+    freeze_lidar_components=True)
+
+
+def build_hot_path(cfg):
+    """(Voxelization, voxel encoder, SparseEncoder, multimodal encoder | None) from one of
+    the dicts above -- what MSMDFusionDetector.__init__ / MVXTwoStageDetector.__init__ build
+    for this path (mmdet3d/models/detectors/mvx_two_stage.py:38-60, MSMDFusion.py:92-104)."""
+    from .registry import build_middle_encoder, build_voxel_encoder
+    from .voxelize import Voxelization
+    m = cfg["model"]
+    vox = Voxelization(**m["pts_voxel_layer"])
+    vfe = build_voxel_encoder(m["pts_voxel_encoder"])
+    enc = build_middle_encoder(m["pts_middle_encoder"])
+    mm = build_middle_encoder(m["multimodal_middle_encoder"]) \
+        if "multimodal_middle_encoder" in m else None
+    return vox, vfe, enc, mm

@@ -104,3 +104,37 @@ def test_synthetic_generators_are_seeded_and_shaped():
     idx = S.random_voxel_indices(500, 2, [5, 30, 30], seed=0)
     assert np.unique(idx, axis=0).shape[0] == idx.shape[0]
     assert (idx.min(0) >= 0).all() and (idx.max(0) < [2, 5, 30, 30]).all()
+
+
+def test_configs_match_the_reference_dicts():
+    """msmdfusion_amd/configs.py restates the hot-path sections of the two
+    reference configs; tests/golden/reference_configs.json holds the values
+    dumped from the reference files (make_config_fixture.py)."""
+    import json
+    from msmdfusion_amd import configs as C
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_configs.json")))
+    norm = lambda o: json.loads(json.dumps(o))   # tuples -> lists
+    assert norm(C.MSMDFUSION_LC) == fx["MSMDFusion_nusc_voxel_LC"]
+    assert norm(C.TRANSFUSION_L) == fx["transfusion_nusc_voxel_L"]
+
+
+def test_hot_path_builds_from_the_configs():
+    """Registry strings + constructor arguments of the unchanged config dicts
+    build the modules, with the reference's parameter names (state-dict keys)."""
+    from msmdfusion_amd import configs as C
+    vox, vfe, enc, mm = C.build_hot_path(C.MSMDFUSION_LC)
+    assert type(enc).__name__ == "SparseEncoder" and type(mm).__name__ == "SparseMultiModalEncoderPaint"
+    assert type(vfe).__name__ == "HardSimpleVFE" and vox.max_num_points == 10
+    keys = set(enc.state_dict().keys())
+    for k in ("conv_input.0.weight", "conv_input.1.running_mean",
+              "encoder_layers.encoder_layer1.0.conv1.weight",
+              "encoder_layers.encoder_layer1.2.0.weight",
+              "encoder_layers.encoder_layer4.1.bn2.weight", "conv_out.0.weight"):
+        assert k in keys, k
+    assert tuple(enc.state_dict()["conv_input.0.weight"].shape) == (16, 3, 3, 3, 5)      # KRSC
+    assert tuple(enc.state_dict()["conv_out.0.weight"].shape) == (128, 3, 1, 1, 128)
+    mk = set(mm.state_dict().keys())
+    assert any(k.startswith("downscale_blocks") for k in mk)
+    assert any(k.startswith("aggregation_blocks") for k in mk)
+    _, _, enc_l, mm_l = C.build_hot_path(C.TRANSFUSION_L)
+    assert mm_l is None and set(enc_l.state_dict().keys()) == keys
