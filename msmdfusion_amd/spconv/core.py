@@ -34,7 +34,6 @@ class IndiceData:
         self._order_fwd = None
         self._order_bwd = None
         self._tiled_fwd = None
-        self._tiled_bwd = None
 
     @property
     def n_in(self):
@@ -72,23 +71,26 @@ class IndiceData:
             self._order_bwd = (K.row_mask_order(self.nbr_bwd),)
         return self._order_bwd[0]
 
-    def tiled_fwd(self):
-        """The forward table with its columns in tiling order (column p belongs
-        to output row order_fwd()[p]): what the split-bf16 kernel stages per tile."""
+    def tiling_fwd(self):
+        """(table, row_order) the split-bf16 kernel tiles the forward pass by.
+        SubM rulebooks serve 8 launches per step (4 convs x forward/dgrad): the
+        table goes in mask-sorted tile order (column p belongs to output row
+        order[p]).  A strided conv's tables serve one launch each and its rows
+        are already in ascending linear id -- spatial neighbours, similar masks:
+        mask + sort + permute (~100 us) costs more than it saves there
+        (tools/strided_order.py), so those stay in natural order."""
+        if not self.is_subm:
+            return self.nbr_fwd, None
         if self._tiled_fwd is None:
             order = self.order_fwd()
             self._tiled_fwd = (K.permute_cols(self.nbr_fwd, order) if order is not None
                                else self.nbr_fwd,)
-        return self._tiled_fwd[0]
+        return self._tiled_fwd[0], self.order_fwd()
 
-    def tiled_bwd(self):
-        if self.is_subm:
-            return self.tiled_fwd()
-        if self._tiled_bwd is None:
-            order = self.order_bwd()
-            self._tiled_bwd = (K.permute_cols(self.nbr_bwd, order) if order is not None
-                               else self.nbr_bwd,)
-        return self._tiled_bwd[0]
+    def tiling_bwd(self):
+        if self.is_subm:      # forward table + flipped weights == backward table
+            return self.tiling_fwd()
+        return self.nbr_bwd, None
 
 
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,

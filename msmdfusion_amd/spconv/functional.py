@@ -48,8 +48,9 @@ class _SparseConvFunction(Function):
         if _use_split(c_in, c_out, rb.nbr_fwd.shape[0]):
             np_ = conv_planes()
             packed = K.pack_weight_split(weight, np_, krsc=krsc)
-            return K.conv_forward_split(features, packed, rb.tiled_fwd(), rb.n_out, c_out, np_,
-                                        row_order=rb.order_fwd())
+            table, order = rb.tiling_fwd()
+            return K.conv_forward_split(features, packed, table, rb.n_out, c_out, np_,
+                                        row_order=order)
         packed = K.pack_weight(weight, krsc=krsc)
         return K.conv_forward(features, packed, rb.nbr_fwd, rb.n_out, c_out,
                               row_order=rb.order_fwd() if _wants_order(c_in, c_out) else None)
@@ -64,9 +65,9 @@ class _SparseConvFunction(Function):
         if ctx.needs_input_grad[0] and _use_split(c_out, c_in, rb.nbr_fwd.shape[0]):
             np_ = conv_planes()
             packed_t = K.pack_weight_split(weight, np_, transpose=True, krsc=krsc)
-            # SubM: forward table + flipped weights == backward table
-            d_feat = K.conv_forward_split(grad_out, packed_t, rb.tiled_bwd(), rb.n_in, c_in, np_,
-                                          weight_flip=rb.is_subm, row_order=rb.order_bwd())
+            table, order = rb.tiling_bwd()
+            d_feat = K.conv_forward_split(grad_out, packed_t, table, rb.n_in, c_in, np_,
+                                          weight_flip=rb.is_subm, row_order=order)
         elif ctx.needs_input_grad[0]:
             packed_t = K.pack_weight(weight, transpose=True, krsc=krsc)
             order = rb.order_bwd() if _wants_order(c_out, c_in) else None
