@@ -121,18 +121,25 @@ class SparseMultiModalEncoderPaint(nn.Module):
         pad_feat = features.new_zeros((missing.numel(), features.shape[1]))
         return torch.cat([indices, pad_idx], 0), torch.cat([features, pad_feat], 0)
 
+    @staticmethod
+    def sample_counts(only_2d_bzyx, voxel_3d_bzyx, batch_size):
+        """[2, B] device tensor: rows per sample of both voxel sets."""
+        return torch.stack([torch.bincount(only_2d_bzyx[:, 0].long(), minlength=batch_size),
+                            torch.bincount(voxel_3d_bzyx[:, 0].long(), minlength=batch_size)])
+
     def nearest_3d_of_only_2d(self, only_2d_bzyx, voxel_3d_bzyx, batch_size, fps_num, radius,
-                              max_cluster_samples, dist_thresh):
+                              max_cluster_samples, dist_thresh, counts=None):
         """Per sample nearest LiDAR voxel of every only-2D voxel (:349-369);
         returns global row indices into voxel_3D, -1 = unassigned.  Rows of both
         tensors are grouped by sample (they always are: voxelize concatenates
-        samples in order).  One host read (the per-sample counts); when every
-        sample needs the FPS path, all samples' FPS run in ONE ragged launch."""
+        samples in order).  One host read (the per-sample counts; none when the
+        caller passes them as nested lists); when every sample needs the FPS
+        path, all samples' FPS run in ONE ragged launch."""
         dev = only_2d_bzyx.device
         out = torch.full((only_2d_bzyx.shape[0],), -1, dtype=torch.long, device=dev)
-        counts = torch.stack([torch.bincount(only_2d_bzyx[:, 0].long(), minlength=batch_size),
-                              torch.bincount(voxel_3d_bzyx[:, 0].long(), minlength=batch_size)])
-        c2, c3 = counts.tolist()
+        if counts is None:
+            counts = self.sample_counts(only_2d_bzyx, voxel_3d_bzyx, batch_size).tolist()
+        c2, c3 = counts
         o2 = [0]
         o3 = [0]
         for b in range(batch_size):
@@ -163,24 +170,55 @@ class SparseMultiModalEncoderPaint(nn.Module):
             out[o2[b]:o2[b + 1]] = torch.where(nn_idx >= 0, nn_idx + o3[b], nn_idx)
         return out   # offsets are cumulative (reference: last sample's count only, B.4)
 
+    # ---- index-only half of a GMA-Conv stage ------------------------------------
+    def plan_stage_rows(self, idx3_5, idx2_5, batch_size):
+        """Everything grouped_sparse_conv derives from the two 5-column index
+        tensors alone, up to the neighbour search: row lists of the only-3D /
+        only-2D voxels, the padded only-2D indices, the per-sample counts (device
+        tensor -- the caller reads all stages' counts in one transfer)."""
+        zyx = [0, 2, 3, 4]
+        only_3D_rows = (idx3_5[:, 1] == 0).nonzero().flatten()
+        only_2D_rows = (idx2_5[:, 1] == 0).nonzero().flatten()
+        o2_idx = idx2_5.index_select(0, only_2D_rows)
+        n_raw = o2_idx.shape[0]
+        o2_idx, _ = self.pad_missing_batch_id(o2_idx, o2_idx.new_zeros((n_raw, 0)).float(),
+                                              batch_size)
+        o2_bzyx = o2_idx[:, zyx].contiguous()
+        idx3 = idx3_5[:, zyx].contiguous()
+        return dict(only_3D_rows=only_3D_rows, only_2D_rows=only_2D_rows, o2_idx=o2_idx,
+                    o2_bzyx=o2_bzyx, idx3=idx3, n_pad=o2_idx.shape[0] - n_raw,
+                    counts=self.sample_counts(o2_bzyx, idx3, batch_size))
+
+    def plan_stage_nn(self, plan, counts, batch_size, fps_num, radius, max_cluster_samples,
+                      dist_thresh):
+        """The neighbour search of a planned stage (no host read: `counts` are the
+        nested lists already on the host).  Stream-agnostic: the fusion path
+        enqueues it on a side stream under the LiDAR encoder's forward pass."""
+        plan["nn3"] = self.nearest_3d_of_only_2d(plan["o2_bzyx"], plan["idx3"], batch_size,
+                                                 fps_num, radius, max_cluster_samples,
+                                                 dist_thresh, counts=counts)
+        return plan
+
     # ---- one GMA-Conv stage (:325-430) -----------------------------------------
     def grouped_sparse_conv(self, voxel_3D, voxel_2D, syn_mix_3D, syn_mix_2D, stage_id, fps_num,
-                            radius, max_cluster_samples, dist_thresh):
+                            radius, max_cluster_samples, dist_thresh, plan=None):
         B = voxel_3D.batch_size
         c3 = self.in_channels_3D[stage_id]
         zyx = [0, 2, 3, 4]      # indices are (batch, mix_flag, z, y, x)
         # row lists instead of boolean masks: gathers go through index_select,
         # whose backward is index_add_ (torch's advanced-indexing backward sorts
         # the indices -- 2.8 ms per call on the [N3+1,64] gate table here)
-        only_3D_rows = (voxel_3D.indices[:, 1] == 0).nonzero().flatten()
-        only_2D_rows = (voxel_2D.indices[:, 1] == 0).nonzero().flatten()
-
-        o2_idx, o2_feat = self.pad_missing_batch_id(
-            voxel_2D.indices.index_select(0, only_2D_rows),
-            voxel_2D.features.index_select(0, only_2D_rows), B)
-        idx3 = voxel_3D.indices[:, zyx].contiguous()
-        nn3 = self.nearest_3d_of_only_2d(o2_idx[:, zyx].contiguous(), idx3, B, fps_num, radius,
-                                         max_cluster_samples, dist_thresh)
+        if plan is None:        # index-only work not done ahead of time: do it here
+            plan = self.plan_stage_rows(voxel_3D.indices, voxel_2D.indices, B)
+            self.plan_stage_nn(plan, plan["counts"].tolist(), B, fps_num, radius,
+                               max_cluster_samples, dist_thresh)
+        elif plan.get("ready") is not None:     # computed on another stream
+            torch.cuda.current_stream().wait_event(plan["ready"])
+        only_3D_rows, only_2D_rows = plan["only_3D_rows"], plan["only_2D_rows"]
+        o2_idx, nn3 = plan["o2_idx"], plan["nn3"]
+        o2_feat = voxel_2D.features.index_select(0, only_2D_rows)
+        if plan["n_pad"]:       # :208-225 samples without an only-2D voxel got a zero row
+            o2_feat = torch.cat([o2_feat, o2_feat.new_zeros((plan["n_pad"], o2_feat.shape[1]))], 0)
         # uncovered 2D voxels are gated by a random embedding (row -1 -> last row)
         dummy = self.dummy_embedding_fn(c3, voxel_3D.features.device)
         cross_gating = self.cross_gate_control[stage_id](
@@ -216,14 +254,18 @@ class SparseMultiModalEncoderPaint(nn.Module):
         return getattr(self.aggregation_blocks, stage)(unified)
 
     def forward(self, voxel_3D_list, voxel_2D_list, syn_mix_3D_list, syn_mix_2D_list,
-                fps_num_list, radius_list, max_cluster_samples_list, dist_thresh_list):
+                fps_num_list, radius_list, max_cluster_samples_list, dist_thresh_list,
+                stage_plans=None):
+        """stage_plans (optional, not in the reference): per-stage results of
+        plan_stage_rows / plan_stage_nn computed ahead of the feature pass."""
         stage_outs = []
         for stage_id in range(len(voxel_2D_list)):
             out = self.grouped_sparse_conv(
                 voxel_3D_list[stage_id], voxel_2D_list[stage_id], syn_mix_3D_list[stage_id],
                 syn_mix_2D_list[stage_id], stage_id, fps_num_list[stage_id],
                 radius_list[stage_id], max_cluster_samples_list[stage_id],
-                dist_thresh_list[stage_id])
+                dist_thresh_list[stage_id],
+                plan=None if stage_plans is None else stage_plans[stage_id])
             if stage_id > 0:
                 out = Fsp.sparse_add(out, stage_outs[stage_id - 1])
             stage_outs.append(getattr(self.downscale_blocks, f"stage_{stage_id + 1}")(out))

@@ -46,12 +46,29 @@ class SparseEncoder(nn.Module):
             encoder_out_channels, output_channels, kernel_size=(3, 1, 1), stride=(2, 1, 1),
             norm_cfg=norm_cfg, padding=0, indice_key="spconv_down2", conv_type="SparseConv3d")
 
-    def forward(self, voxel_features, coors, batch_size):
-        """voxel_features [N,C] fp32, coors [N,4] (b,z,y,x) -> (BEV, stage outputs)."""
-        x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size)
-        # all 21 rulebooks (4 SubM voxel sets + 4 strided) before any feature work
+    def plan(self, coors, batch_size):
+        """Index-only half of forward(): every rulebook of the encoder (4 SubM
+        voxel sets + 4 strided convs) from the voxel coordinates alone.  Returns
+        (planned, stage_indices): `planned` goes back into forward(planned=...),
+        stage_indices[i] = (indices, spatial_shape) of encode_features[i] -- known
+        before any feature is computed, so work that depends on the voxel sets
+        only (the fusion path's neighbour search) can start on another stream."""
+        planned = spconv.SparseConvTensor(
+            torch.empty((coors.shape[0], 0), dtype=torch.float32, device=coors.device),
+            coors.int(), self.sparse_shape, batch_size)
         convs = [m for m in self.modules() if isinstance(m, spconv.SparseConvolution)]
-        x.plan(convs, need_grad=torch.is_grad_enabled())
+        outs = []
+        planned.plan(convs, need_grad=torch.is_grad_enabled(), strided_outputs=outs)
+        stages = [(planned.indices, list(self.sparse_shape))] + outs[:self.stage_num - 1]
+        stages.append(stages[-1])        # the last stage has no strided conv
+        return planned, stages
+
+    def forward(self, voxel_features, coors, batch_size, planned=None):
+        """voxel_features [N,C] fp32, coors [N,4] (b,z,y,x) -> (BEV, stage outputs)."""
+        if planned is None:
+            # all 21 rulebooks (4 SubM voxel sets + 4 strided) before any feature work
+            planned, _ = self.plan(coors, batch_size)
+        x = planned.replace_feature(voxel_features)
         x = self.conv_input(x)
         encode_features = [x]
         for encoder_layer in self.encoder_layers:

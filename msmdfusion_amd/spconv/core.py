@@ -182,13 +182,14 @@ class SparseConvTensor:
         self._rb_cache[ident] = rb
         return rb
 
-    def plan(self, convs, need_grad):
+    def plan(self, convs, need_grad, strided_outputs=None):
         """Index-only pre-pass: build (or fetch) the rulebook of every sparse
         conv in `convs` (execution order), following the voxel set through the
         strided ones.  Rulebooks depend on indices only, never on features, so
         the whole chain -- including its host reads of output-voxel counts --
         runs before the first feature kernel; the feature pass then finds every
-        rulebook in the shared cache."""
+        rulebook in the shared cache.  `strided_outputs` (a list) receives the
+        (indices, spatial_shape) after every strided conv, in order."""
         t = self
         for conv in convs:
             if getattr(conv, "conv1x1", False):
@@ -202,6 +203,8 @@ class SparseConvTensor:
                 t = t.shadow_copy()
                 t.indices = rb.out_indices
                 t.spatial_shape = rb.out_spatial_shape
+                if strided_outputs is not None:
+                    strided_outputs.append((rb.out_indices, list(rb.out_spatial_shape)))
         return t
 
     def dense(self, channels_first: bool = True):

@@ -176,6 +176,25 @@ def test_sparse_fusion_path_end_to_end(dev):
     assert torch.isfinite(x).all() and torch.isfinite(x_mm).all() and x_mm.abs().sum() > 0
     x2, x_mm2 = path(pts, [virt] * 4)
     assert torch.equal(x_mm, x_mm2)
+    # the planned / side-stream schedule computes exactly what the reference's
+    # order of calls does (extract_pts_feat, MSMDFusion.py:421-443)
+    from msmdfusion_amd.fusion import (virtual_points_to_voxels, voxel_modality_split,
+                                       voxelize_batch)
+    with torch.no_grad():
+        feats, _, coors = voxelize_batch(vox, pts, 1.0, fused_mean=True)
+        x_ref, enc_feats = enc(feats, coors, 2)
+        v3, v2, s3, s2 = [], [], [], []
+        for i in range(4):
+            voxel_2D = virtual_points_to_voxels(vox, virt, path.spatial_shapes[i],
+                                                path.downscale_factors[i], 2)
+            a, b, pa, pb = voxel_modality_split(enc_feats[i].shadow_copy(), voxel_2D, 2)
+            v3.append(a); v2.append(b); s3.append(pa); s2.append(pb)
+        outs = mm(v3, v2, s3, s2, path.fps_num_list, path.radius_list,
+                  path.max_cluster_samples_list, path.dist_thresh_list)
+        mm_ref = outs[-1].dense()
+        x_p, x_mm_p = path(pts, [virt] * 4)
+    assert torch.equal(x_ref, x_p)
+    assert torch.equal(mm_ref.view(2, -1, 180, 180), x_mm_p)
     (x.mean() + x_mm.mean()).backward()
     used = [n for n, p in path.named_parameters() if p.grad is not None]
     dead = [n for n, p in path.named_parameters() if p.grad is None]
