@@ -208,6 +208,12 @@ def main():
         opt.zero_grad(set_to_none=True)
         return loss
 
+    # Setup, untimed: let torch's caching allocator reach its steady state before
+    # the W warm-up steps.  The LC path allocates on two streams (record_stream
+    # defers block reuse), and needs ~8 steps before no step calls hipMalloc any
+    # more (37 ms -> 28 ms per step, tools/lc_steps.py).
+    for _ in range(10 if lc else 2):
+        step()
     for _ in range(args.warmup):
         step()
     if args.diag and rank == 0:     # host enqueue time vs device time, outside the timed region

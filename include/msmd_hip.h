@@ -193,8 +193,9 @@ int msmd_spconv_fwd_f32(const float* in_feat /* [n_in,c_in] */, int n_in,
  * cycles than the fp32 MFMA.  `planes` = 3 is that mode; 2 keeps three products
  * (relative error ~2^-17); 1 is plain bf16 operands.  Features are read as fp32
  * and split in registers; weights are split by the pack call.
- * Covers c_in % 32 == 0, c_out in {32, 64, 96, 128}, K <= 32 (ask
- * msmd_spconv_fwd_split_supported); other layers use msmd_spconv_fwd_f32.
+ * Covers c_in % 8 == 0 and c_out % 4 == 0, both >= 32, K <= 32 (ask
+ * msmd_spconv_fwd_split_supported; c_out > 128 runs in column passes); other
+ * layers use msmd_spconv_fwd_f32.
  * With `row_order`, `nbr` must be in TILE order: nbr[k][p] refers to output row
  * row_order[p] (msmd_rulebook_permute_cols).  `tile_counter` is required.      */
 int msmd_spconv_fwd_split_supported(int c_in, int c_out, int kernel_volume);

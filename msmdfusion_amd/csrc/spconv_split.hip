@@ -224,9 +224,11 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     const float* __restrict__ in, int n_in, int cin, const u32x4* __restrict__ wp,
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
     const int32_t* __restrict__ order, int* __restrict__ tile_counter, float* __restrict__ out,
-    int cout, int dbg) {
+    int ldo, int cout, int nt_total, int mt0, int dbg) {
+  // `out` points at this pass's first output channel (tile mt0 of nt_total in the
+  // packed weights), rows are ldo floats apart, `cout` channels are stored.
   constexpr int R = 2, kRows = 4 * R * 16;
-  constexpr int kUnitU = NP * NT * 64;  // 16-byte units of one unit's weights
+  constexpr int kUnitU = NP * NT * 64;  // 16-byte units of one unit's weights (in LDS)
   constexpr int kWU = UB * kUnitU;
   constexpr int kGr = R * 2;            // gather loads per unit per lane
   constexpr int kPw = (NP * NT + 3) / 4;  // weight DMA ops per unit per wave
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
-  const int kbt = cin >> 5;
+  const int kbt = (cin + 31) >> 5;      // the last k-block may be partial (c_in % 8 == 0)
   const int n_tiles = (n_out + kRows - 1) / kRows;
   // every workgroup draws 1 + (tiles it processed) tickets: the draw that returns
   // this value is the last one of the launch and puts the counter back to 0
@@ -321,13 +323,15 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     };
     auto issue_g = [&](u32x4 (&raw)[R][2], int& valid) {  // cursor `g`, rows s_next
       valid = -1;
-      const unsigned col = (unsigned)(kbg * 128 + q * 32);
+      const int chan0 = kbg * 32 + q * 8;   // this lane's 8 channels; past c_in -> zeros
+      const unsigned col = (unsigned)chan0 * 4u;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int src = s_next[r];
         valid = src > valid ? src : valid;
-        const unsigned off =
-            (src < 0 || (dbg & 2)) ? kOobOffset : (unsigned)src * row_bytes + col;
+        const unsigned off = (src < 0 || chan0 >= cin || (dbg & 2))
+                                 ? kOobOffset
+                                 : (unsigned)src * row_bytes + col;
         gather_row8(raw[r], off, rs);
       }
       MSMD_ADV(mg, kbg);
@@ -338,14 +342,17 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
       for (int u = 0; u < UB; ++u) {
         const int k = mw ? __builtin_ctz(mw) : 0;
         const int kw = flip ? kvol - 1 - k : k;
-        const u32x4* g = wp + ((size_t)kw * kbt + kbw) * kUnitU;
+        const u32x4* g = wp + ((size_t)kw * kbt + kbw) * (NP * nt_total * 64);
         // every wave issues the same number of ops (a short last round repeats
         // piece 0: same bytes to the same place) so the queue counts are static
 #pragma unroll
         for (int pp = 0; pp < kPw; ++pp) {
           int piece = wave + 4 * pp;
           if ((NP * NT) % 4 != 0 && piece >= NP * NT) piece = 0;
-          __builtin_amdgcn_global_load_lds((glb_void*)(g + piece * 64 + lane),
+          const int pl = piece / NT;
+          int tile = mt0 + piece - pl * NT;          // tiles past the packed image repeat
+          tile = tile < nt_total ? tile : nt_total - 1;   // the last one (never stored)
+          __builtin_amdgcn_global_load_lds((glb_void*)(g + (pl * nt_total + tile) * 64 + lane),
                                            (lds_void*)(wb + u * kUnitU + piece * 64), 16, 0, 0);
         }
         MSMD_ADV(mw, kbw);
@@ -487,9 +494,10 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
       const int p = tile * kRows + lr[r];
       if (p >= n_out) continue;
       const int row = order ? tab[kvol * kRows + lr[r]] : p;
-      float* o = out + (size_t)row * cout + 4 * q;
+      float* o = out + (size_t)row * ldo + 4 * q;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) *(f32x4*)(o + 16 * n) = acc[r][n];
+      for (int n = 0; n < NT; ++n)
+        if (16 * n + 4 * q < cout) *(f32x4*)(o + 16 * n) = acc[r][n];
     }
     // ---- next tile ----
     if (!staged) {
@@ -518,9 +526,10 @@ int split_slots_per_cu() {
 }
 
 template <int NT, int UB, int NP>
-int launch_fwd_split(const float* planes, int n_in, int cin, const void* wp, const int32_t* nbr,
+int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                      int ld, int n_out, int kvol, int flip, const int32_t* order,
-                     int* tile_counter, float* out, int cout, hipStream_t st) {
+                     int* tile_counter, float* out, int ldo, int cout, int nt_total, int mt0,
+                     hipStream_t st) {
   constexpr int kRows = 128;
   const size_t smem = sizeof(u32x4) * 2 * UB * NP * NT * 64 +
                       sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 8);
@@ -534,27 +543,38 @@ int launch_fwd_split(const float* planes, int n_in, int cin, const void* wp, con
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_smem = smem;
   }
-  MSMD_LAUNCH(kern, dim3(nblk), dim3(256), smem, st, planes, n_in, cin,
-              (const u32x4*)wp, nbr, ld, n_out, kvol, flip, order, tile_counter, out, cout,
+  MSMD_LAUNCH(kern, dim3(nblk), dim3(256), smem, st, in, n_in, cin, (const u32x4*)wp, nbr, ld,
+              n_out, kvol, flip, order, tile_counter, out, ldo, cout, nt_total, mt0,
               env_int2("MSMD_DBG", 0));
   return launch_status();
 }
 
+// c_out is covered in passes of at most 128 channels (8 tiles of 16; a pass's
+// tile count is rounded up to even, the extra tile is computed and not stored).
 template <int NP>
-int dispatch_fwd_split(const float* planes, int n_in, int cin, const void* wp, const int32_t* nbr,
+int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                        int ld, int n_out, int kvol, int flip, const int32_t* order,
                        int* tile_counter, float* out, int cout, hipStream_t st) {
+  const int nt_total = (cout + 15) / 16;
+  const int n_pass = (nt_total + 7) / 8;
+  const int per = (nt_total + n_pass - 1) / n_pass;   // tiles per pass
+  for (int ps = 0; ps < n_pass; ++ps) {
+    const int mt0 = ps * per;
+    const int tiles = (mt0 + per <= nt_total) ? per : nt_total - mt0;
+    const int width = (16 * (mt0 + tiles) <= cout ? 16 * tiles : cout - 16 * mt0);
+    float* o = out + 16 * mt0;
+    int rc;
 #define MSMD_GO(NT_, UB_)                                                                      \
-  return launch_fwd_split<NT_, UB_, NP>(planes, n_in, cin, wp, nbr, ld, n_out, kvol, flip,    \
-                                        order, tile_counter, out, cout, st)
-  switch (cout / 16) {
-    case 8: MSMD_GO(8, 1);
-    case 6: MSMD_GO(6, 1);
-    case 4: MSMD_GO(4, 2);
-    case 2: MSMD_GO(2, 4);
-    default: return MSMD_ERR_UNSUPPORTED;
-  }
+  rc = launch_fwd_split<NT_, UB_, NP>(in, n_in, cin, wp, nbr, ld, n_out, kvol, flip, order,   \
+                                      tile_counter, o, cout, width, nt_total, mt0, st)
+    if (tiles > 6) { MSMD_GO(8, 1); }
+    else if (tiles > 4) { MSMD_GO(6, 1); }
+    else if (tiles > 2) { MSMD_GO(4, 2); }
+    else { MSMD_GO(2, 4); }
 #undef MSMD_GO
+    if (rc != MSMD_OK) return rc;
+  }
+  return MSMD_OK;
 }
 
 // out[k][p] = nbr[k][order[p]]: the neighbour table in tile order.
@@ -743,9 +763,10 @@ MSMD_EXPORT int msmd_spconv_pack_weight_split(const float* w, int kvol, int cin,
 }
 
 MSMD_EXPORT int msmd_spconv_fwd_split_supported(int cin, int cout, int kvol) {
-  const int nt = cout / 16;
-  return cin > 0 && (cin & 31) == 0 && (cout & 15) == 0 && kvol <= kMaxK &&
-         (nt == 8 || nt == 6 || nt == 4 || nt == 2);
+  // 8-channel gather pieces, 16-byte stores; below 32 channels on either side the
+  // 32-wide k-blocks / paired output tiles would be mostly padding
+  return cin >= 32 && (cin & 7) == 0 && cout >= 32 && (cout & 3) == 0 && kvol >= 1 &&
+         kvol <= kMaxK;
 }
 
 MSMD_EXPORT int msmd_spconv_fwd_split(const float* planes, int n_in, int cin, const void* packed,

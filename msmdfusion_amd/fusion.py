@@ -141,5 +141,8 @@ class SparseFusionPath(nn.Module):
     def _side_stream(self, device):
         st = getattr(self, "_side", None)
         if st is None or st.device != device:
-            st = self._side = torch.cuda.Stream(device=device)
+            # high priority: the FPS workgroups are 1024 threads x 128 registers -- a whole
+            # CU each -- and must win the CU when one drains between the main stream's
+            # chip-filling persistent kernels, or the search starts late
+            st = self._side = torch.cuda.Stream(device=device, priority=-1)
         return st

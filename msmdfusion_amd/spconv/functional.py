@@ -21,13 +21,16 @@ def conv_planes():
                    (csrc/spconv_split.hip) at 2.7x fewer MFMA cycles;
     2           -- two planes, three products (relative error ~2^-17);
     0           -- the fp32 matrix instruction (csrc/spconv.hip).
-    Layers the split kernel does not cover (c_in % 32 != 0, c_out not in
-    {32, 64, 96, 128}) always use the fp32 kernel."""
+    Layers the split kernels do not cover (fewer than 32 channels on a side,
+    c_in % 8 != 0; for wgrad: not multiples of 64) always use the fp32 kernels."""
     return int(os.environ.get("MSMD_CONV_PLANES", "3"))
 
 
 def _use_split(c_in, c_out, kvol):
-    return conv_planes() in (1, 2, 3) and K.split_supported(c_in, c_out, kvol)
+    # the kernel also takes c_in % 8 == 0, but with a partial last k-block (the
+    # fusion stack's 80-channel layers) the fp32 kernel is faster: 118 vs 160 us
+    return (conv_planes() in (1, 2, 3) and c_in % 32 == 0
+            and K.split_supported(c_in, c_out, kvol))
 
 
 def _wants_order(c_in, c_out):

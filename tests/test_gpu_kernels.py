@@ -221,7 +221,10 @@ def test_strided_conv_fwd_bwd(dev, ks, st, pd, cin, cout):
 
 # --------------------------------------------- split-bf16 ("fp32-equivalent") convolution
 SPLIT_CHANNELS = [(32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (96, 96), (64, 32),
-                  (128, 64), (128, 96)]
+                  (128, 64), (128, 96),
+                  # the fusion stack's widths: partial last k-block (c_in % 32 != 0), odd
+                  # tile counts, c_out > 128 (two column passes)
+                  (80, 80), (80, 96), (96, 128), (128, 192), (192, 192), (40, 72)]
 
 
 @pytest.mark.parametrize("planes", [3, 2])
@@ -346,7 +349,8 @@ def test_split_conv_edges(dev):
     from msmdfusion_amd import kernels as K
     from msmdfusion_amd._lib import MsmdError
     assert not K.split_supported(16, 16) and not K.split_supported(5, 16)
-    assert not K.split_supported(32, 48) and not K.split_supported(48, 64)
+    assert not K.split_supported(36, 64) and not K.split_supported(32, 30)
+    assert K.split_supported(48, 64) and K.split_supported(192, 192)
     w = torch.randn(27, 32, 64, device=dev)
     ws = K.pack_weight_split(w, 3)
     for n in (0, 1, 3, 129):

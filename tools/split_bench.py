@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--planes", type=int, default=3)
     ap.add_argument("--wgrad", action="store_true")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--lc", action="store_true", help="the fusion stack's channel widths")
     args = ap.parse_args()
     import torch
     import torch.nn.functional as F
@@ -61,7 +62,11 @@ def main():
         idx, _, _, shape = K.rulebook_conv(idx, 4, shape, 3, 2, pad)
     stages.append((idx, shape))
     torch.manual_seed(0)
-    for si, cin, cout in [(3, 128, 128), (2, 64, 64), (2, 64, 128), (1, 32, 32), (1, 32, 64)]:
+    layers = [(3, 128, 128), (2, 64, 64), (2, 64, 128), (1, 32, 32), (1, 32, 64)]
+    if args.lc:
+        layers = [(0, 80, 80), (0, 80, 96), (1, 96, 96), (1, 96, 128), (2, 128, 192),
+                  (3, 192, 192)]
+    for si, cin, cout in layers:
         idx, shape = stages[si]
         n = idx.shape[0]
         nbr = K.rulebook_subm(idx, 4, shape, 3)

@@ -1,0 +1,22 @@
+"""Per-step wall time of the headline workload (warm-up behaviour)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from msmdfusion_amd import synthetic as S
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = bench.Backbone().to(dev).train()
+opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+clouds = [torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in range(4)]
+def step():
+    out = model(clouds)
+    out.mean().backward()
+    opt.step(); opt.zero_grad(set_to_none=True)
+ts = []
+for i in range(40):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+print(" ".join("%.1f" % t for t in ts))
