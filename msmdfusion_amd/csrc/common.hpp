@@ -27,6 +27,27 @@ inline thread_local int g_last_detail = 0;  // kept for msmd_last_launch_error()
     if (e_ != hipSuccess && !::msmd::g_launch_err) ::msmd::g_launch_err = (int)e_; \
   } while (0)
 
+// XCD-aware work assignment of the wgrad kernels.  The dispatcher places block b
+// on XCD b % 8 (observed, MI355X_MICROARCH.md); each XCD has its own 4 MiB L2.
+// The (chunk, offset k, slab) workgroups of one chunk gather the same ~2k feature
+// rows: give every XCD whole chunks (chunk % 8 == xcd) and walk (k, slab) for a
+// chunk in consecutive blocks of that XCD, so the rows are fetched from HBM once
+// per chunk instead of once per (k, slab).  Bijective over
+// [0, wgrad_grid(nchunks, kvol, slabs)).
+inline int wgrad_grid(int nchunks, int kvol, int slabs) {
+  return ((nchunks + 7) / 8) * 8 * kvol * slabs;
+}
+__device__ __forceinline__ bool wgrad_work(int nchunks, int kvol, int slabs, int& chunk, int& k,
+                                           int& slab) {
+  const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+  const int per = kvol * slabs;
+  const int cg = j / per, r = j - cg * per;
+  chunk = cg * 8 + xcd;
+  k = r / slabs;
+  slab = r - k * slabs;
+  return chunk < nchunks;
+}
+
 inline int launch_status() {
   int e = g_launch_err;
   g_launch_err = 0;

@@ -562,7 +562,7 @@ template <int SA, int SB, int CHUNK, bool VEC, int WPS>  // VEC: c_in % SA == 0 
 __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
     const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
-    float* __restrict__ partial /* [K][nchunks][cin][cout] */) {
+    int kvol, int slab_groups, float* __restrict__ partial /* [K][nchunks][cin][cout] */) {
   // LDS: the chunk's pair indices during the main loop, then the tree reduction
   // of the four wave partials (aliased)
   constexpr int kRedBytes = 2 * SA * SB * 64 * (int)sizeof(f32x4);
@@ -571,7 +571,8 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
   int* s_in = (int*)lds_raw;
   int* s_out = s_in + 2 * CHUNK;
   f32x4* red = (f32x4*)lds_raw;
-  const int k = blockIdx.y, chunk = blockIdx.x;
+  int k, chunk, zz;
+  if (!wgrad_work(nchunks, kvol, slab_groups, chunk, k, zz)) return;
   const int P = num[k];
   const int span = wgrad_span(P, CHUNK);   // pairs per workgroup for this offset
   const int p_begin = chunk * span;
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(
   const int cnt = (P - p_begin) < span ? (P - p_begin) : span;
   const int NTs = (cout + 16 * SB - 1) / (16 * SB);  // slabs along c_out
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slab = blockIdx.z * (4 / WPS) + wave / WPS, rank = wave % WPS;
+  const int slab = zz * (4 / WPS) + wave / WPS, rank = wave % WPS;
   const int sa = slab / NTs, sb = slab % NTs;
   const int a0 = sa * SA * 16, b0 = sb * SB * 16;   // first channel of the slab
   const int i = lane & 15, q = lane >> 4;
@@ -833,10 +834,11 @@ void launch_wgrad(int chunk, dim3 grid, hipStream_t st, const float* in_feat, in
   const int n_slabs = (int)grid.z, nb = ceil_div(c_out, 16 * SB);
   static const int multi = env_int("MSMD_WGRAD_MULTISLAB", 0);
   const int spw = !multi ? 1 : ((n_slabs % 4 == 0 && nb % 2 == 0) ? 4 : (nb % 2 == 0 ? 2 : 1));
-  grid.z = n_slabs / spw;
+  const int kvol = (int)grid.y, groups = n_slabs / spw;
+  const dim3 grid1(wgrad_grid(nchunks, kvol, groups));
 #define MSMD_GOW(C_, V_, W_)                                                                  \
-  MSMD_LAUNCH((spconv_wgrad_kernel<SA, SB, C_, V_, W_>), grid, dim3(256), 0, st, in_feat,     \
-              c_in, d_out, c_out, pairs, num, ld, nchunks, ws)
+  MSMD_LAUNCH((spconv_wgrad_kernel<SA, SB, C_, V_, W_>), grid1, dim3(256), 0, st, in_feat,    \
+              c_in, d_out, c_out, pairs, num, ld, nchunks, kvol, groups, ws)
 #define MSMD_GOV(C_, W_)                                                                      \
   if (vec) MSMD_GOW(C_, true, W_); else MSMD_GOW(C_, false, W_)
   if (chunk == 512) {

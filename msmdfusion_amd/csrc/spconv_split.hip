@@ -607,7 +607,7 @@ template <int NP>
 __global__ __launch_bounds__(256, 2) void spconv_wgrad_split_kernel(
     const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
-    float* __restrict__ partial /* [K][nchunks][cin][cout] */) {
+    int kvol, float* __restrict__ partial /* [K][nchunks][cin][cout] */) {
   constexpr int CHUNK = 2048, S = 4;
   using P = Products<NP>;
   __shared__ __attribute__((aligned(16))) char lds_raw[2 * S * S * 64 * sizeof(f32x4)];
@@ -615,13 +615,14 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_split_kernel(
   int* s_out = s_in + CHUNK;
   f32x4* red = (f32x4*)lds_raw;
   static_assert(2 * CHUNK * sizeof(int) <= sizeof(lds_raw), "index arrays must fit");
-  const int k = blockIdx.y, chunk = blockIdx.x;
+  const int NTs = cout / 64;
+  int k, chunk, slab;
+  if (!wgrad_work(nchunks, kvol, (cin / 64) * NTs, chunk, k, slab)) return;
   const int Pk = num[k];
   const int p_begin = chunk * CHUNK;
   if (p_begin >= Pk) return;
   const int cnt = (Pk - p_begin) < CHUNK ? (Pk - p_begin) : CHUNK;
-  const int NTs = cout / 64;
-  const int sa = blockIdx.z / NTs, sb = blockIdx.z % NTs;
+  const int sa = slab / NTs, sb = slab % NTs;
   const int a0 = sa * 64, b0 = sb * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -807,16 +808,16 @@ namespace msmd {
 int wgrad_split_partials(const float* in_feat, int c_in, const float* d_out, int c_out,
                          const int32_t* pairs, const int32_t* num, int ld, int kvol, int np,
                          int nchunks, float* ws, hipStream_t st) {
-  const dim3 grid(nchunks, kvol, (c_in / 64) * (c_out / 64));
+  const dim3 grid(wgrad_grid(nchunks, kvol, (c_in / 64) * (c_out / 64)));
   if (np == 3)
     MSMD_LAUNCH(spconv_wgrad_split_kernel<3>, grid, dim3(256), 0, st, in_feat, c_in, d_out,
-                c_out, pairs, num, ld, nchunks, ws);
+                c_out, pairs, num, ld, nchunks, kvol, ws);
   else if (np == 2)
     MSMD_LAUNCH(spconv_wgrad_split_kernel<2>, grid, dim3(256), 0, st, in_feat, c_in, d_out,
-                c_out, pairs, num, ld, nchunks, ws);
+                c_out, pairs, num, ld, nchunks, kvol, ws);
   else
     MSMD_LAUNCH(spconv_wgrad_split_kernel<1>, grid, dim3(256), 0, st, in_feat, c_in, d_out,
-                c_out, pairs, num, ld, nchunks, ws);
+                c_out, pairs, num, ld, nchunks, kvol, ws);
   return launch_status();
 }
 }  // namespace msmd
