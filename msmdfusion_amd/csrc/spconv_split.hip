@@ -193,6 +193,22 @@ __device__ __forceinline__ void split_quarter(const u32x4& piece, int h, u32x4 (
   }
 }
 
+// Phase timing of one wave (build with `make PROF=1`; never in the shipped library):
+// s_memtime deltas of wave 1 of the first 8 workgroups, summed per phase.
+#ifdef MSMD_KERNEL_PROF
+__device__ unsigned long long g_kprof[16];
+#define KP_BEGIN() unsigned long long kp_t = __builtin_amdgcn_s_memtime()
+#define KP_MARK(i)                                                          \
+  {                                                                         \
+    const unsigned long long kp_n = __builtin_amdgcn_s_memtime();           \
+    if (lane == 0 && wave == 1 && blockIdx.x < 8) atomicAdd(&g_kprof[i], kp_n - kp_t); \
+    kp_t = kp_n;                                                            \
+  }
+#else
+#define KP_BEGIN()
+#define KP_MARK(i)
+#endif
+
 // ------------------------------------------------------- forward / dgrad --
 // One workgroup = 4 waves x 32 output rows (two 16-row MFMA groups per wave) x
 // all of c_out; persistent, drawing 128-row tiles from a global counter.
@@ -224,7 +240,12 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     const float* __restrict__ in, int n_in, int cin, const u32x4* __restrict__ wp,
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
     const int32_t* __restrict__ order, int* __restrict__ tile_counter, float* __restrict__ out,
-    int ldo, int cout, int nt_total, int mt0, int dbg) {
+    int ldo, int cout, int nt_total, int mt0, int ksl, int dbg) {
+  // ksl = 1: every 128-row tile is TWO scheduling units, each contracting over half of
+  // the k-blocks and adding its partial sums to a zeroed `out` with float atomics (two
+  // addends onto 0: the result does not depend on their order).  Twice the units on
+  // the same 512 workgroup slots: a shorter tail (simulated makespan / useful work of
+  // the 128-channel layers 2.01 -> 1.72).
   // `out` points at this pass's first output channel (tile mt0 of nt_total in the
   // packed weights), rows are ldo floats apart, `cout` channels are stored.
   constexpr int R = 2, kRows = 4 * R * 16;
@@ -245,7 +266,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int kbt = (cin + 31) >> 5;      // the last k-block may be partial (c_in % 8 == 0)
-  const int n_tiles = (n_out + kRows - 1) / kRows;
+  const int n_tiles = ((n_out + kRows - 1) / kRows) << ksl;   // scheduling units ("tiles" below)
   // every workgroup draws 1 + (tiles it processed) tickets: the draw that returns
   // this value is the last one of the launch and puts the counter back to 0
   const int last_ticket = n_tiles + (int)gridDim.x - 1;
@@ -262,7 +283,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     const int n_e = (kvol + (order ? 1 : 0)) * kRows;
     for (int e0 = wave * 64; e0 < n_e; e0 += 256) {
       const int e = e0 + lane, k = e >> 7;
-      int p = T * kRows + (e & (kRows - 1));
+      int p = (T >> ksl) * kRows + (e & (kRows - 1));
       p = p < n_out ? p : n_out - 1;
       const int32_t* src = k < kvol ? nbr + (size_t)k * ld + p : order + p;
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + e0), 4, 0, 0);
@@ -297,7 +318,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the tile-id atomic too)
     __builtin_amdgcn_s_barrier();
     const unsigned mask = __builtin_amdgcn_readfirstlane(ctl[tb]);
-    const int n_units = __builtin_popcount(mask) * kbt;
+    const int kb0 = (tile & ((1 << ksl) - 1)) * (kbt >> ksl);   // this unit's k-blocks
+    const int kb1 = kb0 + (kbt >> ksl);
+    const int n_units = __builtin_popcount(mask) * (kb1 - kb0);
     const int n_items = (n_units + UB - 1) / UB;
 
     f32x4 acc[R][NT];
@@ -308,10 +331,10 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
 
     // unit cursors (scalar): remaining-offset mask + k-block
     unsigned mw = mask, mg = mask, ms = mask;
-    int kbw = 0, kbg = 0, kbs = 0;
+    int kbw = kb0, kbg = kb0, kbs = kb0;
 #define MSMD_ADV(M, KB)          \
-  if (++(KB) == kbt) {           \
-    (KB) = 0;                    \
+  if (++(KB) == kb1) {           \
+    (KB) = kb0;                  \
     (M) &= (M)-1;                \
   }
     int s_next[R];
@@ -448,11 +471,14 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     const int v_cur = V_C;                                              \
     issue_g(RAW_C, V_C);                                                \
     load_src();                                                         \
+    KP_MARK(3);                                                         \
     if ((U) == 0)                                                       \
       wait_rows<kGr + kWp>(RAW_N);                                      \
     else                                                                \
       wait_rows<kGr>(RAW_N);                                            \
+    KP_MARK(4);                                                         \
     compute((IT), (U), CV_C, v_cur, RAW_N, CV_N);                       \
+    KP_MARK(5);                                                         \
   }
 #define MSMD_SLOT_UNIT(IT, U, S)                                        \
   if ((S) % 2 == 0) MSMD_UNIT(IT, U, raw0, vr0, cv0, raw1, vr1, cv1)    \
@@ -467,37 +493,58 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
       ctl[tb ^ 1] = 0;                                                                 \
       if (nxt_v == last_ticket) *tile_counter = 0;                                     \
     }                                                                                  \
+    KP_MARK(6);                                                                        \
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(UB * kGr) : "memory");         \
+    KP_MARK(0);                                                                        \
     __builtin_amdgcn_s_barrier();                                                      \
+    KP_MARK(1);                                                                        \
     if ((IT) == 1) {                                                                   \
       nxt = __builtin_amdgcn_readfirstlane(ctl[2]);                                    \
       if (nxt < n_tiles) stage_table(nxt, tb ^ 1);                                     \
       staged = true;                                                                   \
     }                                                                                  \
     issue_w((IT) + 1);                                                                 \
+    KP_MARK(2);                                                                        \
     MSMD_SLOT_UNIT(IT, 0, (PH)*UB + 0)                                                 \
     if (UB > 1) { MSMD_SLOT_UNIT(IT, 1, (PH)*UB + 1) }                                 \
     if (UB > 2) { MSMD_SLOT_UNIT(IT, 2, (PH)*UB + 2) }                                 \
     if (UB > 3) { MSMD_SLOT_UNIT(IT, 3, (PH)*UB + 3) }                                 \
   }
+    KP_BEGIN();
     for (int it = 0; it < n_items; it += 2) {
       MSMD_ITEM(it, 0);
       if (it + 1 < n_items) MSMD_ITEM(it + 1, 1);
     }
+#ifdef MSMD_KERNEL_PROF
+    if (lane == 0 && wave == 1 && blockIdx.x < 8) atomicAdd(&g_kprof[7], (unsigned long long)n_items);
+#endif
 #undef MSMD_ITEM
 #undef MSMD_SLOT_UNIT
 #undef MSMD_UNIT
 #undef MSMD_ADV
+    // The last units started gathers for units past the end (out-of-range: zeros).
+    // The compiler does not know those asm loads are still in flight and reuses the
+    // ring registers as epilogue temporaries: drain them first.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- epilogue: lane (j,q) holds out[row j][16n + 4q .. +3] ----
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int p = tile * kRows + lr[r];
+      const int p = (tile >> ksl) * kRows + lr[r];
       if (p >= n_out) continue;
       const int row = order ? tab[kvol * kRows + lr[r]] : p;
       float* o = out + (size_t)row * ldo + 4 * q;
+      if (ksl) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-        if (16 * n + 4 * q < cout) *(f32x4*)(o + 16 * n) = acc[r][n];
+        for (int n = 0; n < NT; ++n)
+          if (16 * n + 4 * q < cout) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) unsafeAtomicAdd(o + 16 * n + c, acc[r][n][c]);
+          }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          if (16 * n + 4 * q < cout) *(f32x4*)(o + 16 * n) = acc[r][n];
+      }
     }
     // ---- next tile ----
     if (!staged) {
@@ -529,11 +576,11 @@ template <int NT, int UB, int NP>
 int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                      int ld, int n_out, int kvol, int flip, const int32_t* order,
                      int* tile_counter, float* out, int ldo, int cout, int nt_total, int mt0,
-                     hipStream_t st) {
+                     int ksl, hipStream_t st) {
   constexpr int kRows = 128;
   const size_t smem = sizeof(u32x4) * 2 * UB * NP * NT * 64 +
                       sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 8);
-  const int n_tiles = ceil_div(n_out, kRows);
+  const int n_tiles = ceil_div(n_out, kRows) << ksl;
   int nblk = n_tiles;
   const int slots = 256 * split_slots_per_cu();
   if (nblk > slots) nblk = slots;
@@ -544,7 +591,7 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
     attr_smem = smem;
   }
   MSMD_LAUNCH(kern, dim3(nblk), dim3(256), smem, st, in, n_in, cin, (const u32x4*)wp, nbr, ld,
-              n_out, kvol, flip, order, tile_counter, out, ldo, cout, nt_total, mt0,
+              n_out, kvol, flip, order, tile_counter, out, ldo, cout, nt_total, mt0, ksl,
               env_int2("MSMD_DBG", 0));
   return launch_status();
 }
@@ -558,6 +605,16 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
   const int nt_total = (cout + 15) / 16;
   const int n_pass = (nt_total + 7) / 8;
   const int per = (nt_total + n_pass - 1) / n_pass;   // tiles per pass
+  // k-block split (MSMD_SPLIT_KB=1; off by default): when the row tiles alone leave
+  // the 512 slots a long tail (fewer than 2 tiles per slot) and the contraction has
+  // an even number of k-blocks.  Measured on the 128->128 layers: 477 us against
+  // 449 us -- the zero-fill, the atomic epilogue and twice the per-unit setup cost
+  // more than the shorter tail gives back.
+  static const int kb_split = env_int2("MSMD_SPLIT_KB", 0);
+  const int kbt = (cin + 31) / 32;
+  const int ksl = (kb_split && kbt % 2 == 0 && kbt >= 2 &&
+                   ceil_div(n_out, 128) < 2 * 256 * split_slots_per_cu()) ? 1 : 0;
+  if (ksl) hipMemsetAsync(out, 0, sizeof(float) * (size_t)n_out * cout, st);
   for (int ps = 0; ps < n_pass; ++ps) {
     const int mt0 = ps * per;
     const int tiles = (mt0 + per <= nt_total) ? per : nt_total - mt0;
@@ -566,7 +623,7 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
     int rc;
 #define MSMD_GO(NT_, UB_)                                                                      \
   rc = launch_fwd_split<NT_, UB_, NP>(in, n_in, cin, wp, nbr, ld, n_out, kvol, flip, order,   \
-                                      tile_counter, o, cout, width, nt_total, mt0, st)
+                                      tile_counter, o, cout, width, nt_total, mt0, ksl, st)
     if (tiles > 6) { MSMD_GO(8, 1); }
     else if (tiles > 4) { MSMD_GO(6, 1); }
     else if (tiles > 2) { MSMD_GO(4, 2); }
@@ -821,3 +878,16 @@ int wgrad_split_partials(const float* in_feat, int c_in, const float* d_out, int
   return launch_status();
 }
 }  // namespace msmd
+
+#ifdef MSMD_KERNEL_PROF
+// out[16] <- phase cycle sums (then cleared): 0 top wait, 1 barrier, 2 weight issue,
+// 3 gather issue + index fetch, 4 wait for rows, 5 convert + multiply, 6 loop glue,
+// 7 items
+MSMD_EXPORT int msmd_debug_kprof(unsigned long long* out) {
+  hipDeviceSynchronize();
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kprof), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_kprof), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
