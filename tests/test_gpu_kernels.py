@@ -344,6 +344,33 @@ def test_split_wgrad(dev, cin, cout, planes):
     np.testing.assert_allclose(dw2.cpu().numpy(), edw2, rtol=tol, atol=5 * tol)
 
 
+def test_split_conv_bf16_operands(dev):
+    """planes=1 (MSMD_CONV_PLANES=1): plain bf16 operands, fp32 accumulate -- the
+    arithmetic of configs[2]'s "bf16".  Equal to an fp64 evaluation on operands
+    rounded to bf16 (up to fp32 accumulation error), and within bf16's 2^-9 relative
+    operand rounding of the fp32 result."""
+    from msmdfusion_amd import kernels as K
+    shape = [11, 64, 64]
+    idx = S.random_voxel_indices(1500, 2, shape, seed=5)
+    n = idx.shape[0]
+    rng = np.random.RandomState(5)
+    f = rng.randn(n, 64).astype(np.float32)
+    w = (rng.randn(27, 64, 128) / np.sqrt(27 * 64)).astype(np.float32)
+    nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
+    fd, wd = t(f, dev), t(w, dev)
+    out = K.conv_forward_split(fd, K.pack_weight_split(wd, 1), nbr, n, 128, 1).double()
+    fb, wb = fd.bfloat16().double(), wd.bfloat16().double()
+    ref_b = torch.zeros(n, 128, dtype=torch.float64, device=dev)
+    ref = torch.zeros(n, 128, dtype=torch.float64, device=dev)
+    for k in range(27):
+        m = nbr[k] >= 0
+        rows = nbr[k][m].long()
+        ref_b[m] += fb[rows] @ wb[k]
+        ref[m] += fd.double()[rows] @ wd.double()[k]
+    assert (out - ref_b).abs().max().item() < 1e-5
+    assert (out - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+
+
 def test_split_conv_edges(dev):
     """Empty and tiny inputs, a single tile with padding rows, unsupported shapes."""
     from msmdfusion_amd import kernels as K
