@@ -270,6 +270,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(loss).item()
+    # untimed sanity step: every parameter and every gradient of the trained modules is
+    # finite (a skipped tile or a stale buffer shows up as NaN/garbage here, not in the rate)
+    loss = None
+    bev = net(clouds, virtual) if lc else net(clouds)
+    (bev * target).mean().backward()
+    bad = [n for n, p in model.named_parameters()
+           if p.requires_grad and (p.grad is None and "blocks_2D" not in n and "blocks_mix" not in n
+                                   or p.grad is not None and not torch.isfinite(p.grad).all())]
+    bad += [n for n, p in model.named_parameters() if not torch.isfinite(p).all()]
+    assert not bad, "non-finite parameters / gradients after the timed steps: %s" % bad[:5]
+    opt.zero_grad(set_to_none=True)
 
     if rank == 0:
         n_samples = args.steps * spg * world

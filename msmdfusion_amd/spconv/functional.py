@@ -39,6 +39,38 @@ def _wants_order(c_in, c_out):
     return c_out >= 64 and c_in % 16 == 0
 
 
+_SIDE_STREAMS = {}
+
+
+class _SideLaunch:
+    """Enqueue fn() on a per-device side stream behind everything the current
+    stream has queued; result() makes the current stream wait for it and hands
+    the tensor over.  MSMD_WGRAD_STREAM=0 (or enabled=False) runs fn inline."""
+
+    def __init__(self, fn, enabled=True):
+        self.event = None
+        if not enabled or os.environ.get("MSMD_WGRAD_STREAM", "1") == "0":
+            self.value = fn()
+            return
+        main = torch.cuda.current_stream()
+        key = main.device
+        side = _SIDE_STREAMS.get(key)
+        if side is None:
+            side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.value = fn()
+            self.event = torch.cuda.Event()
+            self.event.record(side)
+        self.main = main
+
+    def result(self):
+        if self.event is not None:
+            self.main.wait_event(self.event)
+            self.value.record_stream(self.main)
+        return self.value
+
+
 class _SparseConvFunction(Function):
     """indice_conv / indice_subm_conv / implicit_gemm in one: forward and dgrad
     are the same implicit-GEMM kernel, wgrad contracts over the pair lists."""
@@ -65,6 +97,19 @@ class _SparseConvFunction(Function):
         c_in, c_out = (weight.shape[-1], weight.shape[0]) if krsc else weight.shape[1:]
         grad_out = grad_out.contiguous()
         d_feat = d_w = None
+        if ctx.needs_input_grad[1]:
+            # wgrad and dgrad both need grad_out only: wgrad goes to a side stream,
+            # its thousands of short workgroups fill the CUs the persistent dgrad
+            # kernel leaves idle in its tail (half the wave slots on average)
+            pairs, num = rb.pairs()     # (cached; built on this stream if not yet)
+
+            def run_wgrad():
+                if conv_planes() in (1, 2, 3) and K.wgrad_split_supported(c_in, c_out):
+                    return K.conv_wgrad_split(features, grad_out, pairs, num, conv_planes(),
+                                              krsc_shape=weight.shape if krsc else None)
+                return K.conv_wgrad(features, grad_out, pairs, num,
+                                    krsc_shape=weight.shape if krsc else None)
+            wgrad_done = _SideLaunch(run_wgrad, enabled=ctx.needs_input_grad[0])
         if ctx.needs_input_grad[0] and _use_split(c_out, c_in, rb.nbr_fwd.shape[0]):
             np_ = conv_planes()
             packed_t = K.pack_weight_split(weight, np_, transpose=True, krsc=krsc)
@@ -81,13 +126,7 @@ class _SparseConvFunction(Function):
                 d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_bwd, rb.n_in, c_in,
                                         row_order=order)
         if ctx.needs_input_grad[1]:
-            pairs, num = rb.pairs()
-            if conv_planes() in (1, 2, 3) and K.wgrad_split_supported(c_in, c_out):
-                d_w = K.conv_wgrad_split(features, grad_out, pairs, num, conv_planes(),
-                                         krsc_shape=weight.shape if krsc else None)
-            else:
-                d_w = K.conv_wgrad(features, grad_out, pairs, num,
-                                   krsc_shape=weight.shape if krsc else None)
+            d_w = wgrad_done.result()
         return d_feat, d_w, None, None
 
 

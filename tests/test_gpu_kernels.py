@@ -371,6 +371,35 @@ def test_split_conv_bf16_operands(dev):
     assert (out - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
 
 
+def test_split_conv_under_cu_contention(dev):
+    """The persistent kernels' tile counter must be back at 0 after every launch
+    even when workgroups become resident late because another stream holds the
+    CUs (wgrad on its side stream, RCCL under DDP): a late workgroup can draw the
+    launch's last ticket with its very first draw."""
+    from msmdfusion_amd import kernels as K
+    shape = [21, 128, 128]
+    idx = S.random_voxel_indices(40000, 2, shape, seed=3)
+    n = idx.shape[0]
+    nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
+    order = K.row_mask_order(nbr)
+    nbr_t = K.permute_cols(nbr, order)
+    f = torch.randn(n, 64, device=dev)
+    ws = K.pack_weight_split(torch.randn(27, 64, 64, device=dev) * 0.05, 3)
+    ref = K.conv_forward_split(f, ws, nbr_t, n, 64, 3, row_order=order)
+    torch.cuda.synchronize()
+    hog = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device=dev)
+    for rep in range(6):
+        with torch.cuda.stream(hog):
+            for _ in range(4):
+                a = torch.mm(a, a) * 1e-4        # chip-filling GEMMs on the other stream
+        outs = [K.conv_forward_split(f, ws, nbr_t, n, 64, 3, row_order=order) for _ in range(4)]
+        for o in outs:
+            assert torch.equal(o, ref)
+        assert int(K._tile_counter(f.device).item()) == 0
+    torch.cuda.synchronize()
+
+
 def test_split_conv_edges(dev):
     """Empty and tiny inputs, a single tile with padding rows, unsupported shapes."""
     from msmdfusion_amd import kernels as K
