@@ -216,7 +216,7 @@ int msmd_spconv_fwd_split(const float* in_feat /* [n_in,c_in] */, int n_in, int 
                           msmd_stream_t stream);
 
 /* wgrad with the same operand splitting (both operands are read as fp32 and
- * split in registers); c_in and c_out multiples of 64.  Workspace as
+ * split in registers); c_in, c_out >= 64 and multiples of 4.  Workspace as
  * msmd_spconv_wgrad_workspace_bytes. */
 int msmd_spconv_wgrad_split_supported(int c_in, int c_out);
 

@@ -896,7 +896,9 @@ int wgrad_split_partials(const float* in_feat, int c_in, const float* d_out, int
 }
 
 MSMD_EXPORT int msmd_spconv_wgrad_split_supported(int c_in, int c_out) {
-  return c_in > 0 && c_out > 0 && c_in % 64 == 0 && c_out % 64 == 0;
+  // 64x64 channel slabs, the last one of a side possibly partial (16-byte pieces);
+  // below 64 channels a slab is mostly padding: the fp32 kernel's narrow slabs win
+  return c_in >= 64 && c_out >= 64 && c_in % 4 == 0 && c_out % 4 == 0;
 }
 
 MSMD_EXPORT int msmd_spconv_wgrad_split(const float* in_feat, int c_in, const float* d_out,
@@ -915,7 +917,7 @@ MSMD_EXPORT int msmd_spconv_wgrad_split(const float* in_feat, int c_in, const fl
     return launch_status();
   }
   if (!in_feat || !d_out || !indice_pairs) return MSMD_ERR_INVALID_ARG;
-  const int chunk = 2048;   // = wgrad_chunk() for every supported shape
+  const int chunk = 2048;   // = wgrad_chunk() for every supported shape (c_in * c_out >= 4096)
   const int nchunks = ceil_div(ld, chunk);
   if (workspace_bytes < sizeof(float) * (size_t)kernel_volume * nchunks * per_k ||
       ((uintptr_t)workspace & 255))

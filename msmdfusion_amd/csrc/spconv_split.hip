@@ -681,9 +681,9 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_split_kernel(
   int* s_out = s_in + CHUNK;
   f32x4* red = (f32x4*)lds_raw;
   static_assert(2 * CHUNK * sizeof(int) <= sizeof(lds_raw), "index arrays must fit");
-  const int NTs = cout / 64;
+  const int NTs = (cout + 63) / 64;   // slabs may be partial: c_in, c_out % 4 == 0
   int k, chunk, slab;
-  if (!wgrad_work(nchunks, kvol, (cin / 64) * NTs, chunk, k, slab)) return;
+  if (!wgrad_work(nchunks, kvol, ((cin + 63) / 64) * NTs, chunk, k, slab)) return;
   const int Pk = num[k];
   const int p_begin = chunk * CHUNK;
   if (p_begin >= Pk) return;
@@ -710,6 +710,7 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_split_kernel(
 
   const float* pa = in + a0 + 4 * i;
   const float* pb = dout + b0 + 4 * i;
+  const bool in_a = a0 + 4 * i < cin, in_b = b0 + 4 * i < cout;   // this lane's channels exist
   f32x4 ra[8], rb[8];   // this lane's 8 pairs x 4 channels, both sides
   auto fetch = [&](int step) {
     const int e0 = 32 * step + 8 * g;
@@ -718,10 +719,10 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_split_kernel(
       const i32x4 ia = *(const i32x4*)(s_in + e0 + 4 * h), ib = *(const i32x4*)(s_out + e0 + 4 * h);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        ra[4 * h + s] = ia[s] >= 0 ? *(const f32x4*)(pa + (size_t)ia[s] * cin)
-                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
-        rb[4 * h + s] = ib[s] >= 0 ? *(const f32x4*)(pb + (size_t)ib[s] * cout)
-                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
+        ra[4 * h + s] = (ia[s] >= 0 && in_a) ? *(const f32x4*)(pa + (size_t)ia[s] * cin)
+                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
+        rb[4 * h + s] = (ib[s] >= 0 && in_b) ? *(const f32x4*)(pb + (size_t)ib[s] * cout)
+                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
   };
@@ -791,7 +792,8 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_split_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ci = a0 + 4 * (4 * g + r) + a;
-        *(f32x4*)(dst + (size_t)ci * cout + cb) = (f32x4){v[0][r], v[1][r], v[2][r], v[3][r]};
+        if (ci < cin && cb < cout)
+          *(f32x4*)(dst + (size_t)ci * cout + cb) = (f32x4){v[0][r], v[1][r], v[2][r], v[3][r]};
       }
     }
   }
@@ -874,7 +876,7 @@ namespace msmd {
 int wgrad_split_partials(const float* in_feat, int c_in, const float* d_out, int c_out,
                          const int32_t* pairs, const int32_t* num, int ld, int kvol, int np,
                          int nchunks, float* ws, hipStream_t st) {
-  const dim3 grid(wgrad_grid(nchunks, kvol, (c_in / 64) * (c_out / 64)));
+  const dim3 grid(wgrad_grid(nchunks, kvol, ((c_in + 63) / 64) * ((c_out + 63) / 64)));
   if (np == 3)
     MSMD_LAUNCH(spconv_wgrad_split_kernel<3>, grid, dim3(256), 0, st, in_feat, c_in, d_out,
                 c_out, pairs, num, ld, nchunks, kvol, ws);

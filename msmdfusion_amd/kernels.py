@@ -340,7 +340,7 @@ def wgrad_split_supported(c_in, c_out):
 
 def conv_wgrad_split(feat, d_out, pairs, num, planes=3, krsc_shape=None):
     """conv_wgrad at bf16 MFMA rate (operands split into `planes` bf16 planes in
-    registers; planes=3 is fp32-equivalent).  c_in, c_out multiples of 64."""
+    registers; planes=3 is fp32-equivalent).  c_in, c_out >= 64, multiples of 4."""
     _need_cuda(feat, d_out, pairs, num)
     f, g = feat.contiguous().float(), d_out.contiguous().float()
     kvol, _, ld = pairs.shape
