@@ -848,6 +848,8 @@ MSMD_EXPORT int msmd_spconv_fwd_split(const float* planes, int n_in, int cin, co
     return MSMD_ERR_UNSUPPORTED;
   if (!tile_counter) return MSMD_ERR_INVALID_ARG;
   if (n_out <= 0) return MSMD_OK;
+  // the gathers address the features through a 32-bit buffer offset
+  if ((size_t)n_in * cin * sizeof(float) >= (size_t)kOobOffset) return MSMD_ERR_RANGE;
   if (np == 3)
     return dispatch_fwd_split<3>(planes, n_in, cin, packed, nbr, ld, n_out, kvol, weight_flip,
                                  row_order, tile_counter, out, cout, st);

@@ -26,10 +26,11 @@ def conv_planes():
     return int(os.environ.get("MSMD_CONV_PLANES", "3"))
 
 
-def _use_split(c_in, c_out, kvol):
+def _use_split(c_in, c_out, kvol, n_in=0):
     # the kernel also takes c_in % 8 == 0, but with a partial last k-block (the
-    # fusion stack's 80-channel layers) the fp32 kernel is faster: 118 vs 160 us
-    return (conv_planes() in (1, 2, 3) and c_in % 32 == 0
+    # fusion stack's 80-channel layers) the fp32 kernel is faster: 118 vs 160 us.
+    # Its gathers use 32-bit byte offsets: features beyond 4 GiB go the fp32 way.
+    return (conv_planes() in (1, 2, 3) and c_in % 32 == 0 and n_in * c_in * 4 < 0xFFFFFF00
             and K.split_supported(c_in, c_out, kvol))
 
 
@@ -80,7 +81,7 @@ class _SparseConvFunction(Function):
         ctx.rb, ctx.krsc = rb, krsc
         ctx.save_for_backward(features, weight)
         c_in, c_out = (weight.shape[-1], weight.shape[0]) if krsc else weight.shape[1:]
-        if _use_split(c_in, c_out, rb.nbr_fwd.shape[0]):
+        if _use_split(c_in, c_out, rb.nbr_fwd.shape[0], features.shape[0]):
             np_ = conv_planes()
             packed = K.pack_weight_split(weight, np_, krsc=krsc)
             table, order = rb.tiling_fwd()
@@ -110,7 +111,8 @@ class _SparseConvFunction(Function):
                 return K.conv_wgrad(features, grad_out, pairs, num,
                                     krsc_shape=weight.shape if krsc else None)
             wgrad_done = _SideLaunch(run_wgrad, enabled=ctx.needs_input_grad[0])
-        if ctx.needs_input_grad[0] and _use_split(c_out, c_in, rb.nbr_fwd.shape[0]):
+        if ctx.needs_input_grad[0] and _use_split(c_out, c_in, rb.nbr_fwd.shape[0],
+                                                  grad_out.shape[0]):
             np_ = conv_planes()
             packed_t = K.pack_weight_split(weight, np_, transpose=True, krsc=krsc)
             table, order = rb.tiling_bwd()
