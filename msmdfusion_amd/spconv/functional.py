@@ -46,11 +46,15 @@ _SIDE_STREAMS = {}
 class _SideLaunch:
     """Enqueue fn() on a per-device side stream behind everything the current
     stream has queued; result() makes the current stream wait for it and hands
-    the tensor over.  MSMD_WGRAD_STREAM=0 (or enabled=False) runs fn inline."""
+    the tensor over.  Opt-in (MSMD_WGRAD_STREAM=1): measured +2 % on configs[1],
+    +3 % on the LC path, gradients bit-identical -- but two kernels sharing the
+    chip stretch each other's launch durations, which blurs the per-kernel
+    roofline figures bench.py and rocprofv3 report, so the default keeps one
+    kernel at a time."""
 
     def __init__(self, fn, enabled=True):
         self.event = None
-        if not enabled or os.environ.get("MSMD_WGRAD_STREAM", "1") == "0":
+        if not enabled or os.environ.get("MSMD_WGRAD_STREAM", "0") != "1":
             self.value = fn()
             return
         main = torch.cuda.current_stream()
@@ -99,9 +103,9 @@ class _SparseConvFunction(Function):
         grad_out = grad_out.contiguous()
         d_feat = d_w = None
         if ctx.needs_input_grad[1]:
-            # wgrad and dgrad both need grad_out only: wgrad goes to a side stream,
-            # its thousands of short workgroups fill the CUs the persistent dgrad
-            # kernel leaves idle in its tail (half the wave slots on average)
+            # wgrad and dgrad both need grad_out only: with MSMD_WGRAD_STREAM=1 wgrad
+            # goes to a side stream and its thousands of short workgroups fill the CUs
+            # the persistent dgrad kernel leaves idle in its tail
             pairs, num = rb.pairs()     # (cached; built on this stream if not yet)
 
             def run_wgrad():
