@@ -74,9 +74,16 @@ class Backbone(torch.nn.Module):
             coors.append(F.pad(c, (1, 0), mode="constant", value=b))
         return torch.cat(feats, 0), torch.cat(coors, 0)
 
-    def forward(self, points):
+    def prepare(self, points):
+        """The index-only part of a step (needs no weights, no previous step):
+        voxelization + every rulebook / tiling order / pair list of the encoder."""
         feats, coors = self.voxelize(points)
-        bev, _ = self.middle_encoder(feats, coors, len(points))
+        planned, _ = self.middle_encoder.plan(coors, len(points))
+        return feats, coors, planned
+
+    def forward(self, points, prepared=None):
+        feats, coors, planned = prepared if prepared is not None else self.prepare(points)
+        bev, _ = self.middle_encoder(feats, coors, len(points), planned=planned)
         return bev
 
 
@@ -220,20 +227,33 @@ def main():
         if lc else None
     target = torch.randn(spg, 640 if lc else 256, 180, 180, device=dev)
 
+    prefetch = None
+    if not lc and os.environ.get("MSMD_PREFETCH", "1") == "1":
+        from msmdfusion_amd.prefetch import IndexPrefetcher
+        prefetch = IndexPrefetcher(model.prepare, dev)
+        pending = [prefetch.submit(clouds)]
+
     def step():
-        bev = net(clouds, virtual) if lc else net(clouds)
+        if prefetch is not None:
+            pending.append(prefetch.submit(clouds))      # next step's batch
+            ticket = pending.pop(0)
+            bev = net(clouds, prepared=prefetch.take(ticket))
+        else:
+            bev = net(clouds, virtual) if lc else net(clouds)
         loss = (bev * target).mean()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 10.0)     # grad_clip max_norm=10 (config)
         opt.step()
         opt.zero_grad(set_to_none=True)
+        if prefetch is not None:
+            prefetch.retire(ticket)
         return loss
 
     # Setup, untimed: let torch's caching allocator reach its steady state before
     # the W warm-up steps.  The LC path allocates on two streams (record_stream
     # defers block reuse), and needs ~8 steps before no step calls hipMalloc any
     # more (37 ms -> 28 ms per step, tools/lc_steps.py).
-    for _ in range(10 if lc else 2):
+    for _ in range(10 if (lc or prefetch is not None) else 2):
         step()
     for _ in range(args.warmup):
         step()
@@ -300,7 +320,8 @@ def main():
                                     "configs[1]: TransFusion-L voxel backbone (voxelize+VFE+"
                                     "SparseEncoder->BEV), fwd+bwd+AdamW, 4 synthetic ~28.7k-pt "
                                     "clouds/GPU, 0.075 m voxels, fp32"),
-                       "global_batch": spg * world, "parallelism": "dp%d" % world},
+                       "global_batch": spg * world, "parallelism": "dp%d" % world,
+                       "index_prefetch": prefetch is not None},
         }
         out["roofline"] = roofline(prof) if prof else None
         if world == 1 and not args.no_cpu_baseline and not lc:

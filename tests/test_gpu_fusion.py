@@ -200,3 +200,40 @@ def test_sparse_fusion_path_end_to_end(dev):
     dead = [n for n, p in path.named_parameters() if p.grad is None]
     assert all(("blocks_2D" in n or "blocks_mix" in n) for n in dead), dead   # built, never called
     assert any("gate_control" in n for n in used)
+
+
+@pytest.mark.gpu
+def test_index_prefetch_matches_inline(dev):
+    """bench.py's step pipelining: voxelization + rulebooks of batch i+1 built on
+    a side stream while batch i's feature pass runs (msmdfusion_amd/prefetch.py).
+    Same BEV map and the same weight gradients, bit for bit, as the inline order,
+    over several steps with a different batch each (lifetime of the handed-over
+    tables across streams)."""
+    import bench
+    from msmdfusion_amd import synthetic as S
+    from msmdfusion_amd.prefetch import IndexPrefetcher
+    torch.manual_seed(0)
+    model = bench.Backbone().to(dev).train()
+    batches = [[torch.from_numpy(S.lidar_sweep(2 * i + j)).to(dev) for j in range(2)]
+               for i in range(4)]
+
+    def run(bev):
+        model.zero_grad(set_to_none=True)
+        bev.square().mean().backward()
+        return bev.detach().clone(), [p.grad.clone() for p in model.parameters()
+                                      if p.grad is not None]
+
+    want = [run(model(b)) for b in batches]
+    pf = IndexPrefetcher(model.prepare, dev)
+    pending = [pf.submit(batches[0])]
+    for i, b in enumerate(batches):
+        if i + 1 < len(batches):
+            pending.append(pf.submit(batches[i + 1]))
+        ticket = pending.pop(0)
+        bev, grads = run(model(b, prepared=pf.take(ticket)))
+        pf.retire(ticket)
+        assert torch.equal(bev, want[i][0])
+        assert len(grads) == len(want[i][1])
+        for g, w in zip(grads, want[i][1]):
+            assert torch.equal(g, w)
+    assert len(pf._retired) <= pf.max_behind + 1
