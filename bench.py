@@ -111,8 +111,12 @@ class FusionBackbone(torch.nn.Module):
         freeze_unused_fusion_blocks(mm)     # built, never called: no find_unused_parameters
         self.path = SparseFusionPath(vox, enc, mm)
 
-    def forward(self, points, virtual):
-        x, x_mm = self.path(points, [virtual] * 4)
+    def prepare(self, points, virtual):
+        """Index-only part of a step, for the prefetcher (its own stream, a step ahead)."""
+        return self.path.prepare(points, [virtual] * 4, nn_side_stream=False)
+
+    def forward(self, points, virtual, prepared=None):
+        x, x_mm = self.path(points, [virtual] * 4, prepared=prepared)
         return torch.cat([x, x_mm], 1)
 
 
@@ -228,16 +232,17 @@ def main():
     target = torch.randn(spg, 640 if lc else 256, 180, 180, device=dev)
 
     prefetch = None
-    if not lc and os.environ.get("MSMD_PREFETCH", "1") == "1":
+    if os.environ.get("MSMD_PREFETCH", "1") == "1":
         from msmdfusion_amd.prefetch import IndexPrefetcher
         prefetch = IndexPrefetcher(model.prepare, dev)
-        pending = [prefetch.submit(clouds)]
+        batch = (clouds, virtual) if lc else (clouds,)
+        pending = [prefetch.submit(*batch)]
 
     def step():
         if prefetch is not None:
-            pending.append(prefetch.submit(clouds))      # next step's batch
+            pending.append(prefetch.submit(*batch))      # next step's batch
             ticket = pending.pop(0)
-            bev = net(clouds, prepared=prefetch.take(ticket))
+            bev = net(*batch, prepared=prefetch.take(ticket))
         else:
             bev = net(clouds, virtual) if lc else net(clouds)
         loss = (bev * target).mean()

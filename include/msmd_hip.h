@@ -317,6 +317,17 @@ int msmd_sparse_add_fill(const float* feat_a, const int32_t* idx_a, int n_a,
                          int32_t* map_a /* [n_a] */, int32_t* map_b /* [n_b] */,
                          void* workspace, size_t workspace_bytes,
                          msmd_stream_t stream);
+/* c == 0 makes msmd_sparse_add_fill an index-only pass (out_indices + maps; the
+ * feature pointers may be NULL).  msmd_sparse_add_rows is then the feature half
+ * on its own: out_feat[map_a[i]] += feat_a[i], out_feat[map_b[j]] += feat_b[j]
+ * over a zeroed out_feat -- the same sums as the fused call, bit for bit (at
+ * most two addends per element).  Together they let a caller that knows the
+ * coordinate sets ahead of the features (step pipelining) keep the host read of
+ * n_out off the feature pass. */
+int msmd_sparse_add_rows(const float* feat_a, const int32_t* map_a, int n_a,
+                         const float* feat_b, const int32_t* map_b, int n_b,
+                         int c, int n_out, float* out_feat /* [n_out,c] */,
+                         msmd_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * a14  voxel_modality_split: LiDAR voxels vs virtual-point voxels

@@ -95,6 +95,20 @@ __global__ __launch_bounds__(256) void add_rows(const float* __restrict__ feat,
     unsafeAtomicAdd(&out_feat[(size_t)o * c + ch], feat[(size_t)i * c + ch]);
 }
 
+// the feature half alone, rows routed by the maps of an earlier index pass
+__global__ __launch_bounds__(256) void add_mapped_rows(const float* __restrict__ feat,
+                                                       const int32_t* __restrict__ map, int n,
+                                                       int c, int n_out,
+                                                       float* __restrict__ out_feat) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int i = (int)(t >> 4), sub = (int)(t & 15);
+  if (i >= n) return;
+  const int o = map[i];
+  if (o < 0 || o >= n_out) return;
+  for (int ch = sub; ch < c; ch += 16)
+    unsafeAtomicAdd(&out_feat[(size_t)o * c + ch], feat[(size_t)i * c + ch]);
+}
+
 // ------------------------------------------------------- modality split ----
 __global__ __launch_bounds__(256) void and_words(uint32_t* a, const uint32_t* __restrict__ b,
                                                  size_t words) {
@@ -228,20 +242,39 @@ MSMD_EXPORT int msmd_sparse_add_fill(const float* feat_a, const int32_t* idx_a, 
   Shape3 sh;
   int rc = check_grid(batch_size, spatial_shape, &sh);
   if (rc) return rc;
-  if (n_a < 0 || n_b < 0 || c < 1 || n_out < 0 || (n_out > 0 && (!out_indices || !out_feat)))
+  // c == 0: index-only pass (out_indices + maps; no feature pointer is touched)
+  if (n_a < 0 || n_b < 0 || c < 0 || n_out < 0 ||
+      (n_out > 0 && (!out_indices || (c > 0 && !out_feat))))
     return MSMD_ERR_INVALID_ARG;
   Arena a(workspace, workspace_bytes);
   SetWs w;
   carve_set(a, &w, batch_size, spatial_shape, false);
   if (!a.ok()) return MSMD_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  if (n_out > 0) hipMemsetAsync(out_feat, 0, sizeof(float) * (size_t)n_out * c, st);
+  if (n_out > 0 && c > 0) hipMemsetAsync(out_feat, 0, sizeof(float) * (size_t)n_out * c, st);
   if (n_a > 0)
     MSMD_LAUNCH(add_rows, dim3(ceil_div((long)n_a * 16, 256)), dim3(256), 0, st, feat_a,
                        idx_a, n_a, c, sh, w.bits, w.prefix, n_out, out_indices, out_feat, map_a);
   if (n_b > 0)
     MSMD_LAUNCH(add_rows, dim3(ceil_div((long)n_b * 16, 256)), dim3(256), 0, st, feat_b,
                        idx_b, n_b, c, sh, w.bits, w.prefix, n_out, out_indices, out_feat, map_b);
+  return launch_status();
+}
+
+MSMD_EXPORT int msmd_sparse_add_rows(const float* feat_a, const int32_t* map_a, int n_a,
+                                     const float* feat_b, const int32_t* map_b, int n_b, int c,
+                                     int n_out, float* out_feat, msmd_stream_t stream) {
+  if (n_a < 0 || n_b < 0 || c < 1 || n_out < 0 || (n_out > 0 && !out_feat) ||
+      (n_a > 0 && (!feat_a || !map_a)) || (n_b > 0 && (!feat_b || !map_b)))
+    return MSMD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_out > 0) hipMemsetAsync(out_feat, 0, sizeof(float) * (size_t)n_out * c, st);
+  if (n_a > 0)
+    MSMD_LAUNCH(add_mapped_rows, dim3(ceil_div((long)n_a * 16, 256)), dim3(256), 0, st, feat_a,
+                       map_a, n_a, c, n_out, out_feat);
+  if (n_b > 0)
+    MSMD_LAUNCH(add_mapped_rows, dim3(ceil_div((long)n_b * 16, 256)), dim3(256), 0, st, feat_b,
+                       map_b, n_b, c, n_out, out_feat);
   return launch_status();
 }
 

@@ -92,16 +92,16 @@ class SparseFusionPath(nn.Module):
         self.dist_thresh_list = list(dist_thresh_list)
         self.base_voxel_size = list(base_voxel_size)
 
-    def forward(self, points, virtual_points_per_stage):
-        """points: list of B [N,5] clouds; virtual_points_per_stage: 4 lists of
-        B [Nv,64] tensors (what get_foreground2D yields per image scale).
+    def prepare(self, points, virtual_points_per_stage, nn_side_stream=True):
+        """Everything of a step that depends on the INPUTS alone (no weights, no
+        previous step): LiDAR voxelization, the encoder's rulebooks, the
+        virtual-point voxels, the modality split and the FPS / nearest-voxel
+        search of all four stages (9 of the step's 38 ms, two workgroups wide).
 
-        Order of work (results are those of MSMDFusion.py:421-443; only the
-        schedule differs): everything that depends on voxel COORDINATES only --
-        the encoder's rulebooks, the virtual-point voxels, the modality split and
-        the FPS / nearest-voxel search of all four stages (9 of the step's 38 ms,
-        two workgroups wide) -- is planned first; the neighbour search then runs
-        on a side stream underneath the LiDAR encoder's feature pass."""
+        nn_side_stream=True enqueues the neighbour search on a high-priority side
+        stream so that it runs underneath the LiDAR encoder's feature pass of the
+        SAME step; a caller that runs prepare() a step ahead on its own stream
+        (msmdfusion_amd/prefetch.py) passes False."""
         B = len(points)
         enc, mm = self.pts_middle_encoder, self.multimodal_middle_encoder
         feats, _, coors = voxelize_batch(self.pts_voxel_layer, points, 1.0, self.base_voxel_size,
@@ -117,23 +117,46 @@ class SparseFusionPath(nn.Module):
             i3, voxel_2D.indices, pa, pb = modality_split_indices(idx3, voxel_2D.indices, B, shape)
             v2.append(voxel_2D); idx3_5.append(i3); s3.append(pa); s2.append(pb)
             plans.append(mm.plan_stage_rows(i3, voxel_2D.indices, B))
-        counts = torch.stack([p["counts"] for p in plans]).tolist()   # the only host read
+        # the fusion stack's own voxel sets and rulebooks, stage by stage (each needs
+        # the previous stage's output set).  Before the neighbour search is enqueued:
+        # these calls read counts back, and must not wait behind 9 ms of FPS
+        need_grad = torch.is_grad_enabled()
+        prev = None
+        for i in range(4):
+            prev = mm.plan_stage_tensors(plans[i], idx3_5[i], v2[i].indices, s2[i], stages[i][1],
+                                         self.spatial_shapes[i], B, i, prev, need_grad)
+        counts = torch.stack([p["counts"] for p in plans]).tolist()
         main = torch.cuda.current_stream()
-        side = self._side_stream(feats.device)
+        side = self._side_stream(feats.device) if nn_side_stream else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
             for i in range(4):
                 mm.plan_stage_nn(plans[i], counts[i], B, self.fps_num_list[i],
                                  self.radius_list[i], self.max_cluster_samples_list[i],
                                  self.dist_thresh_list[i])
-                plans[i]["nn3"].record_stream(main)
-                plans[i]["ready"] = torch.cuda.Event()
-                plans[i]["ready"].record(side)
-        x, encode_features = enc(feats, coors, B, planned=planned)
-        v3 = [spconv.SparseConvTensor(encode_features[i].features, idx3_5[i], stages[i][1], B)
-              for i in range(4)]
-        stage_outs = mm(v3, v2, s3, s2, self.fps_num_list, self.radius_list,
-                        self.max_cluster_samples_list, self.dist_thresh_list, stage_plans=plans)
+                if nn_side_stream:
+                    plans[i]["nn3"].record_stream(main)
+                    plans[i]["ready"] = torch.cuda.Event()
+                    plans[i]["ready"].record(side)
+        return dict(feats=feats, coors=coors, planned=planned, stages=stages, v2=v2,
+                    idx3_5=idx3_5, s3=s3, s2=s2, plans=plans)
+
+    def forward(self, points, virtual_points_per_stage, prepared=None):
+        """points: list of B [N,5] clouds; virtual_points_per_stage: 4 lists of
+        B [Nv,64] tensors (what get_foreground2D yields per image scale).
+
+        Order of work (results are those of MSMDFusion.py:421-443; only the
+        schedule differs): the index-only part (prepare) first, then the two
+        feature passes.  `prepared` = a prepare() result computed ahead of time."""
+        B = len(points)
+        enc, mm = self.pts_middle_encoder, self.multimodal_middle_encoder
+        p = prepared if prepared is not None else self.prepare(points, virtual_points_per_stage)
+        x, encode_features = enc(p["feats"], p["coors"], B, planned=p["planned"])
+        v3 = [spconv.SparseConvTensor(encode_features[i].features, p["idx3_5"][i],
+                                      p["stages"][i][1], B) for i in range(4)]
+        stage_outs = mm(v3, p["v2"], p["s3"], p["s2"], self.fps_num_list, self.radius_list,
+                        self.max_cluster_samples_list, self.dist_thresh_list,
+                        stage_plans=p["plans"])
         mm_dense = stage_outs[-1].dense()
         n, c, d, h, w = mm_dense.shape
         return x, mm_dense.view(n, c * d, h, w)

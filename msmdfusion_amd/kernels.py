@@ -445,6 +445,40 @@ def sparse_add(feat_a, idx_a, feat_b, idx_b, batch_size, spatial_shape):
     return oi, of, ma, mb
 
 
+def sparse_add_index(idx_a, idx_b, batch_size, spatial_shape):
+    """Index half of sparse_add -> (out_indices[m,4], map_a[na], map_b[nb])."""
+    _need_cuda(idx_a, idx_b)
+    ia, ib = idx_a.contiguous().int(), idx_b.contiguous().int()
+    na, nb = ia.shape[0], ib.shape[0]
+    dev = ia.device
+    nbytes = lib.msmd_sparse_add_workspace_bytes(int(batch_size), int3(spatial_shape))
+    ws = _ws(nbytes, dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    check(lib.msmd_sparse_add_count(_p(ia), na, _p(ib), nb, int(batch_size), int3(spatial_shape),
+                                    _p(count), _p(ws), nbytes, _stream()), "msmd_sparse_add_count")
+    m = int(count.item())
+    oi = torch.empty((m, 4), dtype=torch.int32, device=dev)
+    ma = torch.empty((na,), dtype=torch.int32, device=dev)
+    mb = torch.empty((nb,), dtype=torch.int32, device=dev)
+    check(lib.msmd_sparse_add_fill(None, _p(ia), na, None, _p(ib), nb, 0, int(batch_size),
+                                   int3(spatial_shape), m, _p(oi), None, _p(ma), _p(mb), _p(ws),
+                                   nbytes, _stream()), "msmd_sparse_add_fill")
+    return oi, ma, mb
+
+
+def sparse_add_rows(feat_a, map_a, feat_b, map_b, n_out):
+    """Feature half of sparse_add with the maps of sparse_add_index (no host read)."""
+    _need_cuda(feat_a, map_a, feat_b, map_b)
+    fa, fb = feat_a.contiguous().float(), feat_b.contiguous().float()
+    assert fa.shape[1] == fb.shape[1] and map_a.dtype == map_b.dtype == torch.int32
+    assert map_a.shape[0] == fa.shape[0] and map_b.shape[0] == fb.shape[0]
+    of = torch.empty((int(n_out), fa.shape[1]), dtype=torch.float32, device=fa.device)
+    check(lib.msmd_sparse_add_rows(_p(fa), _p(map_a.contiguous()), fa.shape[0], _p(fb),
+                                   _p(map_b.contiguous()), fb.shape[0], fa.shape[1], int(n_out),
+                                   _p(of), _stream()), "msmd_sparse_add_rows")
+    return of
+
+
 def modality_split(idx_3d, idx_2d, batch_size, spatial_shape):
     """-> (mix3d[n3], mix2d[n2], pair_3d[m], pair_2d[m])"""
     _need_cuda(idx_3d, idx_2d)

@@ -199,6 +199,46 @@ class SparseMultiModalEncoderPaint(nn.Module):
                                                  dist_thresh, counts=counts)
         return plan
 
+    def plan_stage_tensors(self, plan, idx3_5, idx2_5, syn_mix_2D, shape3, shape2, batch_size,
+                           stage_id, prev, need_grad):
+        """The rest of a stage's index-only work, given plan_stage_rows' result:
+        the voxel sets grouped_sparse_conv / forward build (only-3D, unified,
+        the sparse_add union with the previous stage's output), every rulebook of
+        the stage's conv blocks on them, and the per-call dummy embedding.  With
+        this in `plan` the feature pass reads nothing back from the device.
+        `prev` = the index-only output tensor of the previous stage (None for the
+        first); returns this stage's."""
+        zyx = [0, 2, 3, 4]
+        stage = f"stage_{stage_id + 1}"
+        dev = idx3_5.device
+
+        def shell(idx, shape):
+            return spconv.SparseConvTensor(
+                torch.empty((idx.shape[0], 0), dtype=torch.float32, device=dev), idx, shape,
+                batch_size)
+
+        def convs(block):
+            return [m for m in block.modules() if isinstance(m, spconv.SparseConvolution)]
+
+        plan["dummy"] = self.dummy_embedding_fn(self.in_channels_3D[stage_id], dev)
+        o3_idx = idx3_5.index_select(0, plan["only_3D_rows"])[:, zyx].contiguous()
+        only3d = shell(o3_idx, shape3)
+        only3d.plan(convs(getattr(self.grouped_sp_conv_blocks_3D, stage)), need_grad)
+        n_mix = syn_mix_2D.shape[0]
+        mixed_idx, _ = self.pad_missing_batch_id(
+            idx2_5.index_select(0, syn_mix_2D),
+            torch.empty((n_mix, 0), dtype=torch.float32, device=dev), batch_size)
+        unified = shell(torch.cat([o3_idx, plan["o2_idx"][:, zyx], mixed_idx[:, zyx]],
+                                  0).contiguous(), shape2)
+        unified.plan(convs(getattr(self.aggregation_blocks, stage)), need_grad)
+        total = unified
+        if prev is not None:
+            assert prev.spatial_shape == list(shape2), "sparse_add needs equal spatial_shape"
+            plan["add"] = Fsp.plan_sparse_add(unified.indices, prev.indices, batch_size, shape2)
+            total = plan["add"]["sum"]
+        plan.update(only3d=only3d, unified=unified, mixed_pad=mixed_idx.shape[0] - n_mix)
+        return total.plan(convs(getattr(self.downscale_blocks, stage)), need_grad)
+
     # ---- one GMA-Conv stage (:325-430) -----------------------------------------
     def grouped_sparse_conv(self, voxel_3D, voxel_2D, syn_mix_3D, syn_mix_2D, stage_id, fps_num,
                             radius, max_cluster_samples, dist_thresh, plan=None):
@@ -220,37 +260,48 @@ class SparseMultiModalEncoderPaint(nn.Module):
         if plan["n_pad"]:       # :208-225 samples without an only-2D voxel got a zero row
             o2_feat = torch.cat([o2_feat, o2_feat.new_zeros((plan["n_pad"], o2_feat.shape[1]))], 0)
         # uncovered 2D voxels are gated by a random embedding (row -1 -> last row)
-        dummy = self.dummy_embedding_fn(c3, voxel_3D.features.device)
+        dummy = plan["dummy"] if "dummy" in plan else \
+            self.dummy_embedding_fn(c3, voxel_3D.features.device)
         cross_gating = self.cross_gate_control[stage_id](
             torch.cat([voxel_3D.features, dummy.to(voxel_3D.features.dtype)], 0))
         n3 = voxel_3D.features.shape[0]
         o2_feat = cross_gating.index_select(
             0, torch.where(nn3 >= 0, nn3, torch.full_like(nn3, n3))) * o2_feat
 
-        voxel_only_3D = spconv.SparseConvTensor(
-            voxel_3D.features.index_select(0, only_3D_rows),
-            voxel_3D.indices.index_select(0, only_3D_rows)[:, zyx].contiguous(),
-            voxel_3D.spatial_shape, B)
-        voxel_only_2D = spconv.SparseConvTensor(o2_feat, o2_idx[:, zyx].contiguous(),
-                                                voxel_2D.spatial_shape, voxel_2D.batch_size)
+        planned = "unified" in plan     # plan_stage_tensors ran: voxel sets + rulebooks exist
+        f3_only = voxel_3D.features.index_select(0, only_3D_rows)
+        if planned:
+            voxel_only_3D = plan["only3d"].replace_feature(f3_only)
+        else:
+            voxel_only_3D = spconv.SparseConvTensor(
+                f3_only, voxel_3D.indices.index_select(0, only_3D_rows)[:, zyx].contiguous(),
+                voxel_3D.spatial_shape, B)
 
         mixed_3D = voxel_3D.features.index_select(0, syn_mix_3D)
         mixed_2D = voxel_2D.features.index_select(0, syn_mix_2D)
         assert mixed_3D.shape[0] == mixed_2D.shape[0]
         mixed_2D = self.gate_control[stage_id](mixed_3D) * mixed_2D
         mixed_feat = torch.cat([mixed_3D, mixed_2D], -1)
-        mixed_idx, mixed_feat = self.pad_missing_batch_id(voxel_2D.indices.index_select(0, syn_mix_2D),
-                                                          mixed_feat, B)
+        if planned:
+            if plan["mixed_pad"]:
+                mixed_feat = torch.cat([mixed_feat, mixed_feat.new_zeros(
+                    (plan["mixed_pad"], mixed_feat.shape[1]))], 0)
+        else:
+            mixed_idx, mixed_feat = self.pad_missing_batch_id(
+                voxel_2D.indices.index_select(0, syn_mix_2D), mixed_feat, B)
         stage = f"stage_{stage_id + 1}"
         voxel_only_3D = getattr(self.grouped_sp_conv_blocks_3D, stage)(voxel_only_3D)
-        f2 = F.pad(voxel_only_2D.features, (c3, 0), mode="constant", value=0)
+        f2 = F.pad(o2_feat, (c3, 0), mode="constant", value=0)
         f3 = F.pad(voxel_only_3D.features, (0, 64), mode="constant", value=0)
         assert f2.shape[-1] == f3.shape[-1] == mixed_feat.shape[-1]
-        unified = spconv.SparseConvTensor(
-            torch.cat([f3, f2, mixed_feat], 0),
-            torch.cat([voxel_only_3D.indices, voxel_only_2D.indices,
-                       mixed_idx[:, zyx]], 0).contiguous(),
-            voxel_2D.spatial_shape, voxel_2D.batch_size)
+        feats = torch.cat([f3, f2, mixed_feat], 0)
+        if planned:
+            unified = plan["unified"].replace_feature(feats)
+        else:
+            unified = spconv.SparseConvTensor(
+                feats, torch.cat([voxel_only_3D.indices, o2_idx[:, zyx], mixed_idx[:, zyx]],
+                                 0).contiguous(),
+                voxel_2D.spatial_shape, voxel_2D.batch_size)
         return getattr(self.aggregation_blocks, stage)(unified)
 
     def forward(self, voxel_3D_list, voxel_2D_list, syn_mix_3D_list, syn_mix_2D_list,
@@ -267,6 +318,8 @@ class SparseMultiModalEncoderPaint(nn.Module):
                 dist_thresh_list[stage_id],
                 plan=None if stage_plans is None else stage_plans[stage_id])
             if stage_id > 0:
-                out = Fsp.sparse_add(out, stage_outs[stage_id - 1])
+                add = None if stage_plans is None else stage_plans[stage_id].get("add")
+                out = Fsp.sparse_add(out, stage_outs[stage_id - 1]) if add is None else \
+                    Fsp.sparse_add_planned(out, stage_outs[stage_id - 1], add)
             stage_outs.append(getattr(self.downscale_blocks, f"stage_{stage_id + 1}")(out))
         return stage_outs

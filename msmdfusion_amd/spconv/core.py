@@ -49,12 +49,25 @@ class IndiceData:
             self._pairs = K.rulebook_pairs(self.nbr_fwd, ld=max(self.n_in, self.n_out, 1))
         return self._pairs
 
-    def prepare(self, need_grad):
-        """Compute everything derived from the table now (tiling orders, and
-        the pair lists when a weight gradient will be needed) so that the
-        feature pass enqueues no index work and never waits on the host."""
+    def prepare(self, need_grad, c_in=None, c_out=None):
+        """Compute everything derived from the table now -- the pair lists when a
+        weight gradient will be needed and, for a conv of c_in -> c_out channels,
+        the tiling order / tile-ordered table its kernels will ask for -- so that
+        the feature pass enqueues no index work and never waits on the host."""
         if need_grad:
             self.pairs()
+        if c_in is not None:
+            from .functional import _use_split, _wants_order
+            kvol = self.nbr_fwd.shape[0]
+            if _use_split(c_in, c_out, kvol, self.n_in):
+                self.tiling_fwd()
+            elif _wants_order(c_in, c_out):
+                self.order_fwd()
+            if need_grad:       # dgrad: the same kernel over the mirrored problem
+                if _use_split(c_out, c_in, kvol, self.n_out):
+                    self.tiling_bwd()
+                elif _wants_order(c_out, c_in):
+                    self.order_bwd()
         return self
 
     def order_fwd(self):
@@ -198,7 +211,7 @@ class SparseConvTensor:
             if rb is None:
                 rb = t.cached_rulebook(conv.kernel_size, conv.stride, conv.padding,
                                        conv.dilation, conv.subm)
-            rb.prepare(need_grad)
+            rb.prepare(need_grad, conv.in_channels, conv.out_channels)
             if not conv.subm:
                 t = t.shadow_copy()
                 t.indices = rb.out_indices

@@ -237,3 +237,35 @@ def sparse_add(*tensors):
                                              other.indices, acc.batch_size, acc.spatial_shape)
         acc = SparseConvTensor(feat, idx, acc.spatial_shape, acc.batch_size)
     return acc
+
+
+class _SparseAddRowsFunction(Function):
+    """Feature half of sparse_add over the maps of an index pass done earlier."""
+
+    @staticmethod
+    def forward(ctx, fa, fb, plan):
+        ctx.plan = plan
+        return K.sparse_add_rows(fa, plan["ma"], fb, plan["mb"], plan["sum"].indices.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return g.index_select(0, ctx.plan["ma_l"]), g.index_select(0, ctx.plan["mb_l"]), None
+
+
+def plan_sparse_add(a_indices, b_indices, batch_size, spatial_shape):
+    """Index half of sparse_add(a, b) from the two coordinate sets alone: the
+    union (an index-only SparseConvTensor whose rulebooks can be planned) and the
+    row maps the feature half and its backward need."""
+    from .core import SparseConvTensor
+    oi, ma, mb = K.sparse_add_index(a_indices, b_indices, batch_size, spatial_shape)
+    total = SparseConvTensor(torch.empty((oi.shape[0], 0), dtype=torch.float32,
+                                         device=oi.device), oi, spatial_shape, batch_size)
+    return dict(sum=total, ma=ma, mb=mb, ma_l=ma.long(), mb_l=mb.long())
+
+
+def sparse_add_planned(a, b, plan):
+    """sparse_add(a, b) with plan = plan_sparse_add(a.indices, b.indices, ...):
+    same result, no host read; the output shares the planned tensor's rulebooks."""
+    assert a.features.shape[0] == plan["ma"].shape[0] and b.features.shape[0] == plan["mb"].shape[0]
+    return plan["sum"].replace_feature(_SparseAddRowsFunction.apply(a.features, b.features, plan))

@@ -237,3 +237,43 @@ def test_index_prefetch_matches_inline(dev):
         for g, w in zip(grads, want[i][1]):
             assert torch.equal(g, w)
     assert len(pf._retired) <= pf.max_behind + 1
+
+
+@pytest.mark.gpu
+def test_index_prefetch_matches_inline_lc(dev):
+    """Same for the LC fusion path: SparseFusionPath.prepare (voxelization of the
+    LiDAR and the virtual points, modality split, FPS / ball query / nearest voxel
+    of all four stages) a step ahead on the prefetcher's stream == inline."""
+    import bench
+    from msmdfusion_amd.prefetch import IndexPrefetcher
+    torch.manual_seed(0)
+    model = bench.FusionBackbone().to(dev).train()
+    mm = model.path.multimodal_middle_encoder
+    fixed = {c: torch.rand(1, c) for c in mm.in_channels_3D}
+    mm.dummy_embedding_fn = lambda c, device: fixed[c].to(device)
+    batches = [([torch.from_numpy(S.lidar_sweep(3 * i + j)).to(dev) for j in range(2)],
+                [torch.from_numpy(S.virtual_points(3 * i + j)).to(dev) for j in range(2)])
+               for i in range(3)]
+
+    def run(bev):
+        model.zero_grad(set_to_none=True)
+        bev.square().mean().backward()
+        return bev.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()
+                                      if p.grad is not None}
+
+    want = [run(model(*b)) for b in batches]
+    pf = IndexPrefetcher(model.prepare, dev)
+    pending = [pf.submit(*batches[0])]
+    for i, b in enumerate(batches):
+        if i + 1 < len(batches):
+            pending.append(pf.submit(*batches[i + 1]))
+        ticket = pending.pop(0)
+        bev, grads = run(model(*b, prepared=pf.take(ticket)))
+        pf.retire(ticket)
+        assert torch.equal(bev, want[i][0])
+        assert grads.keys() == want[i][1].keys()
+        # forward is bit-exact; the gate tables' index_select backward is torch's
+        # index_add_ (fp32 atomics, order not fixed), so gradients agree to rounding
+        for n in grads:
+            w = want[i][1][n]
+            assert (grads[n] - w).abs().max().item() <= 2e-5 * w.abs().max().item() + 1e-12, n

@@ -535,3 +535,26 @@ def test_nn_search(dev):
     exp = O.nn_search(q, k, 13.3)
     got = K.nn_search(t(q.astype(np.int32), dev), t(k.astype(np.int32), dev), 13.3)
     assert np.array_equal(got.cpu().numpy(), exp)
+
+
+@pytest.mark.gpu
+def test_sparse_add_index_then_rows_equals_fused(dev):
+    """The split sparse_add (index pass ahead of time, feature pass with its maps)
+    returns exactly what the fused call does -- including empty operands."""
+    from msmdfusion_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    shape = [11, 60, 60]
+    for na, nb in [(5000, 7000), (0, 300), (300, 0), (1, 1)]:
+        def coords(n):
+            lin = torch.randperm(2 * shape[0] * shape[1] * shape[2], generator=g)[:n]
+            b, r = lin // (shape[0] * shape[1] * shape[2]), lin % (shape[0] * shape[1] * shape[2])
+            return torch.stack([b, r // (shape[1] * shape[2]), (r // shape[2]) % shape[1],
+                                r % shape[2]], 1).int().to(dev)
+        ia, ib = coords(na), coords(nb)
+        fa = torch.randn(na, 48, generator=g).to(dev)
+        fb = torch.randn(nb, 48, generator=g).to(dev)
+        oi, of, ma, mb = K.sparse_add(fa, ia, fb, ib, 2, shape)
+        oi2, ma2, mb2 = K.sparse_add_index(ia, ib, 2, shape)
+        of2 = K.sparse_add_rows(fa, ma2, fb, mb2, oi2.shape[0])
+        assert torch.equal(oi, oi2) and torch.equal(ma, ma2) and torch.equal(mb, mb2)
+        assert torch.equal(of, of2)
