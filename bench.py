@@ -234,7 +234,12 @@ def main():
     prefetch = None
     if os.environ.get("MSMD_PREFETCH", "1") == "1":
         from msmdfusion_amd.prefetch import IndexPrefetcher
-        prefetch = IndexPrefetcher(model.prepare, dev)
+        # worker thread: pays on the LC path (its prepare() waits ~10 ms on host reads,
+        # 70 -> 77 samples/s); configs[1] is GPU-bound either way (366 vs 368)
+        threaded = os.environ.get("MSMD_PREFETCH_THREAD", "1" if lc else "0") == "1"
+        if threaded:    # two threads share the GIL: hand it over promptly (default 5 ms)
+            sys.setswitchinterval(float(os.environ.get("MSMD_SWITCH_INTERVAL", "0.0005")))
+        prefetch = IndexPrefetcher(model.prepare, dev, threaded=threaded)
         batch = (clouds, virtual) if lc else (clouds,)
         pending = [prefetch.submit(*batch)]
 

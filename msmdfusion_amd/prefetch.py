@@ -14,28 +14,43 @@ next submit) before the main stream is past its last reader.  retire() records
 that point; the object is dropped only once the event has completed.
 """
 import collections
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
 
 class IndexPrefetcher:
 
-    def __init__(self, prepare_fn, device, priority=-1):
+    def __init__(self, prepare_fn, device, priority=-1, threaded=True):
+        """threaded: run prepare_fn on a worker thread.  Its host reads (voxel and
+        pair counts) wait for the side stream with the GIL released, so the calling
+        thread keeps the main stream fed meanwhile -- without it those waits come
+        straight out of the time the host has to enqueue the feature pass."""
         self.prepare_fn = prepare_fn
         self.device = torch.device(device)
         self.side = torch.cuda.Stream(device=self.device, priority=priority)
         self._retired = collections.deque()
         self.max_behind = 2      # steps the host may run ahead of the main stream
+        self._pool = ThreadPoolExecutor(1, thread_name_prefix="msmd-index") if threaded else None
 
-    def submit(self, *args, **kw):
-        self._collect()
-        with torch.cuda.stream(self.side):
+    def _run(self, grad, args, kw):
+        torch.cuda.set_device(self.device)          # current device / stream / grad mode
+        with torch.set_grad_enabled(grad), torch.cuda.stream(self.side):    # are per thread
             value = self.prepare_fn(*args, **kw)
             ready = torch.cuda.Event()
             ready.record(self.side)
         return {"value": value, "ready": ready}
 
+    def submit(self, *args, **kw):
+        self._collect()
+        grad = torch.is_grad_enabled()
+        if self._pool is None:
+            return self._run(grad, args, kw)
+        return {"future": self._pool.submit(self._run, grad, args, kw)}
+
     def take(self, ticket):
+        if "future" in ticket:
+            ticket.update(ticket.pop("future").result())
         torch.cuda.current_stream(self.device).wait_event(ticket["ready"])
         return ticket["value"]
 

@@ -203,7 +203,8 @@ def test_sparse_fusion_path_end_to_end(dev):
 
 
 @pytest.mark.gpu
-def test_index_prefetch_matches_inline(dev):
+@pytest.mark.parametrize("threaded", [False, True])
+def test_index_prefetch_matches_inline(dev, threaded):
     """bench.py's step pipelining: voxelization + rulebooks of batch i+1 built on
     a side stream while batch i's feature pass runs (msmdfusion_amd/prefetch.py).
     Same BEV map and the same weight gradients, bit for bit, as the inline order,
@@ -224,7 +225,7 @@ def test_index_prefetch_matches_inline(dev):
                                       if p.grad is not None]
 
     want = [run(model(b)) for b in batches]
-    pf = IndexPrefetcher(model.prepare, dev)
+    pf = IndexPrefetcher(model.prepare, dev, threaded=threaded)
     pending = [pf.submit(batches[0])]
     for i, b in enumerate(batches):
         if i + 1 < len(batches):
