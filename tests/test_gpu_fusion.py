@@ -278,3 +278,43 @@ def test_index_prefetch_matches_inline_lc(dev):
         for n in grads:
             w = want[i][1][n]
             assert (grads[n] - w).abs().max().item() <= 2e-5 * w.abs().max().item() + 1e-12, n
+
+
+@pytest.mark.gpu
+def test_prefetched_step_through_ddp(dev):
+    """bench.py's N>1 step on one rank: the prepared batch travels through
+    DistributedDataParallel's forward as a keyword argument (RCCL backend, world
+    size 1 here; the 2-rank gradient averaging is covered on gloo in
+    test_dist_cpu.py).  Same BEV map and gradients as the bare module."""
+    import socket
+    import torch.distributed as dist
+    import bench
+    from msmdfusion_amd.prefetch import IndexPrefetcher
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0,
+                            world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(0)
+        model = bench.Backbone().to(dev).train()
+        clouds = [torch.from_numpy(S.lidar_sweep(j)).to(dev) for j in range(2)]
+        bev = model(clouds)
+        bev.square().mean().backward()
+        want = bev.detach().clone(), [p.grad.clone() for p in model.parameters()]
+        model.zero_grad(set_to_none=True)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index],
+                                                        gradient_as_bucket_view=True)
+        pf = IndexPrefetcher(model.prepare, dev, threaded=False)
+        ticket = pf.submit(clouds)
+        bev = net(clouds, prepared=pf.take(ticket))
+        bev.square().mean().backward()
+        pf.retire(ticket)
+        torch.cuda.synchronize()
+        assert torch.equal(bev, want[0])
+        for p, w in zip(model.parameters(), want[1]):
+            assert torch.equal(p.grad, w)
+    finally:
+        dist.destroy_process_group()
