@@ -197,6 +197,10 @@ __device__ __forceinline__ void split_quarter(const u32x4& piece, int h, u32x4 (
 // s_memtime deltas of wave 1 of the first 8 workgroups, summed per phase.
 #ifdef MSMD_KERNEL_PROF
 __device__ unsigned long long g_kprof[16];
+// per-tile trace: {HW_ID, XCC_ID, block, tile, t_start, t_end (100 MHz wall clock), items, -}
+constexpr int kTraceCap = 16384;
+__device__ unsigned long long g_ktrace[kTraceCap * 8];
+__device__ unsigned int g_ktrace_n;
 #define KP_BEGIN() unsigned long long kp_t = __builtin_amdgcn_s_memtime()
 #define KP_MARK(i)                                                          \
   {                                                                         \
@@ -520,12 +524,29 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     if (UB > 3) { MSMD_SLOT_UNIT(IT, 3, (PH)*UB + 3) }                                 \
   }
     KP_BEGIN();
+#ifdef MSMD_KERNEL_PROF
+    const unsigned long long kt0 = wall_clock64();
+#endif
     for (int it = 0; it < n_items; it += 2) {
       MSMD_ITEM(it, 0);
       if (it + 1 < n_items) MSMD_ITEM(it + 1, 1);
     }
 #ifdef MSMD_KERNEL_PROF
     if (lane == 0 && wave == 1 && blockIdx.x < 8) atomicAdd(&g_kprof[7], (unsigned long long)n_items);
+    if (tid == 0) {
+      const unsigned e = atomicAdd(&g_ktrace_n, 1u);
+      if (e < (unsigned)kTraceCap) {
+        unsigned long long* t = g_ktrace + (size_t)e * 8;
+        t[0] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);    // HW_REG_HW_ID
+        t[1] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);    // HW_REG_XCC_ID
+        t[2] = blockIdx.x;
+        t[3] = (unsigned)tile;
+        t[4] = kt0;
+        t[5] = wall_clock64();
+        t[6] = (unsigned)n_items;
+        t[7] = mask;
+      }
+    }
 #endif
 #undef MSMD_ITEM
 #undef MSMD_SLOT_UNIT
@@ -902,5 +923,18 @@ MSMD_EXPORT int msmd_debug_kprof(unsigned long long* out) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kprof), sizeof(z)) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_kprof), z, sizeof(z)) != hipSuccess) return -1;
   return 0;
+}
+// out[cap][8] <- the per-tile trace since the last call (then cleared); returns the count
+MSMD_EXPORT int msmd_debug_ktrace(unsigned long long* out, int cap) {
+  hipDeviceSynchronize();
+  unsigned n = 0, zero = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_ktrace_n), sizeof(n)) != hipSuccess) return -1;
+  if (n > (unsigned)kTraceCap) n = kTraceCap;
+  if ((int)n > cap) n = cap;
+  if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ktrace), sizeof(unsigned long long) * 8 * n) !=
+               hipSuccess)
+    return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_ktrace_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+  return (int)n;
 }
 #endif
