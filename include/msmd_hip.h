@@ -207,12 +207,23 @@ int msmd_spconv_pack_weight_split(const float* weight, int kernel_volume, int c_
                                   int c_out, int flags /* as msmd_spconv_pack_weight */,
                                   int planes, void* packed, msmd_stream_t stream);
 
+/* `tile_counter`: `sync_ints` zeroed int32 owned by the stream ([0] = the tile
+ * counter, [1 + t] = exchange flag of row tile t); every launch leaves all of them
+ * at 0 again.  `workspace` (msmd_spconv_fwd_split_workspace_bytes; may be NULL):
+ * exchange buffer that lets the heaviest 128-row tiles run as two scheduling units
+ * -- used when sync_ints >= 1 + ceil(n_out / 128) and the row tiles alone would
+ * leave the workgroup slots unbalanced; without it every tile is one unit.  The
+ * sum order per output element is fixed either way (deterministic), but differs
+ * between the two modes in the last bit.                                        */
+size_t msmd_spconv_fwd_split_workspace_bytes(int n_out, int c_out);
+
 int msmd_spconv_fwd_split(const float* in_feat /* [n_in,c_in] */, int n_in, int c_in,
                           const void* packed_weight, const int32_t* nbr /* [K,ld] */,
                           int ld, int n_out, int kernel_volume, int weight_flip,
                           const int32_t* row_order /* [n_out] or NULL */,
-                          int32_t* tile_counter /* [1] scratch */,
+                          int32_t* tile_counter /* [sync_ints] */, int sync_ints,
                           float* out_feat /* [n_out,c_out] */, int c_out, int planes,
+                          void* workspace, size_t workspace_bytes,
                           msmd_stream_t stream);
 
 /* wgrad with the same operand splitting (both operands are read as fp32 and

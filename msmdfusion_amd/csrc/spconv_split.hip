@@ -31,6 +31,7 @@
 namespace msmd {
 namespace {
 
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -244,12 +245,23 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     const float* __restrict__ in, int n_in, int cin, const u32x4* __restrict__ wp,
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
     const int32_t* __restrict__ order, int* __restrict__ tile_counter, float* __restrict__ out,
-    int ldo, int cout, int nt_total, int mt0, int ksl, int dbg) {
-  // ksl = 1: every 128-row tile is TWO scheduling units, each contracting over half of
-  // the k-blocks and adding its partial sums to a zeroed `out` with float atomics (two
-  // addends onto 0: the result does not depend on their order).  Twice the units on
-  // the same 512 workgroup slots: a shorter tail (simulated makespan / useful work of
-  // the 128-channel layers 2.01 -> 1.72).
+    int ldo, int cout, int nt_total, int mt0, int n_split, f32x4* __restrict__ scratch,
+    int* __restrict__ flags, int dbg) {
+  // Scheduling units.  A 128-row tile whose rows are connected through all 27 offsets is
+  // ~108 items of work -- about what a workgroup slot's fair share of the whole launch is
+  // when there are fewer than two tiles per slot, so the slots that draw a second tile
+  // set the launch time and half the chip idles (tools/ktrace.py).  The first `n_split`
+  // row tiles (the heaviest: rows are mask-sorted) are therefore TWO units each, splitting
+  // the tile's active offsets: part B (upper half of the mask) leaves its accumulators in
+  // `scratch` (same lane layout, 16-byte stores) and raises flags[tile]; part A (lower
+  // half) adds them to its own before the one store of the output rows.  Nothing is
+  // gathered or streamed twice, no atomics on `out`, no zero fill, and the sum order is
+  // fixed: (A's offsets in order) + (B's offsets in order).
+  //   unit u <  n_split            part B of tile u
+  //   n_split <= u < 2 n_split     part A of tile u - n_split
+  //   u >= 2 n_split               tile u - n_split, whole
+  // Tickets are handed out in this order: a part A is drawn after its part B, whose
+  // workgroup is resident and never waits -- the wait in A's epilogue cannot deadlock.
   // `out` points at this pass's first output channel (tile mt0 of nt_total in the
   // packed weights), rows are ldo floats apart, `cout` channels are stored.
   constexpr int R = 2, kRows = 4 * R * 16;
@@ -270,7 +282,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int kbt = (cin + 31) >> 5;      // the last k-block may be partial (c_in % 8 == 0)
-  const int n_tiles = ((n_out + kRows - 1) / kRows) << ksl;   // scheduling units ("tiles" below)
+  const int n_tiles = (n_out + kRows - 1) / kRows + n_split;   // scheduling units ("tiles" below)
+  auto row_tile = [&](int u) { return u < n_split ? u : u - n_split; };
   // every workgroup draws 1 + (tiles it processed) tickets: the draw that returns
   // this value is the last one of the launch and puts the counter back to 0
   const int last_ticket = n_tiles + (int)gridDim.x - 1;
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     const int n_e = (kvol + (order ? 1 : 0)) * kRows;
     for (int e0 = wave * 64; e0 < n_e; e0 += 256) {
       const int e = e0 + lane, k = e >> 7;
-      int p = (T >> ksl) * kRows + (e & (kRows - 1));
+      int p = row_tile(T) * kRows + (e & (kRows - 1));
       p = p < n_out ? p : n_out - 1;
       const int32_t* src = k < kvol ? nbr + (size_t)k * ld + p : order + p;
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + e0), 4, 0, 0);
@@ -325,9 +338,17 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the tile-id atomic too)
     __builtin_amdgcn_s_barrier();
-    const unsigned mask = __builtin_amdgcn_readfirstlane(ctl[tb]);
-    const int kb0 = (tile & ((1 << ksl) - 1)) * (kbt >> ksl);   // this unit's k-blocks
-    const int kb1 = kb0 + (kbt >> ksl);
+    unsigned mask = __builtin_amdgcn_readfirstlane(ctl[tb]);
+    const int part = tile < n_split ? 2 : (tile < 2 * n_split ? 1 : 0);   // 0 whole, 1 A, 2 B
+    if (part) {   // A: the lower ceil(pc/2) active offsets; B: the rest
+      unsigned lo = 0, rest = mask;
+      for (int c = (__builtin_popcount(mask) + 1) >> 1; c > 0; --c) {
+        lo |= rest & -rest;
+        rest &= rest - 1;
+      }
+      mask = part == 1 ? lo : rest;
+    }
+    const int kb0 = 0, kb1 = kbt;
     const int n_units = __builtin_popcount(mask) * (kb1 - kb0);
     const int n_items = (n_units + UB - 1) / UB;
 
@@ -557,23 +578,58 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     // ring registers as epilogue temporaries: drain them first.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- epilogue: lane (j,q) holds out[row j][16n + 4q .. +3] ----
+    const int rt = row_tile(tile);
+    // The exchange goes through agent-scope (sc1) accesses to the scratch lines and the
+    // flag only: coherent across the XCDs' L2s on their own.  Fences would do it too,
+    // but an agent-scope release writes back the whole L2 and an acquire invalidates it
+    // -- the weights and the table live there (measured: 62 -> 192 us on a 32-channel layer).
+    if (part == 2) {   // partial sums -> scratch, then signal (one count per wave)
+      unsigned long long* sp =
+          (unsigned long long*)(scratch + (size_t)rt * (4 * R * NT * 64) + lane);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int p = (tile >> ksl) * kRows + lr[r];
-      if (p >= n_out) continue;
-      const int row = order ? tab[kvol * kRows + lr[r]] : p;
-      float* o = out + (size_t)row * ldo + 4 * q;
-      if (ksl) {
+      for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          if (16 * n + 4 * q < cout) {
+        for (int n = 0; n < NT; ++n) {
+          const u64x2 v = __builtin_bit_cast(u64x2, acc[r][n]);
+          unsigned long long* d = sp + ((wave * R + r) * NT + n) * 128;
+          __hip_atomic_store(d, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(d + 1, v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // written through before the signal
+      if (lane == 0)
+        __hip_atomic_fetch_add(&flags[rt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (part == 1) {   // wait for the four waves of part B, add their sums
+        while (__hip_atomic_load(&flags[rt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4)
+          __builtin_amdgcn_s_sleep(4);
+        asm volatile("" ::: "memory");
+        unsigned long long* sp =
+            (unsigned long long*)(scratch + (size_t)rt * (4 * R * NT * 64) + lane);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) unsafeAtomicAdd(o + 16 * n + c, acc[r][n][c]);
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            unsigned long long* d = sp + ((wave * R + r) * NT + n) * 128;
+            u64x2 v;
+            v[0] = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[1] = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc[r][n] += __builtin_bit_cast(f32x4, v);
           }
-      } else {
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int p = rt * kRows + lr[r];
+        if (p >= n_out) continue;
+        const int row = order ? tab[kvol * kRows + lr[r]] : p;
+        float* o = out + (size_t)row * ldo + 4 * q;
 #pragma unroll
         for (int n = 0; n < NT; ++n)
           if (16 * n + 4 * q < cout) *(f32x4*)(o + 16 * n) = acc[r][n];
+      }
+      if (part == 1 && lane == 0) {   // the last reader re-arms the flag for the next launch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (its scratch reads have landed)
+        if (__hip_atomic_fetch_add(&flags[rt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 7)
+          __hip_atomic_store(&flags[rt], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     // ---- next tile ----
@@ -606,11 +662,11 @@ template <int NT, int UB, int NP>
 int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                      int ld, int n_out, int kvol, int flip, const int32_t* order,
                      int* tile_counter, float* out, int ldo, int cout, int nt_total, int mt0,
-                     int ksl, hipStream_t st) {
+                     int n_split, void* scratch, int* flags, hipStream_t st) {
   constexpr int kRows = 128;
   const size_t smem = sizeof(u32x4) * 2 * UB * NP * NT * 64 +
                       sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 8);
-  const int n_tiles = ceil_div(n_out, kRows) << ksl;
+  const int n_tiles = ceil_div(n_out, kRows) + n_split;
   int nblk = n_tiles;
   const int slots = 256 * split_slots_per_cu();
   if (nblk > slots) nblk = slots;
@@ -621,9 +677,18 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
     attr_smem = smem;
   }
   MSMD_LAUNCH(kern, dim3(nblk), dim3(256), smem, st, in, n_in, cin, (const u32x4*)wp, nbr, ld,
-              n_out, kvol, flip, order, tile_counter, out, ldo, cout, nt_total, mt0, ksl,
-              env_int2("MSMD_DBG", 0));
+              n_out, kvol, flip, order, tile_counter, out, ldo, cout, nt_total, mt0, n_split,
+              (f32x4*)scratch, flags, env_int2("MSMD_DBG", 0));
   return launch_status();
+}
+
+// exchange buffer of the split tiles: one pass's accumulators of `n_split` row tiles
+size_t fwd_split_ws_bytes(int n_split, int cout) {
+  const int nt_total = (cout + 15) / 16;
+  const int n_pass = (nt_total + 7) / 8;
+  int per = (nt_total + n_pass - 1) / n_pass;
+  per = per > 6 ? 8 : per > 4 ? 6 : per > 2 ? 4 : 2;      // the instantiation's NT
+  return (size_t)n_split * 128 * 16 * per * sizeof(float);
 }
 
 // c_out is covered in passes of at most 128 channels (8 tiles of 16; a pass's
@@ -631,20 +696,31 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
 template <int NP>
 int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                        int ld, int n_out, int kvol, int flip, const int32_t* order,
-                       int* tile_counter, float* out, int cout, hipStream_t st) {
+                       int* tile_counter, int sync_ints, float* out, int cout, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
   const int nt_total = (cout + 15) / 16;
   const int n_pass = (nt_total + 7) / 8;
   const int per = (nt_total + n_pass - 1) / n_pass;   // tiles per pass
-  // k-block split (MSMD_SPLIT_KB=1; off by default): when the row tiles alone leave
-  // the 512 slots a long tail (fewer than 2 tiles per slot) and the contraction has
-  // an even number of k-blocks.  Measured on the 128->128 layers: 477 us against
-  // 449 us -- the zero-fill, the atomic epilogue and twice the per-unit setup cost
-  // more than the shorter tail gives back.
-  static const int kb_split = env_int2("MSMD_SPLIT_KB", 0);
-  const int kbt = (cin + 31) / 32;
-  const int ksl = (kb_split && kbt % 2 == 0 && kbt >= 2 &&
-                   ceil_div(n_out, 128) < 2 * 256 * split_slots_per_cu()) ? 1 : 0;
-  if (ksl) hipMemsetAsync(out, 0, sizeof(float) * (size_t)n_out * cout, st);
+  // Split tiles (see the kernel): only where the row tiles alone are too few to balance
+  // the slots, and only if the caller provided the exchange buffers.  All passes of a
+  // launch sequence reuse them (stream order; the flags re-arm themselves).
+  // MSMD_SPLIT_TILES: percent of the row tiles to split (-1 = automatic).
+  static const int split_pct = env_int2("MSMD_SPLIT_TILES", -1);
+  const int row_tiles = ceil_div(n_out, 128);
+  const int slots = 256 * split_slots_per_cu();
+  int n_split = 0;
+  if (split_pct < 0) {
+    // worth it when a dense tile is long (its MFMA work ~ kvol * k-blocks * NT) and the
+    // row tiles are few: 128->128 425 -> 330 us, 64->128 214 -> 208; the 32-/64-channel
+    // layers' tiles are short enough to balance on their own and only pay for the
+    // exchange (32->32 62 -> 78 us)
+    const int nt_pass = per > 6 ? 8 : per > 4 ? 6 : per > 2 ? 4 : 2;
+    if (row_tiles < 3 * slots && kvol * ((cin + 31) / 32) * nt_pass >= 432) n_split = row_tiles;
+  } else {
+    n_split = (int)((long)row_tiles * (split_pct > 100 ? 100 : split_pct) / 100);
+  }
+  if (!ws || ws_bytes < fwd_split_ws_bytes(n_split, cout) || sync_ints < 1 + n_split) n_split = 0;
+  int* flags = tile_counter + 1;
   for (int ps = 0; ps < n_pass; ++ps) {
     const int mt0 = ps * per;
     const int tiles = (mt0 + per <= nt_total) ? per : nt_total - mt0;
@@ -653,7 +729,8 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
     int rc;
 #define MSMD_GO(NT_, UB_)                                                                      \
   rc = launch_fwd_split<NT_, UB_, NP>(in, n_in, cin, wp, nbr, ld, n_out, kvol, flip, order,   \
-                                      tile_counter, o, cout, width, nt_total, mt0, ksl, st)
+                                      tile_counter, o, cout, width, nt_total, mt0, n_split, ws, \
+                                      flags, st)
     if (tiles > 6) { MSMD_GO(8, 1); }
     else if (tiles > 4) { MSMD_GO(6, 1); }
     else if (tiles > 2) { MSMD_GO(4, 2); }
@@ -859,26 +936,29 @@ MSMD_EXPORT int msmd_spconv_fwd_split_supported(int cin, int cout, int kvol) {
          kvol <= kMaxK;
 }
 
+MSMD_EXPORT size_t msmd_spconv_fwd_split_workspace_bytes(int n_out, int cout) {
+  return fwd_split_ws_bytes(ceil_div(n_out > 0 ? n_out : 0, 128), cout);
+}
+
 MSMD_EXPORT int msmd_spconv_fwd_split(const float* planes, int n_in, int cin, const void* packed,
                                       const int32_t* nbr, int ld, int n_out, int kvol,
                                       int weight_flip, const int32_t* row_order,
-                                      int32_t* tile_counter, float* out, int cout, int np,
+                                      int32_t* tile_counter, int sync_ints, float* out, int cout,
+                                      int np, void* workspace, size_t workspace_bytes,
                                       msmd_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!msmd_spconv_fwd_split_supported(cin, cout, kvol) || np < 1 || np > 3)
     return MSMD_ERR_UNSUPPORTED;
-  if (!tile_counter) return MSMD_ERR_INVALID_ARG;
+  if (!tile_counter || sync_ints < 1) return MSMD_ERR_INVALID_ARG;
   if (n_out <= 0) return MSMD_OK;
   // the gathers address the features through a 32-bit buffer offset
   if ((size_t)n_in * cin * sizeof(float) >= (size_t)kOobOffset) return MSMD_ERR_RANGE;
-  if (np == 3)
-    return dispatch_fwd_split<3>(planes, n_in, cin, packed, nbr, ld, n_out, kvol, weight_flip,
-                                 row_order, tile_counter, out, cout, st);
-  if (np == 2)
-    return dispatch_fwd_split<2>(planes, n_in, cin, packed, nbr, ld, n_out, kvol, weight_flip,
-                                 row_order, tile_counter, out, cout, st);
-  return dispatch_fwd_split<1>(planes, n_in, cin, packed, nbr, ld, n_out, kvol, weight_flip,
-                               row_order, tile_counter, out, cout, st);
+#define MSMD_ARGS planes, n_in, cin, packed, nbr, ld, n_out, kvol, weight_flip, row_order, \
+                  tile_counter, sync_ints, out, cout, workspace, workspace_bytes, st
+  if (np == 3) return dispatch_fwd_split<3>(MSMD_ARGS);
+  if (np == 2) return dispatch_fwd_split<2>(MSMD_ARGS);
+  return dispatch_fwd_split<1>(MSMD_ARGS);
+#undef MSMD_ARGS
 }
 
 MSMD_EXPORT int msmd_rulebook_permute_cols(const int32_t* nbr, int kvol, int ld, int n,

@@ -231,14 +231,32 @@ def row_mask_order(nbr):
 _TILE_COUNTERS = {}
 
 
+_SYNC_INTS = 1 + 8192       # tile counter + one exchange flag per 128-row tile (1 M rows)
+
+
 def _tile_counter(device):
-    """One zeroed int32 per (device, stream): the persistent conv kernels draw
-    tiles from it and leave it at 0 again (see msmd_spconv_fwd_f32)."""
+    """Zeroed int32s per (device, stream): [0] is the counter the persistent conv
+    kernels draw tiles from, the rest are the split kernels' exchange flags; every
+    launch leaves all of them at 0 again (see msmd_spconv_fwd_f32 / _fwd_split)."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     c = _TILE_COUNTERS.get(key)
     if c is None:
-        c = _TILE_COUNTERS[key] = torch.zeros((1,), dtype=torch.int32, device=device)
+        c = _TILE_COUNTERS[key] = torch.zeros((_SYNC_INTS,), dtype=torch.int32, device=device)
     return c
+
+
+_EXCHANGE = {}
+
+
+def _exchange_buffer(device, nbytes):
+    """Grow-only scratch per (device, stream) for the split kernels' tile halves:
+    launches on one stream are ordered, so one buffer serves them all."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    b = _EXCHANGE.get(key)
+    if b is None or b.numel() < nbytes:
+        b = _EXCHANGE[key] = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8,
+                                         device=device)
+    return b
 
 
 def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False, row_order=None):
@@ -295,20 +313,27 @@ def permute_cols(nbr, order):
 
 
 def conv_forward_split(feat, packed_weight, nbr, n_out, c_out, planes=3, weight_flip=False,
-                       row_order=None):
+                       row_order=None, split_tiles=True):
     """conv_forward at bf16 MFMA rate with fp32-equivalent results: fp32 features
     are split into `planes` bf16 planes in registers, weights are pre-split
-    (pack_weight_split).  With row_order, `nbr` must be in tile order (permute_cols)."""
+    (pack_weight_split).  With row_order, `nbr` must be in tile order (permute_cols).
+    split_tiles=False withholds the exchange buffer: every 128-row tile is then one
+    scheduling unit and the result does not depend on the tiling order at all (with
+    it, heavy tiles are summed as two halves: same value to the last bit or two)."""
     _need_cuda(feat, packed_weight, nbr)
     f = feat.contiguous().float()
     n_in, c_in = f.shape
     kvol, ld = nbr.shape
     out = torch.empty((n_out, c_out), dtype=torch.float32, device=f.device)
     counter = _tile_counter(f.device)
+    nbytes = lib.msmd_spconv_fwd_split_workspace_bytes(int(n_out), int(c_out))
+    ws = _exchange_buffer(f.device, nbytes) if split_tiles else None
     ev = _prof_begin()
     check(lib.msmd_spconv_fwd_split(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld,
                                     int(n_out), kvol, int(bool(weight_flip)), _p(row_order),
-                                    _p(counter), _p(out), int(c_out), int(planes), _stream()),
+                                    _p(counter), counter.numel(), _p(out), int(c_out),
+                                    int(planes), _p(ws), 0 if ws is None else ws.numel(),
+                                    _stream()),
           "msmd_spconv_fwd_split")
     _prof_end("spconv_fwd_split", ev, nbr=nbr, c_in=c_in, c_out=int(c_out), n_in=n_in,
               n_out=int(n_out))

@@ -90,8 +90,11 @@ def main():
                 o32 = K.conv_forward(f, wp, nbr, n, cout, row_order=order).double()
                 osp = K.conv_forward_split(f, ws, nbr_t, n, cout, args.planes,
                                            row_order=order).double()
-                onat = K.conv_forward_split(f, ws, nbr, n, cout, args.planes).double()
-                assert torch.equal(onat, osp), "tile order changed the result"
+                onat = K.conv_forward_split(f, ws, nbr, n, cout, args.planes,
+                                            split_tiles=False).double()
+                otil = K.conv_forward_split(f, ws, nbr_t, n, cout, args.planes, row_order=order,
+                                            split_tiles=False).double()
+                assert torch.equal(onat, otil), "tile order changed the result"
                 sc = r.abs().max().item()
                 line += " | max|err|/max|out|: fp32 %.2e split %.2e" % (
                     (o32 - r).abs().max().item() / sc, (osp - r).abs().max().item() / sc)
