@@ -1,6 +1,8 @@
 # rocprofv3 --pmc passes over the default bench (one counter set per pass, kernel
 # trace only), merged into gpurun_out/pmc/pmc_summary.json by tools/pmc_to_json.py.
 #   bash tools/pmc_collect.sh            (on the GPU box, e.g. through gpurun)
+# MSMD_PREFETCH=0: counters are per launch and PMC mode serialises kernels anyway; the
+# inline schedule needs fewer untimed settle steps.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc
@@ -12,7 +14,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -o s -- \
-    python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile > $OUT/g$i.log 2>&1
+    env MSMD_PREFETCH=0 python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile > $OUT/g$i.log 2>&1
   tail -1 $OUT/g$i.log | cut -c1-120
 done
 python $R/tools/pmc_to_json.py $OUT $OUT/pmc_summary.json
