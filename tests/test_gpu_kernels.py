@@ -434,6 +434,22 @@ def test_split_conv_edges(dev):
     with pytest.raises(MsmdError):
         K.conv_forward_split(torch.randn(4, 16, device=dev), ws,
                              torch.zeros((27, 4), dtype=torch.int32, device=dev), 4, 16, 3)
+    # split tiles whose second half is empty (one or no active offset per tile) and
+    # tiles with exactly two offsets; 128 -> 128 is a layer the halves are used on
+    w = torch.randn(27, 128, 128, device=dev) * 0.1
+    ws = K.pack_weight_split(w, 3)
+    for n, ks in [(1, [13]), (200, [13]), (1000, [4, 13]), (300, [])]:
+        f = torch.randn(n, 128, device=dev)
+        nbr = torch.full((27, n), -1, dtype=torch.int32, device=dev)
+        ref = torch.zeros(n, 128, dtype=torch.float64, device=dev)
+        for k in ks:
+            src = torch.randperm(n, device=dev).int()
+            nbr[k] = src
+            ref += f.double()[src.long()] @ w[k].double()
+        for _ in range(2):      # twice: the flags must be back at 0 after the first launch
+            out = K.conv_forward_split(f, ws, nbr, n, 128, 3)
+            np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        assert int(K._tile_counter(dev).abs().sum().item()) == 0
 
 
 # ------------------------------------------------------------------ dense / sets
