@@ -79,44 +79,42 @@ struct RankEmit {  // rank[i] = voxel id if first point; records i* (step 3)
   }
 };
 
-// step 4, round 0 + coordinates: every kept point learns its voxel id.
+// step 4 + coordinates: every kept point learns its voxel id and inserts its index
+// into the voxel's `max_points` slots, which end up holding the smallest indices in
+// ascending order -- one pass.  Slot r is an atomicMin cell: a point (or the value it
+// displaced) that loses at slot r carries max(own, old) on to slot r + 1.  Whatever the
+// interleaving, slot r receives the multiset that entered slot r - 1 minus its minimum,
+// so slot r = the (r+1)-th smallest index: exactly the reference loop's "first
+// max_points points of the voxel in point order" (voxelization_cpu.cpp:84-95).
 __global__ __launch_bounds__(256) void vox_assign(int n, VoxGeom g,
                                                   const uint32_t* __restrict__ key,
                                                   const uint32_t* __restrict__ slot,
                                                   const unsigned long long* __restrict__ table,
                                                   const int* __restrict__ rank,
                                                   const int* __restrict__ istar,
-                                                  int* __restrict__ pv, int* __restrict__ win,
-                                                  int max_points, int32_t* __restrict__ coors) {
+                                                  int* __restrict__ win, int max_points,
+                                                  int32_t* __restrict__ coors) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t k = key[i];
-  int v = -1;
-  if (k != kNoCell && i < *istar) {
-    int first = (int)(uint32_t)table[slot[i]];
-    v = rank[first];
-    if (first == i) {
-      win[(size_t)v * max_points] = i;
-      int x = k % g.grid[0];
-      int y = (k / g.grid[0]) % g.grid[1];
-      int z = k / (g.grid[0] * g.grid[1]);
-      coors[(size_t)v * 3 + 0] = z;
-      coors[(size_t)v * 3 + 1] = y;
-      coors[(size_t)v * 3 + 2] = x;
-    }
+  if (k == kNoCell || i >= *istar) return;
+  const int first = (int)(uint32_t)table[slot[i]];
+  const int v = rank[first];
+  if (first == i) {
+    int x = k % g.grid[0];
+    int y = (k / g.grid[0]) % g.grid[1];
+    int z = k / (g.grid[0] * g.grid[1]);
+    coors[(size_t)v * 3 + 0] = z;
+    coors[(size_t)v * 3 + 1] = y;
+    coors[(size_t)v * 3 + 2] = x;
   }
-  pv[i] = v;
-}
-
-// step 4, round r >= 1.
-__global__ __launch_bounds__(256) void vox_round(int n, const int* __restrict__ pv, int* win,
-                                                 int max_points, int r) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  int v = pv[i];
-  if (v < 0) return;
   int* w = win + (size_t)v * max_points;
-  if (i > w[r - 1]) atomicMin(&w[r], i);
+  int carry = i;
+  for (int r = 0; r < max_points; ++r) {
+    const int old = atomicMin(&w[r], carry);
+    if (old == kNoPoint) break;          // the slot was empty: nothing displaced
+    carry = old > carry ? old : carry;
+  }
 }
 
 // step 5: one thread per (voxel, channel); slots walked in order.
@@ -151,7 +149,7 @@ __global__ void vox_init_scalars(int* istar, int n) { *istar = n; }
 
 struct VoxWs {
   uint32_t *key, *slot;
-  int *rank, *pv, *win, *tiles, *istar;
+  int *rank, *win, *tiles, *istar;
   unsigned long long* table;
   int bits;
 };
@@ -169,7 +167,6 @@ void carve(A& a, VoxWs* w, int n, int max_voxels, int max_points) {
   TAKE(key, uint32_t, n);
   TAKE(slot, uint32_t, n);
   TAKE(rank, int, n);
-  TAKE(pv, int, n);
   TAKE(win, int, (size_t)max_voxels * max_points);
   TAKE(tiles, int, scan_num_tiles(n) + 1);
   TAKE(istar, int, 64);
@@ -227,9 +224,7 @@ MSMD_EXPORT int msmd_hard_voxelize(const float* points, int num_points, int num_
               w.tiles, voxel_num, max_voxels, st);
   if (n > 0) {
     MSMD_LAUNCH(vox_assign, dim3(nb), dim3(256), 0, st, n, g, w.key, w.slot, w.table,
-                       w.rank, w.istar, w.pv, w.win, max_points, coors);
-    for (int r = 1; r < max_points; ++r)
-      MSMD_LAUNCH(vox_round, dim3(nb), dim3(256), 0, st, n, w.pv, w.win, max_points, r);
+                       w.rank, w.istar, w.win, max_points, coors);
   }
   long work = (long)max_voxels * num_features;
   int gb = ceil_div(work, 256);
