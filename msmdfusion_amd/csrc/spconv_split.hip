@@ -245,23 +245,24 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     const float* __restrict__ in, int n_in, int cin, const u32x4* __restrict__ wp,
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
     const int32_t* __restrict__ order, int* __restrict__ tile_counter, float* __restrict__ out,
-    int ldo, int cout, int nt_total, int mt0, int n_split, f32x4* __restrict__ scratch,
+    int ldo, int cout, int nt_total, int mt0, int n_split, int n_parts,
+    f32x4* __restrict__ scratch,
     int* __restrict__ flags, int dbg) {
   // Scheduling units.  A 128-row tile whose rows are connected through all 27 offsets is
   // ~108 items of work -- about what a workgroup slot's fair share of the whole launch is
   // when there are fewer than two tiles per slot, so the slots that draw a second tile
   // set the launch time and half the chip idles (tools/ktrace.py).  The first `n_split`
-  // row tiles (the heaviest: rows are mask-sorted) are therefore TWO units each, splitting
-  // the tile's active offsets: part B (upper half of the mask) leaves its accumulators in
-  // `scratch` (same lane layout, 16-byte stores) and raises flags[tile]; part A (lower
-  // half) adds them to its own before the one store of the output rows.  Nothing is
-  // gathered or streamed twice, no atomics on `out`, no zero fill, and the sum order is
-  // fixed: (A's offsets in order) + (B's offsets in order).
-  //   unit u <  n_split            part B of tile u
-  //   n_split <= u < 2 n_split     part A of tile u - n_split
-  //   u >= 2 n_split               tile u - n_split, whole
-  // Tickets are handed out in this order: a part A is drawn after its part B, whose
-  // workgroup is resident and never waits -- the wait in A's epilogue cannot deadlock.
+  // row tiles (the heaviest: rows are mask-sorted) are therefore P = `n_parts` units each,
+  // splitting the tile's active offsets into P groups by rank: groups 1..P-1 leave their
+  // accumulators in `scratch` (same lane layout, 16-byte stores) and raise flags[tile];
+  // group 0 adds them to its own, in group order, before the one store of the output
+  // rows.  Nothing is gathered or streamed twice, no atomics on `out`, no zero fill, and
+  // the sum order is fixed.  With H = n_split:
+  //   unit u <  P H     group P-1 - u / H of tile u % H   (so group 0 is drawn last)
+  //   u >= P H          tile u - (P-1) H, whole
+  // Tickets are handed out in this order: a group 0 is drawn after the tile's other
+  // groups, whose workgroups are resident and never wait -- the wait in its epilogue
+  // cannot deadlock.
   // `out` points at this pass's first output channel (tile mt0 of nt_total in the
   // packed weights), rows are ldo floats apart, `cout` channels are stored.
   constexpr int R = 2, kRows = 4 * R * 16;
@@ -282,8 +283,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int kbt = (cin + 31) >> 5;      // the last k-block may be partial (c_in % 8 == 0)
-  const int n_tiles = (n_out + kRows - 1) / kRows + n_split;   // scheduling units ("tiles" below)
-  auto row_tile = [&](int u) { return u < n_split ? u : u - n_split; };
+  const int n_tiles = (n_out + kRows - 1) / kRows + (n_parts - 1) * n_split;   // units ("tiles")
+  auto row_tile = [&](int u) { return u < n_parts * n_split ? u % n_split : u - (n_parts - 1) * n_split; };
   // every workgroup draws 1 + (tiles it processed) tickets: the draw that returns
   // this value is the last one of the launch and puts the counter back to 0
   const int last_ticket = n_tiles + (int)gridDim.x - 1;
@@ -339,14 +340,17 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the tile-id atomic too)
     __builtin_amdgcn_s_barrier();
     unsigned mask = __builtin_amdgcn_readfirstlane(ctl[tb]);
-    const int part = tile < n_split ? 2 : (tile < 2 * n_split ? 1 : 0);   // 0 whole, 1 A, 2 B
-    if (part) {   // A: the lower ceil(pc/2) active offsets; B: the rest
-      unsigned lo = 0, rest = mask;
-      for (int c = (__builtin_popcount(mask) + 1) >> 1; c > 0; --c) {
-        lo |= rest & -rest;
+    // group of this unit: -1 = whole tile, 0 = final, 1..P-1 = partial
+    const int grp = tile < n_parts * n_split ? n_parts - 1 - tile / n_split : -1;
+    if (grp >= 0) {   // active offsets of rank [grp pc / P, (grp+1) pc / P)
+      const int pc = __builtin_popcount(mask);
+      const int lo = grp * pc / n_parts, hi = (grp + 1) * pc / n_parts;
+      unsigned sel = 0, rest = mask;
+      for (int c = 0; c < hi; ++c) {
+        if (c >= lo) sel |= rest & -rest;
         rest &= rest - 1;
       }
-      mask = part == 1 ? lo : rest;
+      mask = sel;
     }
     const int kb0 = 0, kb1 = kbt;
     const int n_units = __builtin_popcount(mask) * (kb1 - kb0);
@@ -583,9 +587,9 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     // flag only: coherent across the XCDs' L2s on their own.  Fences would do it too,
     // but an agent-scope release writes back the whole L2 and an acquire invalidates it
     // -- the weights and the table live there (measured: 62 -> 192 us on a 32-channel layer).
-    if (part == 2) {   // partial sums -> scratch, then signal (one count per wave)
-      unsigned long long* sp =
-          (unsigned long long*)(scratch + (size_t)rt * (4 * R * NT * 64) + lane);
+    if (grp > 0) {   // partial sums -> scratch, then signal (one count per wave)
+      unsigned long long* sp = (unsigned long long*)(
+          scratch + ((size_t)rt * (n_parts - 1) + grp - 1) * (4 * R * NT * 64) + lane);
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -599,22 +603,25 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
       if (lane == 0)
         __hip_atomic_fetch_add(&flags[rt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      if (part == 1) {   // wait for the four waves of part B, add their sums
-        while (__hip_atomic_load(&flags[rt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4)
+      if (grp == 0) {   // wait for the four waves of every other group, add their sums
+        while (__hip_atomic_load(&flags[rt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+               4 * (n_parts - 1))
           __builtin_amdgcn_s_sleep(4);
         asm volatile("" ::: "memory");
-        unsigned long long* sp =
-            (unsigned long long*)(scratch + (size_t)rt * (4 * R * NT * 64) + lane);
+        for (int gq = 1; gq < n_parts; ++gq) {
+          unsigned long long* sp = (unsigned long long*)(
+              scratch + ((size_t)rt * (n_parts - 1) + gq - 1) * (4 * R * NT * 64) + lane);
 #pragma unroll
-        for (int r = 0; r < R; ++r)
+          for (int r = 0; r < R; ++r)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            unsigned long long* d = sp + ((wave * R + r) * NT + n) * 128;
-            u64x2 v;
-            v[0] = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v[1] = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            acc[r][n] += __builtin_bit_cast(f32x4, v);
-          }
+            for (int n = 0; n < NT; ++n) {
+              unsigned long long* d = sp + ((wave * R + r) * NT + n) * 128;
+              u64x2 v;
+              v[0] = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              v[1] = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              acc[r][n] += __builtin_bit_cast(f32x4, v);
+            }
+        }
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -626,9 +633,10 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
         for (int n = 0; n < NT; ++n)
           if (16 * n + 4 * q < cout) *(f32x4*)(o + 16 * n) = acc[r][n];
       }
-      if (part == 1 && lane == 0) {   // the last reader re-arms the flag for the next launch
+      if (grp == 0 && lane == 0) {   // the last reader re-arms the flag for the next launch
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (its scratch reads have landed)
-        if (__hip_atomic_fetch_add(&flags[rt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 7)
+        if (__hip_atomic_fetch_add(&flags[rt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+            4 * n_parts - 1)
           __hip_atomic_store(&flags[rt], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -662,11 +670,11 @@ template <int NT, int UB, int NP>
 int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                      int ld, int n_out, int kvol, int flip, const int32_t* order,
                      int* tile_counter, float* out, int ldo, int cout, int nt_total, int mt0,
-                     int n_split, void* scratch, int* flags, hipStream_t st) {
+                     int n_split, int n_parts, void* scratch, int* flags, hipStream_t st) {
   constexpr int kRows = 128;
   const size_t smem = sizeof(u32x4) * 2 * UB * NP * NT * 64 +
                       sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 8);
-  const int n_tiles = ceil_div(n_out, kRows) + n_split;
+  const int n_tiles = ceil_div(n_out, kRows) + (n_parts - 1) * n_split;
   int nblk = n_tiles;
   const int slots = 256 * split_slots_per_cu();
   if (nblk > slots) nblk = slots;
@@ -678,17 +686,18 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   }
   MSMD_LAUNCH(kern, dim3(nblk), dim3(256), smem, st, in, n_in, cin, (const u32x4*)wp, nbr, ld,
               n_out, kvol, flip, order, tile_counter, out, ldo, cout, nt_total, mt0, n_split,
-              (f32x4*)scratch, flags, env_int2("MSMD_DBG", 0));
+              n_parts, (f32x4*)scratch, flags, env_int2("MSMD_DBG", 0));
   return launch_status();
 }
 
 // exchange buffer of the split tiles: one pass's accumulators of `n_split` row tiles
-size_t fwd_split_ws_bytes(int n_split, int cout) {
+constexpr int kMaxParts = 4;
+size_t fwd_split_ws_bytes(int n_split, int cout, int n_parts = kMaxParts) {
   const int nt_total = (cout + 15) / 16;
   const int n_pass = (nt_total + 7) / 8;
   int per = (nt_total + n_pass - 1) / n_pass;
   per = per > 6 ? 8 : per > 4 ? 6 : per > 2 ? 4 : 2;      // the instantiation's NT
-  return (size_t)n_split * 128 * 16 * per * sizeof(float);
+  return (size_t)n_split * (n_parts - 1) * 128 * 16 * per * sizeof(float);
 }
 
 // c_out is covered in passes of at most 128 channels (8 tiles of 16; a pass's
@@ -719,7 +728,11 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
   } else {
     n_split = (int)((long)row_tiles * (split_pct > 100 ? 100 : split_pct) / 100);
   }
-  if (!ws || ws_bytes < fwd_split_ws_bytes(n_split, cout) || sync_ints < 1 + n_split) n_split = 0;
+  static const int parts_env = env_int2("MSMD_SPLIT_PARTS", 0);   // 0 = automatic
+  int n_parts = parts_env >= 2 && parts_env <= kMaxParts ? parts_env : 2;
+  if (!ws || ws_bytes < fwd_split_ws_bytes(n_split, cout, n_parts) || sync_ints < 1 + n_split)
+    n_split = 0;
+  if (!n_split) n_parts = 1;
   int* flags = tile_counter + 1;
   for (int ps = 0; ps < n_pass; ++ps) {
     const int mt0 = ps * per;
@@ -729,7 +742,7 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
     int rc;
 #define MSMD_GO(NT_, UB_)                                                                      \
   rc = launch_fwd_split<NT_, UB_, NP>(in, n_in, cin, wp, nbr, ld, n_out, kvol, flip, order,   \
-                                      tile_counter, o, cout, width, nt_total, mt0, n_split, ws, \
+                                      tile_counter, o, cout, width, nt_total, mt0, n_split, n_parts, ws, \
                                       flags, st)
     if (tiles > 6) { MSMD_GO(8, 1); }
     else if (tiles > 4) { MSMD_GO(6, 1); }
