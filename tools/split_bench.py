@@ -105,8 +105,7 @@ def main():
             t32 = timed(lambda: K.conv_wgrad(f, g, pairs, num))
             line = "wgrad %3d x %3d | fp32 %.0f us %.1f TF" % (cin, cout, t32, flops / t32 / 1e6)
             if K.wgrad_split_supported(cin, cout):
-                pf, pg = K.split_planes(f, args.planes), K.split_planes(g, args.planes)
-                ts = timed(lambda: K.conv_wgrad_split(pf, pg, pairs, num))
+                ts = timed(lambda: K.conv_wgrad_split(f, g, pairs, num, args.planes))
                 line += " | split%d %.0f us %.1f TF" % (args.planes, ts, flops / ts / 1e6)
                 if args.check:
                     r = torch.zeros(27, cin, cout, dtype=torch.float64, device=dev)
@@ -114,7 +113,7 @@ def main():
                         m = nbr[k] >= 0
                         r[k] = f.double()[nbr[k][m].long()].t() @ g.double()[m]
                     d32 = K.conv_wgrad(f, g, pairs, num).double()
-                    dsp = K.conv_wgrad_split(pf, pg, pairs, num).double()
+                    dsp = K.conv_wgrad_split(f, g, pairs, num, args.planes).double()
                     sc = r.abs().max().item()
                     line += " | err fp32 %.2e split %.2e" % (
                         (d32 - r).abs().max().item() / sc, (dsp - r).abs().max().item() / sc)
