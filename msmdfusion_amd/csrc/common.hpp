@@ -10,6 +10,10 @@
 namespace msmd {
 
 constexpr int kWave = 64;  // CDNA wavefront
+#ifndef MSMD_WGS_CHUNK
+#define MSMD_WGS_CHUNK 2048
+#endif
+constexpr int kWgradSplitChunk = MSMD_WGS_CHUNK;  // pairs per workgroup of the split wgrad kernel
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }

@@ -816,7 +816,9 @@ MSMD_EXPORT int msmd_spconv_fwd_f32(const float* in_feat, int n_in, int c_in,
 
 MSMD_EXPORT size_t msmd_spconv_wgrad_workspace_bytes(int kernel_volume, int ld, int c_in,
                                                      int c_out) {
-  size_t nchunks = (size_t)ceil_div(ld > 0 ? ld : 1, wgrad_chunk(c_in, c_out));
+  int chunk = wgrad_chunk(c_in, c_out);
+  if (kWgradSplitChunk < chunk) chunk = kWgradSplitChunk;   // serves msmd_spconv_wgrad_split too
+  size_t nchunks = (size_t)ceil_div(ld > 0 ? ld : 1, chunk);
   return align_up(sizeof(float) * kernel_volume * nchunks * c_in * c_out);
 }
 
@@ -917,7 +919,7 @@ MSMD_EXPORT int msmd_spconv_wgrad_split(const float* in_feat, int c_in, const fl
     return launch_status();
   }
   if (!in_feat || !d_out || !indice_pairs) return MSMD_ERR_INVALID_ARG;
-  const int chunk = 2048;   // = wgrad_chunk() for every supported shape (c_in * c_out >= 4096)
+  const int chunk = kWgradSplitChunk;   // pairs per workgroup (common.hpp)
   const int nchunks = ceil_div(ld, chunk);
   if (workspace_bytes < sizeof(float) * (size_t)kernel_volume * nchunks * per_k ||
       ((uintptr_t)workspace & 255))

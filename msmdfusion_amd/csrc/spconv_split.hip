@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_split_kernel(
     const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
     int kvol, float* __restrict__ partial /* [K][nchunks][cin][cout] */) {
-  constexpr int CHUNK = 2048, S = 4;
+  constexpr int CHUNK = kWgradSplitChunk, S = 4;
   using P = Products<NP>;
   __shared__ __attribute__((aligned(16))) char lds_raw[2 * S * S * 64 * sizeof(f32x4)];
   int* s_in = (int*)lds_raw;
