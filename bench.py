@@ -113,7 +113,10 @@ class FusionBackbone(torch.nn.Module):
 
     def prepare(self, points, virtual):
         """Index-only part of a step, for the prefetcher (its own stream, a step ahead)."""
-        return self.path.prepare(points, [virtual] * 4, nn_side_stream=False)
+        # the FPS / nearest-voxel chain (9 + 2 ms, two workgroups wide) goes to the path's own
+        # side stream: on the prefetcher's stream the NEXT batch's host reads would queue
+        # behind it and the prepare chain (25 ms) would set the step time
+        return self.path.prepare(points, [virtual] * 4, nn_side_stream=True)
 
     def forward(self, points, virtual, prepared=None):
         x, x_mm = self.path(points, [virtual] * 4, prepared=prepared)
