@@ -151,7 +151,9 @@ class SparseMultiModalEncoderPaint(nn.Module):
         big = [b for b in todo if c2[b] > fps_num]
         rep_all = None
         if len(big) == batch_size and batch_size > 1:   # the common case at stages 0/1
-            offsets = torch.tensor(o2, dtype=torch.int32, device=dev)
+            # pinned + non_blocking: a pageable copy would block the host until the stream
+            # (the previous stage's 6 ms FPS, when this runs on the search stream) drains
+            offsets = torch.tensor(o2, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
             rep_all = K.furthest_point_sample_ragged(q_zyx.float(), offsets, max(c2), fps_num)
         for b in todo:
             q = q_zyx[o2[b]:o2[b + 1]]
