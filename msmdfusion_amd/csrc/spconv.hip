@@ -460,7 +460,10 @@ template <int NT, int R>
 int launch_fwd(const float* in, int cin, const float* wp, const int32_t* nbr, int ld, int n_out,
                int kvol, int flip, const int32_t* order, int* tile_counter, float* out, int cout,
                hipStream_t st) {
-  if (fwd_pipe_enabled() && (cin & 15) == 0 && (cout & 3) == 0 && kvol <= kMaxK && NT >= 4)
+  // narrow layers too (c_in % 16 == 0): 16->16 34 -> 21 us, strided 16->32 65 -> 47, bit-identical
+  static const int pipe_min_nt = env_int("MSMD_PIPE_MIN_NT", 1);
+  if (fwd_pipe_enabled() && (cin & 15) == 0 && (cout & 3) == 0 && kvol <= kMaxK &&
+      NT >= pipe_min_nt)
     return dispatch_fwd_pipe<NT, R>(in, cin, wp, nbr, ld, n_out, kvol, flip, order, tile_counter,
                                     out, cout, st);
   const int rows_per_block = 4 * R * 16;
