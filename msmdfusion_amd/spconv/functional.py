@@ -27,10 +27,11 @@ def conv_planes():
 
 
 def _use_split(c_in, c_out, kvol, n_in=0):
-    # the kernel also takes c_in % 8 == 0, but with a partial last k-block (the
-    # fusion stack's 80-channel layers) the fp32 kernel is faster: 118 vs 160 us.
+    # c_in % 8 == 0 with a partial last k-block (the fusion stack's 80-channel layers)
+    # included: 80->80 104 vs 114 us, 80->96 102 vs 135 since the split tiles (before
+    # them the fp32 kernel won there, 118 vs 160).
     # Its gathers use 32-bit byte offsets: features beyond 4 GiB go the fp32 way.
-    return (conv_planes() in (1, 2, 3) and c_in % 32 == 0 and n_in * c_in * 4 < 0xFFFFFF00
+    return (conv_planes() in (1, 2, 3) and n_in * c_in * 4 < 0xFFFFFF00
             and K.split_supported(c_in, c_out, kvol))
 
 
