@@ -266,7 +266,8 @@ def main():
     # the W warm-up steps.  The LC path allocates on two streams (record_stream
     # defers block reuse), and needs ~8 steps before no step calls hipMalloc any
     # more (37 ms -> 28 ms per step, tools/lc_steps.py).
-    for _ in range(10 if (lc or prefetch is not None) else 2):
+    # (LC with the prefetcher allocates on four streams: 16.)
+    for _ in range((16 if lc else 10) if (lc or prefetch is not None) else 2):
         step()
     for _ in range(args.warmup):
         step()
