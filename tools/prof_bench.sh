@@ -6,4 +6,4 @@ mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python $R/bench.py ${2:-} --no-cpu-baseline --no-profile > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log | cut -c1-200
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
-python $R/tools/prof_summary.py $f 36 45
+python $R/tools/prof_summary.py $f $([ "${2:-}" = "--workload lc" ] && echo 42 || echo 36) 45
