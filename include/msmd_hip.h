@@ -244,9 +244,19 @@ int msmd_rulebook_permute_cols(const int32_t* nbr, int kernel_volume, int ld, in
                                const int32_t* order, int32_t* out /* [K,n] */,
                                msmd_stream_t stream);
 
-/* masks[o] = bitset over k of (nbr[k][o] >= 0); sort_keys[o] orders rows
- * heaviest mask first with equal masks adjacent.  Either output may be NULL.
- * kernel_volume <= 64. */
+/* masks[o] = bitset over k of (nbr[k][o] >= 0); sort_keys[o]: ascending order makes
+ * rows with similar masks adjacent (3x3x3: the mask with its bits ranked centre <
+ * faces < edges < corners; other volumes: heaviest mask first).  Either output may be
+ * NULL.  kernel_volume <= 64.
+ * msmd_rulebook_tile_costs: cost[t] = K - |union of the masks of rows
+ * order[t*rows_per_tile ..)| -- ascending = the tile sequence (heaviest first) the
+ * persistent conv kernels balance best on; `order` may be NULL (natural order).
+ * Both only choose a tiling: conv results do not depend on it. */
+int msmd_rulebook_tile_costs(const int32_t* nbr /* [K,n_rows] */, int kernel_volume,
+                             int n_rows, const int32_t* order, int rows_per_tile,
+                             int32_t* cost /* [ceil(n_rows / rows_per_tile)] */,
+                             msmd_stream_t stream);
+
 int msmd_rulebook_row_masks(const int32_t* nbr /* [K,n_rows] */,
                             int kernel_volume, int n_rows, uint64_t* masks,
                             int64_t* sort_keys, msmd_stream_t stream);

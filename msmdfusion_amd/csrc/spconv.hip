@@ -485,20 +485,53 @@ int launch_fwd(const float* in, int cin, const float* wp, const int32_t* nbr, in
 }
 
 // Neighbour mask of every output row: bit k set when nbr[k][row] >= 0 (K <= 64),
-// and a sort key that orders rows heaviest first, equal masks adjacent:
-// key = (K - popcount) << K | mask  (K <= 27: fits 32 bits; else the raw mask).
+// and a sort key that makes rows with similar masks adjacent.
+//   K == 27 (3x3x3): the mask with its bits re-ranked -- centre lowest, then the 6 face
+//   neighbours, the 12 edge ones, the 8 corners highest (z before y before x inside a
+//   class): rows that share their RARE offsets end up in the same wave / tile.  The
+//   heaviest-first sequence the persistent scheduler wants is then imposed on whole
+//   tiles (tile_cost_kernel), not on rows.  Simulated on the bench workload's
+//   128-channel stage (tools/order_sim.py): items a workgroup walks / useful work
+//   1.414 with the previous key ((27 - popcount) << 27 | mask) -> 1.299.
+//   other K <= 31: (K - popcount) << K | mask; larger: the raw mask.
+__constant__ unsigned char kRank27[27] = {19, 15, 20, 11, 5,  12, 21, 16, 22, 7,  3,  8,  1, 0,
+                                          2,  9,  4,  10, 23, 17, 24, 13, 6,  14, 25, 18, 26};
 __global__ __launch_bounds__(256) void row_mask_kernel(const int32_t* __restrict__ nbr, int kvol,
                                                        int n, unsigned long long* __restrict__ m,
                                                        long long* __restrict__ key) {
   int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= n) return;
-  unsigned long long v = 0;
+  unsigned long long v = 0, ranked = 0;
   for (int k = 0; k < kvol; ++k)
-    if (nbr[(size_t)k * n + o] >= 0) v |= 1ull << k;
+    if (nbr[(size_t)k * n + o] >= 0) {
+      v |= 1ull << k;
+      if (kvol == 27) ranked |= 1ull << kRank27[k];
+    }
   if (m) m[o] = v;
   if (key)
-    key[o] = kvol <= 31 ? (long long)(((unsigned long long)(kvol - __popcll(v)) << kvol) | v)
-                        : (long long)(v >> 1);
+    key[o] = kvol == 27   ? (long long)ranked
+             : kvol <= 31 ? (long long)(((unsigned long long)(kvol - __popcll(v)) << kvol) | v)
+                          : (long long)(v >> 1);
+}
+
+// cost[t] = K - |union of the masks of tile t's rows| (ascending = heaviest first),
+// tile t = positions [t * rows, (t+1) * rows) of `order`.  One block per tile.
+__global__ __launch_bounds__(128) void tile_cost_kernel(const int32_t* __restrict__ nbr, int kvol,
+                                                        int n, const int32_t* __restrict__ order,
+                                                        int rows, int32_t* __restrict__ cost) {
+  __shared__ unsigned long long u;
+  if (threadIdx.x == 0) u = 0;
+  __syncthreads();
+  unsigned long long v = 0;
+  for (int p = blockIdx.x * rows + threadIdx.x; p < (blockIdx.x + 1) * rows && p < n;
+       p += blockDim.x) {
+    const int o = order ? order[p] : p;
+    for (int k = 0; k < kvol; ++k)
+      if (nbr[(size_t)k * n + o] >= 0) v |= 1ull << k;
+  }
+  if (v) atomicOr(&u, v);
+  __syncthreads();
+  if (threadIdx.x == 0) cost[blockIdx.x] = kvol - __popcll(u);
 }
 
 // ------------------------------------------------------------------ wgrad --
@@ -781,6 +814,18 @@ MSMD_EXPORT int msmd_rulebook_row_masks(const int32_t* nbr, int kernel_volume, i
   if (n_rows == 0) return MSMD_OK;
   MSMD_LAUNCH(row_mask_kernel, dim3(ceil_div(n_rows, 256)), dim3(256), 0, (hipStream_t)stream,
               nbr, kernel_volume, n_rows, (unsigned long long*)masks, (long long*)sort_keys);
+  return launch_status();
+}
+
+MSMD_EXPORT int msmd_rulebook_tile_costs(const int32_t* nbr, int kernel_volume, int n_rows,
+                                         const int32_t* order, int rows_per_tile, int32_t* cost,
+                                         msmd_stream_t stream) {
+  if (kernel_volume < 1 || kernel_volume > 64) return MSMD_ERR_UNSUPPORTED;
+  if (n_rows < 0 || rows_per_tile < 1 || (n_rows > 0 && (!nbr || !cost)))
+    return MSMD_ERR_INVALID_ARG;
+  if (n_rows == 0) return MSMD_OK;
+  MSMD_LAUNCH(tile_cost_kernel, dim3(ceil_div(n_rows, rows_per_tile)), dim3(128), 0,
+              (hipStream_t)stream, nbr, kernel_volume, n_rows, order, rows_per_tile, cost);
   return launch_status();
 }
 

@@ -219,11 +219,15 @@ def _prof_end(kind, start, **meta):
         PROFILE.append((kind, start, end, meta))
 
 
-def row_mask_order(nbr):
-    """Permutation of the rows of nbr[K,n] that sorts them by neighbour mask
-    (rows with identical empty offsets become adjacent).  The masks come from
-    the C ABI; the sort itself is torch.argsort (device radix sort) -- it only
-    chooses a tiling order, results are identical for any permutation."""
+TILE_ROWS = 128     # rows per workgroup tile of the conv kernels
+
+
+def row_mask_order(nbr, tile_lpt=True):
+    """Tiling order of the rows of nbr[K,n]: rows sorted by (rank-permuted) neighbour
+    mask so that the rows of a wave / a 128-row tile share their empty offsets, then
+    -- tile_lpt -- whole tiles re-sequenced heaviest first for the persistent
+    scheduler.  Masks and tile costs come from the C ABI; the sorts are torch's
+    device radix sort.  It only chooses a tiling: results do not depend on it."""
     _need_cuda(nbr)
     kvol, n = nbr.shape
     if kvol > 64 or n == 0:
@@ -233,7 +237,17 @@ def row_mask_order(nbr):
           "msmd_rulebook_row_masks")
     if 2 * kvol <= 32 or (kvol <= 27):   # key fits 32 bits: half the radix passes
         keys = (keys - 2147483648).int()   # unsigned order under a signed compare
-    return torch.sort(keys, stable=False)[1].int()
+    order = torch.sort(keys, stable=False)[1].int()
+    full = n // TILE_ROWS
+    if tile_lpt and full > 1:
+        cost = torch.empty(((n + TILE_ROWS - 1) // TILE_ROWS,), dtype=torch.int32,
+                           device=nbr.device)
+        check(lib.msmd_rulebook_tile_costs(_p(nbr), kvol, n, _p(order), TILE_ROWS, _p(cost),
+                                           _stream()), "msmd_rulebook_tile_costs")
+        seq = torch.sort(cost[:full], stable=True)[1]      # the partial last tile stays last
+        head = order[:full * TILE_ROWS].view(full, TILE_ROWS).index_select(0, seq).reshape(-1)
+        order = torch.cat([head, order[full * TILE_ROWS:]]) if n % TILE_ROWS else head
+    return order
 
 
 _TILE_COUNTERS = {}
