@@ -252,6 +252,17 @@ int msmd_rulebook_permute_cols(const int32_t* nbr, int kernel_volume, int ld, in
  * order[t*rows_per_tile ..)| -- ascending = the tile sequence (heaviest first) the
  * persistent conv kernels balance best on; `order` may be NULL (natural order).
  * Both only choose a tiling: conv results do not depend on it. */
+/* The whole tiling of a table in one call: order[p] = output row at tile position p
+ * (rows sorted by msmd_rulebook_row_masks' key, full tiles re-sequenced by
+ * msmd_rulebook_tile_costs, a partial last tile stays last) and, if `tiled` is not
+ * NULL, tiled[k][p] = nbr[k][order[p]] (= msmd_rulebook_permute_cols).  In-library
+ * radix sorts over the key's significant bits; kernel_volume <= 31, nbr is [K,n_rows]. */
+size_t msmd_rulebook_tiling_workspace_bytes(int n_rows, int rows_per_tile);
+int msmd_rulebook_tiling(const int32_t* nbr, int kernel_volume, int n_rows,
+                         int rows_per_tile, int32_t* order /* [n_rows] */,
+                         int32_t* tiled /* [K,n_rows] or NULL */, void* workspace,
+                         size_t workspace_bytes, msmd_stream_t stream);
+
 int msmd_rulebook_tile_costs(const int32_t* nbr /* [K,n_rows] */, int kernel_volume,
                              int n_rows, const int32_t* order, int rows_per_tile,
                              int32_t* cost /* [ceil(n_rows / rows_per_tile)] */,

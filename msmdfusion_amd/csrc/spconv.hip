@@ -514,6 +514,21 @@ __global__ __launch_bounds__(256) void row_mask_kernel(const int32_t* __restrict
                           : (long long)(v >> 1);
 }
 
+// The same key in 32 bits (K <= 31), for the in-library radix sort (tiling.hip).
+__global__ __launch_bounds__(256) void row_key32_kernel(const int32_t* __restrict__ nbr, int kvol,
+                                                        int n, uint32_t* __restrict__ key) {
+  int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= n) return;
+  unsigned v = 0, ranked = 0;
+  for (int k = 0; k < kvol; ++k)
+    if (nbr[(size_t)k * n + o] >= 0) {
+      v |= 1u << k;
+      if (kvol == 27) ranked |= 1u << kRank27[k];
+    }
+  // K < 16: (K - popcount) << K | mask fits 2K+1 bits; 16..31 (not 27): mask order only
+  key[o] = kvol == 27 ? ranked : (kvol <= 15 ? ((unsigned)(kvol - __popc(v)) << kvol) | v : v);
+}
+
 // cost[t] = K - |union of the masks of tile t's rows| (ascending = heaviest first),
 // tile t = positions [t * rows, (t+1) * rows) of `order`.  One block per tile.
 __global__ __launch_bounds__(128) void tile_cost_kernel(const int32_t* __restrict__ nbr, int kvol,
@@ -816,6 +831,21 @@ MSMD_EXPORT int msmd_rulebook_row_masks(const int32_t* nbr, int kernel_volume, i
               nbr, kernel_volume, n_rows, (unsigned long long*)masks, (long long*)sort_keys);
   return launch_status();
 }
+
+namespace msmd {
+// for tiling.hip: 32-bit sort keys (and how many of their bits matter) / tile costs
+void launch_row_keys(const int32_t* nbr, int kvol, int n, uint32_t* keys, int* key_bits,
+                     hipStream_t st) {
+  MSMD_LAUNCH(row_key32_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, nbr, kvol, n, keys);
+  *key_bits = kvol == 27 ? 27 : (kvol <= 15 ? 2 * kvol + 1 : 32);
+  if (*key_bits > 32) *key_bits = 32;
+}
+void launch_tile_costs(const int32_t* nbr, int kvol, int n, const int32_t* order, int rows,
+                       int32_t* cost, hipStream_t st) {
+  MSMD_LAUNCH(tile_cost_kernel, dim3(ceil_div(n, rows)), dim3(128), 0, st, nbr, kvol, n, order,
+              rows, cost);
+}
+}  // namespace msmd
 
 MSMD_EXPORT int msmd_rulebook_tile_costs(const int32_t* nbr, int kernel_volume, int n_rows,
                                          const int32_t* order, int rows_per_tile, int32_t* cost,

@@ -250,6 +250,27 @@ def row_mask_order(nbr, tile_lpt=True):
     return order
 
 
+def rulebook_tiling(nbr, want_table=True):
+    """(order[n], table in tile order | None) of nbr[K,n] in one library call: what
+    row_mask_order + permute_cols compute through torch, with the sorts done in the
+    library (K <= 31; falls back to those two otherwise)."""
+    _need_cuda(nbr)
+    kvol, n = nbr.shape
+    if n == 0:
+        return None, nbr
+    if kvol > 31:
+        order = row_mask_order(nbr)
+        return order, (permute_cols(nbr, order) if want_table and order is not None else nbr)
+    t = nbr.contiguous()
+    order = torch.empty((n,), dtype=torch.int32, device=t.device)
+    tiled = torch.empty_like(t) if want_table else None
+    nbytes = lib.msmd_rulebook_tiling_workspace_bytes(n, TILE_ROWS)
+    ws = _ws(nbytes, t.device)
+    check(lib.msmd_rulebook_tiling(_p(t), kvol, n, TILE_ROWS, _p(order), _p(tiled), _p(ws), nbytes,
+                                   _stream()), "msmd_rulebook_tiling")
+    return order, tiled
+
+
 _TILE_COUNTERS = {}
 
 

@@ -58,7 +58,10 @@ class SparseEncoder(nn.Module):
             coors.int(), self.sparse_shape, batch_size)
         convs = [m for m in self.modules() if isinstance(m, spconv.SparseConvolution)]
         outs = []
-        planned.plan(convs, need_grad=torch.is_grad_enabled(), strided_outputs=outs)
+        # a frozen encoder over inputs that carry no gradient (the LC recipe) never runs
+        # backward: no pair lists, no backward tilings
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        planned.plan(convs, need_grad=need_grad, strided_outputs=outs)
         stages = [(planned.indices, list(self.sparse_shape))] + outs[:self.stage_num - 1]
         stages.append(stages[-1])        # the last stage has no strided conv
         return planned, stages

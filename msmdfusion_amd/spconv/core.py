@@ -34,6 +34,7 @@ class IndiceData:
         self._order_fwd = None
         self._order_bwd = None
         self._tiled_fwd = None
+        self._tiled_bwd = None
 
     @property
     def n_in(self):
@@ -71,39 +72,42 @@ class IndiceData:
         return self
 
     def order_fwd(self):
-        """Tiling order of the output rows (sorted by neighbour mask); for SubM
-        the same order serves dgrad (its table is the forward one mirrored)."""
+        """Tiling order of the output rows (similar neighbour masks adjacent, tiles
+        heaviest first); for SubM the same order serves dgrad (its table is the
+        forward one mirrored)."""
         if self._order_fwd is None:
-            self._order_fwd = (K.row_mask_order(self.nbr_fwd),)
+            self._order_fwd = (K.rulebook_tiling(self.nbr_fwd, want_table=False)[0],)
         return self._order_fwd[0]
 
     def order_bwd(self):
         if self.is_subm:
             return self.order_fwd()
         if self._order_bwd is None:
-            self._order_bwd = (K.row_mask_order(self.nbr_bwd),)
+            self._order_bwd = (K.rulebook_tiling(self.nbr_bwd, want_table=False)[0],)
         return self._order_bwd[0]
 
     def tiling_fwd(self):
-        """(table, row_order) the split-bf16 kernel tiles the forward pass by.
-        SubM rulebooks serve 8 launches per step (4 convs x forward/dgrad): the
-        table goes in mask-sorted tile order (column p belongs to output row
-        order[p]).  A strided conv's tables serve one launch each and its rows
-        are already in ascending linear id -- spatial neighbours, similar masks:
-        mask + sort + permute (~100 us) costs more than it saves there
-        (tools/strided_order.py), so those stay in natural order."""
-        if not self.is_subm:
-            return self.nbr_fwd, None
+        """(table, row_order) the split-bf16 kernel tiles the forward pass by: the
+        table in mask-sorted tile order (column p belongs to output row order[p]).
+        SubM rulebooks serve 8 launches per step (4 convs x forward/dgrad), a strided
+        conv's tables one launch each -- but those need it most: a stride-2 output
+        row has ~5 of the 27 offsets and its neighbours in linear order all have
+        different ones, so a 128-row tile in natural order walks every offset
+        (issued / useful work 5.4 forward, 8.1 backward on the bench workload;
+        1.8 / 1.0 sorted -- tools/order_sim.py).  The sort + permute (~100 us) runs
+        in the index pass, off the feature pass."""
         if self._tiled_fwd is None:
-            order = self.order_fwd()
-            self._tiled_fwd = (K.permute_cols(self.nbr_fwd, order) if order is not None
-                               else self.nbr_fwd,)
-        return self._tiled_fwd[0], self.order_fwd()
+            order, table = K.rulebook_tiling(self.nbr_fwd)
+            self._order_fwd, self._tiled_fwd = (order,), (table,)
+        return self._tiled_fwd[0], self._order_fwd[0]
 
     def tiling_bwd(self):
         if self.is_subm:      # forward table + flipped weights == backward table
             return self.tiling_fwd()
-        return self.nbr_bwd, None
+        if self._tiled_bwd is None:
+            order, table = K.rulebook_tiling(self.nbr_bwd)
+            self._order_bwd, self._tiled_bwd = (order,), (table,)
+        return self._tiled_bwd[0], self._order_bwd[0]
 
 
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm,

@@ -585,3 +585,29 @@ def test_sparse_add_index_then_rows_equals_fused(dev):
         of2 = K.sparse_add_rows(fa, ma2, fb, mb2, oi2.shape[0])
         assert torch.equal(oi, oi2) and torch.equal(ma, ma2) and torch.equal(mb, mb2)
         assert torch.equal(of, of2)
+
+
+@pytest.mark.parametrize("n", [1, 127, 128, 129, 5000])
+@pytest.mark.parametrize("kvol", [27, 3])
+def test_rulebook_tiling_one_call(dev, n, kvol):
+    """msmd_rulebook_tiling against row_mask_order + permute_cols (the torch-side
+    route): a permutation of the rows, the table in that order, and tiles that cost
+    the same (ties between equal keys may be broken differently)."""
+    from msmdfusion_amd import kernels as K
+    g = torch.Generator().manual_seed(n + kvol)
+    nbr = torch.where(torch.rand(kvol, n, generator=g) < 0.35,
+                      torch.randint(0, max(n, 1), (kvol, n), generator=g), -1).int().to(dev)
+    order, tiled = K.rulebook_tiling(nbr)
+    assert sorted(order.cpu().tolist()) == list(range(n))
+    assert torch.equal(tiled, K.permute_cols(nbr, order))
+    ref = K.row_mask_order(nbr)
+
+    def unions(o):      # offsets each 128-row tile walks
+        m = (nbr[:, o.long()] >= 0)
+        pad = (-n) % 128
+        m = torch.cat([m, torch.zeros(kvol, pad, dtype=torch.bool, device=dev)], 1)
+        return m.view(kvol, -1, 128).any(2).sum(0)
+    if kvol == 27:
+        assert torch.equal(unions(order), unions(ref))
+    only_order, none = K.rulebook_tiling(nbr, want_table=False)
+    assert none is None and torch.equal(only_order, order)
