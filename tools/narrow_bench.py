@@ -33,8 +33,9 @@ for name, idx, shape, cin, cout, nbr in [
     f = torch.randn(n_in, cin, device=dev)
     w = torch.randn(27, cin, cout, device=dev) * 0.05
     wp = K.pack_weight(w)
-    t = timed(lambda: K.conv_forward(f, wp, nbr, n_out, cout))
-    o = K.conv_forward(f, wp, nbr, n_out, cout).double()
+    order = K.rulebook_tiling(nbr, want_table=False)[0] if os.environ.get("NARROW_SORT") else None
+    t = timed(lambda: K.conv_forward(f, wp, nbr, n_out, cout, row_order=order))
+    o = K.conv_forward(f, wp, nbr, n_out, cout, row_order=order).double()
     r = ref64(f, w, nbr)
     print("%-15s n_out=%d pairs=%d | %.1f us | err %.2e | sum %.9e" % (
         name, n_out, int((nbr >= 0).sum()), t, (o - r).abs().max().item() / r.abs().max().item(),
