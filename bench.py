@@ -227,7 +227,9 @@ def main():
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank],
                                                         gradient_as_bucket_view=True)
     # AdamW lr=1e-4, wd=0.01: configs/transfusion_nusc_voxel_L.py optimizer
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
+    # (fused=True: torch's single multi-tensor kernel per step instead of ~10 foreach launches)
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01,
+                            fused=os.environ.get("MSMD_FUSED_ADAMW", "1") == "1")
 
     clouds = [torch.from_numpy(S.lidar_sweep(rank * spg + i)).to(dev) for i in range(spg)]
     virtual = [torch.from_numpy(S.virtual_points(rank * spg + i)).to(dev) for i in range(spg)] \
