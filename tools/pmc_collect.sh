@@ -18,3 +18,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
   tail -1 $OUT/g$i.log | cut -c1-120
 done
 python $R/tools/pmc_to_json.py $OUT $OUT/pmc_summary.json
+# gpurun merges at most 64 MiB back: the per-dispatch CSVs have served their purpose
+rm -rf $OUT/g[0-9]
