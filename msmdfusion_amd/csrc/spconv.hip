@@ -526,6 +526,8 @@ __global__ __launch_bounds__(256) void row_key32_kernel(const int32_t* __restric
       if (kvol == 27) ranked |= 1u << kRank27[k];
     }
   // K < 16: (K - popcount) << K | mask fits 2K+1 bits; 16..31 (not 27): mask order only
+  // (the Gray code of the ranked mask simulates 1.3 % better, 1.299 -> 1.282 items / useful
+  // work; measured within noise, not used)
   key[o] = kvol == 27 ? ranked : (kvol <= 15 ? ((unsigned)(kvol - __popc(v)) << kvol) | v : v);
 }
 

@@ -71,7 +71,7 @@ def main():
         n = idx.shape[0]
         nbr = K.rulebook_subm(idx, 4, shape, 3)
         pairs_n = int((nbr >= 0).sum())
-        order = K.row_mask_order(nbr)
+        order = K.rulebook_tiling(nbr, want_table=False)[0]
         f = torch.randn(n, cin, device=dev)
         w = torch.randn(27, cin, cout, device=dev) * 0.05
         flops = 2.0 * pairs_n * cin * cout
