@@ -724,7 +724,8 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
     // layers' tiles are short enough to balance on their own and only pay for the
     // exchange (32->32 62 -> 78 us)
     const int nt_pass = per > 6 ? 8 : per > 4 ? 6 : per > 2 ? 4 : 2;
-    if (row_tiles < 3 * slots && kvol * ((cin + 31) / 32) * nt_pass >= 432) n_split = row_tiles;
+    // (with the rank-ordered tiling 64->128 is 188 us whole, 193 split: the bar is 486 now)
+    if (row_tiles < 3 * slots && kvol * ((cin + 31) / 32) * nt_pass >= 486) n_split = row_tiles;
   } else {
     n_split = (int)((long)row_tiles * (split_pct > 100 ? 100 : split_pct) / 100);
   }
