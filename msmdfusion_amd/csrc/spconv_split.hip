@@ -260,6 +260,10 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
   // the sum order is fixed.  With H = n_split:
   //   unit u <  P H     group P-1 - u / H of tile u % H   (so group 0 is drawn last)
   //   u >= P H          tile u - (P-1) H, whole
+  // (Handing a tile's groups out back to back -- strictly descending unit cost -- was
+  // measured slower, 342 us against 296: the final group then finishes together with
+  // the partial ones and spins for them; with all partial groups first their sums are
+  // long there.)
   // Tickets are handed out in this order: a group 0 is drawn after the tile's other
   // groups, whose workgroups are resident and never wait -- the wait in its epilogue
   // cannot deadlock.
