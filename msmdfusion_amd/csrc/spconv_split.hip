@@ -389,9 +389,10 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
       for (int r = 0; r < R; ++r) {
         const int src = s_next[r];
         valid = src > valid ? src : valid;
+        // (dbg & 8, experiments only: fold the gathers onto 4096 rows -- all L2 hits)
         const unsigned off = (src < 0 || chan0 >= cin || (dbg & 2))
                                  ? kOobOffset
-                                 : (unsigned)src * row_bytes + col;
+                                 : (unsigned)((dbg & 8) ? (src & 4095) : src) * row_bytes + col;
         gather_row8(raw[r], off, rs);
       }
       MSMD_ADV(mg, kbg);
