@@ -206,6 +206,11 @@ size_t msmd_spconv_packed_split_bytes(int kernel_volume, int c_in /* contraction
 int msmd_spconv_pack_weight_split(const float* weight, int kernel_volume, int c_in,
                                   int c_out, int flags /* as msmd_spconv_pack_weight */,
                                   int planes, void* packed, msmd_stream_t stream);
+/* The same plus the image of the opposite transposition (flags ^ 1), one launch:
+ * forward and dgrad of a conv read one each. */
+int msmd_spconv_pack_weight_split_pair(const float* weight, int kernel_volume, int c_in,
+                                       int c_out, int flags, int planes, void* packed,
+                                       void* packed_transposed, msmd_stream_t stream);
 
 /* `tile_counter`: `sync_ints` zeroed int32 owned by the stream ([0] = the tile
  * counter, [1 + t] = exchange flag of row tile t); every launch leaves all of them

@@ -58,6 +58,7 @@ SIGNATURES = {
     "msmd_spconv_wgrad_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "msmd_spconv_packed_split_bytes": (_sz, [_i, _i, _i, _i]),
     "msmd_spconv_pack_weight_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "msmd_spconv_pack_weight_split_pair": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "msmd_spconv_fwd_split_supported": (_i, [_i, _i, _i]),
     "msmd_spconv_fwd_split_workspace_bytes": (_sz, [_i, _i]),
     "msmd_spconv_fwd_split": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i,

@@ -78,12 +78,24 @@ template <int NP>
 __global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __restrict__ w,
                                                                 int kvol, int cin, int cout,
                                                                 int flags,
-                                                                u32x4* __restrict__ packed) {
-  const int transpose = flags & 1, krsc = flags & 2;
-  const int ci = transpose ? cout : cin, co = transpose ? cin : cout;
-  const int KB = (ci + 31) / 32, NT = (co + 15) / 16;
-  const long total = (long)kvol * KB * NT * 64;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+                                                                u32x4* __restrict__ packed_a,
+                                                                u32x4* __restrict__ packed_b) {
+  // packed_b (optional): the image of the opposite transposition, same launch (forward
+  // and dgrad of one conv want both)
+  const int krsc = flags & 2;
+  const long total_a =
+      (long)kvol * (((flags & 1 ? cout : cin) + 31) / 32) * (((flags & 1 ? cin : cout) + 15) / 16) * 64;
+  const long total_b =
+      packed_b ? (long)kvol * (((flags & 1 ? cin : cout) + 31) / 32) * (((flags & 1 ? cout : cin) + 15) / 16) * 64
+               : 0;
+  for (long e2 = (long)blockIdx.x * 256 + threadIdx.x; e2 < total_a + total_b;
+       e2 += (long)gridDim.x * 256) {
+    const bool second = e2 >= total_a;
+    const long e = second ? e2 - total_a : e2;
+    const int transpose = (flags & 1) ^ (second ? 1 : 0);
+    u32x4* __restrict__ packed = second ? packed_b : packed_a;
+    const int ci = transpose ? cout : cin, co = transpose ? cin : cout;
+    const int KB = (ci + 31) / 32, NT = (co + 15) / 16;
     const int lane = e & 63;
     long t = e >> 6;
     const int mt = t % NT;
@@ -928,24 +940,42 @@ MSMD_EXPORT size_t msmd_spconv_packed_split_bytes(int kvol, int cin, int cout, i
 // `cin`/`cout` are the weight's own dims; with flags bit0 the packed image is of
 // W[k]^T (contraction over c_out): its size is msmd_spconv_packed_split_bytes(K,
 // cout, cin, np).
-MSMD_EXPORT int msmd_spconv_pack_weight_split(const float* w, int kvol, int cin, int cout,
-                                              int flags, int np, void* packed, msmd_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
-  if (kvol <= 0 || cin <= 0 || cout <= 0 || np < 1 || np > 3) return MSMD_ERR_INVALID_ARG;
+namespace {
+int pack_split(const float* w, int kvol, int cin, int cout, int flags, int np, void* packed,
+               void* packed_other, hipStream_t st) {
+  if (kvol <= 0 || cin <= 0 || cout <= 0 || np < 1 || np > 3 || !w || !packed)
+    return MSMD_ERR_INVALID_ARG;
   const int ci = (flags & 1) ? cout : cin, co = (flags & 1) ? cin : cout;
-  const long total = (long)kvol * ((ci + 31) / 32) * ((co + 15) / 16) * 64;
+  long total = (long)kvol * ((ci + 31) / 32) * ((co + 15) / 16) * 64;
+  if (packed_other) total += (long)kvol * ((co + 31) / 32) * ((ci + 15) / 16) * 64;
   int nblk = (int)((total + 255) / 256);
   if (nblk > 4096) nblk = 4096;
   if (np == 3)
     MSMD_LAUNCH(pack_weight_split_kernel<3>, dim3(nblk), dim3(256), 0, st, w, kvol, cin, cout,
-                flags, (u32x4*)packed);
+                flags, (u32x4*)packed, (u32x4*)packed_other);
   else if (np == 2)
     MSMD_LAUNCH(pack_weight_split_kernel<2>, dim3(nblk), dim3(256), 0, st, w, kvol, cin, cout,
-                flags, (u32x4*)packed);
+                flags, (u32x4*)packed, (u32x4*)packed_other);
   else
     MSMD_LAUNCH(pack_weight_split_kernel<1>, dim3(nblk), dim3(256), 0, st, w, kvol, cin, cout,
-                flags, (u32x4*)packed);
+                flags, (u32x4*)packed, (u32x4*)packed_other);
   return launch_status();
+}
+}  // namespace
+
+MSMD_EXPORT int msmd_spconv_pack_weight_split(const float* w, int kvol, int cin, int cout,
+                                              int flags, int np, void* packed, msmd_stream_t stream) {
+  return pack_split(w, kvol, cin, cout, flags, np, packed, nullptr, (hipStream_t)stream);
+}
+
+// Both images of one weight in one launch: `packed` as msmd_spconv_pack_weight_split
+// with `flags`, `packed_transposed` the same with flags ^ 1 (what dgrad reads).
+MSMD_EXPORT int msmd_spconv_pack_weight_split_pair(const float* w, int kvol, int cin, int cout,
+                                                   int flags, int np, void* packed,
+                                                   void* packed_transposed,
+                                                   msmd_stream_t stream) {
+  if (!packed_transposed) return MSMD_ERR_INVALID_ARG;
+  return pack_split(w, kvol, cin, cout, flags, np, packed, packed_transposed, (hipStream_t)stream);
 }
 
 MSMD_EXPORT int msmd_spconv_fwd_split_supported(int cin, int cout, int kvol) {

@@ -345,6 +345,25 @@ def pack_weight_split(weight, planes=3, transpose=False, krsc=False):
     return packed
 
 
+def pack_weight_split_pair(weight, planes=3, krsc=False):
+    """(pack_weight_split(w), pack_weight_split(w, transpose=True)) in one launch."""
+    _need_cuda(weight)
+    w = weight.contiguous().float()
+    if krsc:
+        cout, cin = w.shape[0], w.shape[-1]
+        kvol = w.numel() // (cout * cin)
+    else:
+        kvol, cin, cout = w.shape
+    a = torch.empty((lib.msmd_spconv_packed_split_bytes(kvol, cin, cout, planes),),
+                    dtype=torch.uint8, device=w.device)
+    b = torch.empty((lib.msmd_spconv_packed_split_bytes(kvol, cout, cin, planes),),
+                    dtype=torch.uint8, device=w.device)
+    check(lib.msmd_spconv_pack_weight_split_pair(_p(w), kvol, cin, cout, 2 if krsc else 0, planes,
+                                                 _p(a), _p(b), _stream()),
+          "msmd_spconv_pack_weight_split_pair")
+    return a, b
+
+
 def permute_cols(nbr, order):
     """nbr[K,n] -> the table in tile order: out[k][p] = nbr[k][order[p]]."""
     _need_cuda(nbr, order)

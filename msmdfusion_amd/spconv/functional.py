@@ -86,9 +86,14 @@ class _SparseConvFunction(Function):
         ctx.rb, ctx.krsc = rb, krsc
         ctx.save_for_backward(features, weight)
         c_in, c_out = (weight.shape[-1], weight.shape[0]) if krsc else weight.shape[1:]
+        ctx.packed_t = None
         if _use_split(c_in, c_out, rb.nbr_fwd.shape[0], features.shape[0]):
             np_ = conv_planes()
-            packed = K.pack_weight_split(weight, np_, krsc=krsc)
+            if ctx.needs_input_grad[0] and _use_split(c_out, c_in, rb.nbr_fwd.shape[0], rb.n_out):
+                # dgrad will want W^T packed: both images in this launch
+                packed, ctx.packed_t = K.pack_weight_split_pair(weight, np_, krsc=krsc)
+            else:
+                packed = K.pack_weight_split(weight, np_, krsc=krsc)
             table, order = rb.tiling_fwd()
             return K.conv_forward_split(features, packed, table, rb.n_out, c_out, np_,
                                         row_order=order)
@@ -119,7 +124,8 @@ class _SparseConvFunction(Function):
         if ctx.needs_input_grad[0] and _use_split(c_out, c_in, rb.nbr_fwd.shape[0],
                                                   grad_out.shape[0]):
             np_ = conv_planes()
-            packed_t = K.pack_weight_split(weight, np_, transpose=True, krsc=krsc)
+            packed_t = ctx.packed_t if ctx.packed_t is not None else \
+                K.pack_weight_split(weight, np_, transpose=True, krsc=krsc)
             table, order = rb.tiling_bwd()
             d_feat = K.conv_forward_split(grad_out, packed_t, table, rb.n_in, c_in, np_,
                                           weight_flip=rb.is_subm, row_order=order)

@@ -611,3 +611,15 @@ def test_rulebook_tiling_one_call(dev, n, kvol):
         assert torch.equal(unions(order), unions(ref))
     only_order, none = K.rulebook_tiling(nbr, want_table=False)
     assert none is None and torch.equal(only_order, order)
+
+
+@pytest.mark.parametrize("cin,cout,krsc", [(64, 128, False), (128, 128, True), (96, 32, True)])
+def test_pack_weight_split_pair(dev, cin, cout, krsc):
+    from msmdfusion_amd import kernels as K
+    w = torch.randn(27, cin, cout, device=dev)
+    if krsc:
+        w = w.permute(2, 0, 1).contiguous().view(cout, 3, 3, 3, cin)
+    for planes in (3, 1):
+        a, b = K.pack_weight_split_pair(w, planes, krsc=krsc)
+        assert torch.equal(a, K.pack_weight_split(w, planes, krsc=krsc))
+        assert torch.equal(b, K.pack_weight_split(w, planes, transpose=True, krsc=krsc))
