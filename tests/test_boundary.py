@@ -138,3 +138,25 @@ def test_hot_path_builds_from_the_configs():
     assert any(k.startswith("aggregation_blocks") for k in mk)
     _, _, enc_l, mm_l = C.build_hot_path(C.TRANSFUSION_L)
     assert mm_l is None and set(enc_l.state_dict().keys()) == keys
+
+
+def test_tiling_rank_table_matches_its_derivation():
+    """kRank27 (csrc/spconv.hip), the bit each 3x3x3 offset gets in the tiling sort key,
+    is the rank of the offset under (|dz|+|dy|+|dx|, |dz|, |dy|): centre lowest, then the
+    face, edge and corner neighbours -- the order tools/order_sim.py evaluates."""
+    import re
+    src = open(os.path.join(ROOT, "msmdfusion_amd", "csrc", "spconv.hip")).read()
+    m = re.search(r"kRank27\[27\]\s*=\s*\{([^}]*)\}", src)
+    assert m, "kRank27 not found"
+    table = [int(x) for x in m.group(1).replace("\n", " ").split(",")]
+    assert sorted(table) == list(range(27))
+
+    def cls(k):     # offset k = (kz*3 + ky)*3 + kx  (spconv geometry.h:62-73)
+        dz, dy, dx = k // 9 - 1, (k // 3) % 3 - 1, k % 3 - 1
+        return (abs(dz) + abs(dy) + abs(dx), abs(dz), abs(dy))
+    by_rank = sorted(range(27), key=cls)
+    want = [0] * 27
+    for bit, k in enumerate(by_rank):
+        want[k] = bit
+    assert table == want
+    assert table[13] == 0 and max(table[k] for k in (0, 2, 6, 8, 18, 20, 24, 26)) == 26
