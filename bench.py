@@ -1,17 +1,28 @@
 #!/usr/bin/env python
-"""bench.py -- the MSMDFusion sparse-voxel hot path on MI355X.
+"""bench.py -- the MSMDFusion sparse-voxel fusion hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): TransFusion-L voxel backbone
-(configs/transfusion_nusc_voxel_L.py: voxelize 0.075 m -> HardSimpleVFE ->
-SparseEncoder 5->16->32->64->128 -> BEV [B,256,180,180]), forward + backward +
-AdamW step, samples_per_gpu = 4, synthetic nuScenes-shaped clouds (seeded,
-resident in HBM before the timed region), fp32 (the reference's precision).
+Headline workload = BASELINE.json configs[2], the configuration the metric is
+quoted on: MSMDFusion-LC (configs/MSMDFusion_nusc_voxel_LC.py) sparse section of
+MSMDFusionDetector.extract_pts_feat (MSMDFusion.py:421-443): LiDAR voxelization
++ SparseEncoder (frozen, tools/train.py:185-219), virtual-point voxels at four
+scales, voxel_modality_split, GMA-Conv with FPS / ball-query neighbour search,
+sparse_add, downscale convs -> BEV [B,640,180,180]; forward + backward + AdamW,
+samples_per_gpu = 2 (config :104), synthetic nuScenes-shaped inputs (seeded,
+resident in HBM before the timed region), fp32-equivalent arithmetic.
 
-One "step" = voxelize 4 clouds + forward + backward + optimizer step on every
-rank; value = samples/s over all ranks.  Prints ONE JSON line (rank 0).
+One "step" = the whole path over one batch on every rank; value = samples/s over
+all ranks.  Rank 0 prints ONE JSON line.  At N = 1 the line also carries
+  roofline      the dominant conv kernel, timed live with HIP events
+  cpu_baseline  the oracle port of the same path on the host cores (bounded sample)
+  also          the same measurement for configs[1] (TransFusion-L voxel backbone,
+                4 clouds/GPU, everything trained) -- a secondary line, not the headline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload lc|transfusion_l]
+                    [--no-cpu-baseline] [--no-also] [--no-profile]
+
+`--gpus N` started as a plain process re-launches itself as N ranks under
+torch.distributed.run (one process per GPU, RCCL over xGMI); started by
+torch.distributed.run it reads RANK/LOCAL_RANK/WORLD_SIZE from the environment.
 """
 import argparse
 import json
@@ -19,9 +30,7 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
-import torch.distributed as dist
 import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,6 +44,21 @@ from msmdfusion_amd.configs import MSMDFUSION_LC, TRANSFUSION_L  # noqa: E402
 ENCODER_CFG = TRANSFUSION_L["model"]["pts_middle_encoder"]   # transfusion_nusc_voxel_L.py:161-169
 SAMPLES_PER_GPU = TRANSFUSION_L["samples_per_gpu"]           # :116
 
+WORKLOADS = {
+    "lc": dict(
+        metric="samples/sec MSMDFusion fwd+bwd nuScenes 0.075m voxel (MSMDFusion-LC sparse "
+               "fusion path)",
+        name="configs[2]: MSMDFusion-LC sparse path (LiDAR SparseEncoder frozen + 4-scale "
+             "virtual-point voxels + modality split + GMA-Conv + sparse_add + downscale -> BEV "
+             "640ch), fwd+bwd+AdamW, 2 x (28.7k LiDAR + 50k virtual pts)/GPU, 0.075 m voxels, fp32",
+        spg=MSMDFUSION_LC["samples_per_gpu"], bev_channels=640, settle=16),
+    "transfusion_l": dict(
+        metric="samples/sec TransFusion-L voxel backbone fwd+bwd (nuScenes 0.075m voxel)",
+        name="configs[1]: TransFusion-L voxel backbone (voxelize+VFE+SparseEncoder->BEV), "
+             "fwd+bwd+AdamW, 4 synthetic ~28.7k-pt clouds/GPU, 0.075 m voxels, fp32",
+        spg=SAMPLES_PER_GPU, bev_channels=256, settle=10),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -42,10 +66,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the secondary configs[1] measurement (N = 1 only)")
     ap.add_argument("--diag", action="store_true", help="print host enqueue vs step time")
-    ap.add_argument("--workload", choices=["transfusion_l", "lc"], default="transfusion_l",
-                    help="transfusion_l = BASELINE configs[1] (the headline); lc = configs[2], "
-                         "the full MSMDFusion-LC sparse path (virtual points, GMA-Conv, sparse_add)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="lc",
+                    help="lc = BASELINE configs[2], the metric's configuration (the headline); "
+                         "transfusion_l = configs[1], the LiDAR-only voxel backbone")
     ap.add_argument("--no-profile", action="store_true",
                     help="skip per-launch event timing of the conv kernels")
     return ap.parse_args()
@@ -123,161 +149,95 @@ class FusionBackbone(torch.nn.Module):
         return torch.cat([x, x_mm], 1)
 
 
-def _cpu_baseline_one(seed):
-    """Reference algorithm on the host (oracle port, OpenMP): one cloud through
-    voxelization, every rulebook and all 21 sparse convs forward + backward
-    (dgrad + wgrad); BN/ReLU (elementwise, <1 % of the work) are skipped."""
-    from msmdfusion_amd import synthetic as S
+def cpu_baseline(workload, seed=0, budget_s=14.0, max_samples=24):
+    """The host baseline on a bounded sample: whole synthetic samples through the
+    oracle port (oracle/baseline.py), one after the other, until ~budget_s of CPU
+    work is done (the first one also warms the OpenMP pool and the page cache and
+    is not counted when more follow)."""
+    from oracle import baseline as B
     from oracle import oracle as O
     # memory-bound gather/scatter loops stop scaling well before the socket is
     # full (256 hardware threads were slower than 8 here): cap at 32
     cores = O.set_threads(min(os.cpu_count() or 1, 32))
-    pts = S.lidar_sweep(seed)
-    t0 = time.perf_counter()
-    v, c, n = O.hard_voxelize(pts, S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 120000)
-    feat = O.voxel_mean(v, n)
-    idx = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
-    rng = np.random.RandomState(0)
-    shape = list(S.SPARSE_SHAPE)
-    layers = [("subm", 5, 16)]
-    for i, blocks in enumerate(ENCODER_CFG["encoder_channels"]):
-        cin = layers[-1][2]
-        for j, cout in enumerate(blocks):
-            last = j == len(blocks) - 1 and i != 3
-            if last:
-                layers.append(("down%d" % i, cin, cout))
-            else:
-                layers += [("subm", cout, cout), ("subm", cout, cout)]
-            cin = cout
-    layers.append(("out", 128, 128))
-    pads = {0: 1, 1: 1, 2: [0, 1, 1]}
-    macs = 0
-    cache = {}
-    for kind, cin, cout in layers:
-        if kind == "subm":
-            key = (idx.shape[0], tuple(shape))
-            if key not in cache:
-                cache[key] = O.get_indice_pairs(idx, 1, shape, 3, 1, 1, 1, True)
-            oi, pr, nm, osz = cache[key]
-            w = rng.randn(27, cin, cout).astype(np.float32) * 0.05
-            out = O.indice_conv_fwd(feat, w, pr, nm, oi.shape[0], subm=True)
-            O.indice_conv_bwd(feat, w, out, pr, nm, subm=True)
-        else:
-            ks, st, pd = (3, 2, pads[int(kind[4])]) if kind != "out" else ([3, 1, 1], [2, 1, 1], 0)
-            oi, pr, nm, osz = O.get_indice_pairs(idx, 1, shape, ks, st, pd, 1, False)
-            w = rng.randn(pr.shape[0], cin, cout).astype(np.float32) * 0.05
-            out = O.indice_conv_fwd(feat, w, pr, nm, oi.shape[0])
-            O.indice_conv_bwd(feat, w, out, pr, nm)
-            idx, shape = oi, osz
-        macs += int(nm.sum()) * cin * cout
-        feat = np.maximum(out, 0)
-    dt = time.perf_counter() - t0
-    return dict(value=round(1.0 / dt, 4), unit="samples/s", cores=cores, kind="port",
-                sample="1 synthetic cloud (seed %d, %d pts, %d voxels): voxelize + all rulebooks + "
-                       "21 sparse convs fwd+dgrad+wgrad with oracle/msmd_oracle.c (OpenMP, %d "
-                       "threads), %.1f GMAC fwd, %.1f s" % (seed, pts.shape[0], c.shape[0], cores,
-                                                           macs / 1e9, dt))
-
-
-def cpu_baseline(seed, budget_s=12.0, max_clouds=24):
-    """The host baseline on a bounded sample: whole synthetic clouds, one after the
-    other, until ~budget_s of CPU work is done (the first one also warms the
-    OpenMP pool and the page cache and is not counted when more follow)."""
+    one = B.lc_sample if workload == "lc" else B.transfusion_l_sample
     runs = []
     t_all = time.perf_counter()
-    while len(runs) < max_clouds and (time.perf_counter() - t_all < budget_s or len(runs) < 2):
-        runs.append(_cpu_baseline_one(seed + len(runs)))
+    while len(runs) < max_samples and (time.perf_counter() - t_all < budget_s or len(runs) < 2):
+        runs.append(one(seed + len(runs)))
     timed = runs[1:] if len(runs) > 1 else runs
-    secs = [1.0 / r["value"] for r in timed]
-    out = dict(timed[-1])
-    out["value"] = round(len(secs) / sum(secs), 4)
-    out["sample"] = ("%d synthetic clouds (seeds %d..%d, ~28.7k pts / ~18.9k voxels each, first one "
-                     "untimed warm-up), each: voxelize + all rulebooks + 21 sparse convs "
-                     "fwd+dgrad+wgrad with oracle/msmd_oracle.c (OpenMP, %d threads), 29.2 GMAC fwd; "
-                     "%.1f s of CPU work, %.2f s per cloud"
-                     % (len(secs), seed + 1, seed + len(runs) - 1, out["cores"], sum(secs),
-                        sum(secs) / len(secs)))
-    return out
+    secs = sum(r["seconds"] for r in timed)
+    r = timed[-1]
+    if workload == "lc":
+        what = ("LiDAR voxelize + rulebooks + 21 encoder convs fwd (frozen), 4-scale virtual-point "
+                "voxelize + mean VFE, modality split, FPS/ball-query neighbour search, gates, 16 "
+                "fusion-stack convs fwd+dgrad+wgrad + sparse_add; %.1f GMAC fwd (%.1f in the "
+                "fusion stack); ~%dk + %dk pts -> ~%dk + %dk voxels"
+                % (r["gmac_fwd"], r["gmac_fwd_fusion"], r["points"] // 1000,
+                   r["virtual_points"] // 1000, r["voxels"] // 1000, r["virtual_voxels"] // 1000))
+    else:
+        what = ("voxelize + all rulebooks + 21 sparse convs fwd+dgrad+wgrad; %.1f GMAC fwd; ~%.1fk "
+                "pts -> ~%.1fk voxels" % (r["gmac_fwd"], r["points"] / 1e3, r["voxels"] / 1e3))
+    return dict(value=round(len(timed) / secs, 4), unit="samples/s", cores=cores, kind="port",
+                sample="%d synthetic samples (seeds %d..%d, first one untimed warm-up), each: %s; "
+                       "oracle/msmd_oracle.c restatement of the reference CPU path, OpenMP %d "
+                       "threads; BN/ReLU/optimizer skipped (elementwise); the real reference loop "
+                       "(torch::mm per offset + index_add) is slower than this port; %.1f s of CPU "
+                       "work, %.2f s per sample"
+                       % (len(timed), seed + (1 if len(runs) > 1 else 0), seed + len(runs) - 1,
+                          what, cores, secs, secs / len(timed)))
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-
+def run_workload(workload, args, dev, rank, world, profile):
+    """Settle + warm-up + K timed steps of one workload on this rank.
+    -> (result dict for rank 0's JSON, profile list | None)."""
+    from msmdfusion_amd import distributed as D
     from msmdfusion_amd import kernels as K
     from msmdfusion_amd import synthetic as S
+    from msmdfusion_amd.prefetch import IndexPrefetcher
 
+    wl = WORKLOADS[workload]
+    lc = workload == "lc"
+    spg = wl["spg"]
     torch.manual_seed(0)
-    lc = args.workload == "lc"
-    spg = 2 if lc else SAMPLES_PER_GPU      # configs/MSMDFusion_nusc_voxel_LC.py:104
     model = (FusionBackbone() if lc else Backbone()).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
-    net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank],
-                                                        gradient_as_bucket_view=True)
-    # AdamW lr=1e-4, wd=0.01: configs/transfusion_nusc_voxel_L.py optimizer
+    net = D.wrap_data_parallel(model, device_ids=[dev.index])
+    # AdamW lr=1e-4, wd=0.01: the configs' optimizer
     # (fused=True: torch's single multi-tensor kernel per step instead of ~10 foreach launches)
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01,
                             fused=os.environ.get("MSMD_FUSED_ADAMW", "1") == "1")
 
-    clouds = [torch.from_numpy(S.lidar_sweep(rank * spg + i)).to(dev) for i in range(spg)]
-    virtual = [torch.from_numpy(S.virtual_points(rank * spg + i)).to(dev) for i in range(spg)] \
-        if lc else None
-    target = torch.randn(spg, 640 if lc else 256, 180, 180, device=dev)
+    ids = D.shard_sample_ids(rank, world, spg)      # disjoint samples per rank (weak scaling)
+    clouds = [torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in ids]
+    batch = (clouds,)
+    if lc:
+        batch = (clouds, [torch.from_numpy(S.virtual_points(i)).to(dev) for i in ids])
+    target = torch.randn(spg, wl["bev_channels"], 180, 180, device=dev)
 
     prefetch = None
     if os.environ.get("MSMD_PREFETCH", "1") == "1":
-        from msmdfusion_amd.prefetch import IndexPrefetcher
         # worker thread: pays on the LC path (its prepare() waits ~10 ms on host reads,
         # 70 -> 77 samples/s); configs[1] is GPU-bound either way (366 vs 368)
         threaded = os.environ.get("MSMD_PREFETCH_THREAD", "1" if lc else "0") == "1"
         if threaded:    # two threads share the GIL: hand it over promptly (default 5 ms)
             sys.setswitchinterval(float(os.environ.get("MSMD_SWITCH_INTERVAL", "0.0005")))
         prefetch = IndexPrefetcher(model.prepare, dev, threaded=threaded)
-        batch = (clouds, virtual) if lc else (clouds,)
-        pending = [prefetch.submit(*batch)]
-
-    def step():
-        if prefetch is not None:
-            pending.append(prefetch.submit(*batch))      # next step's batch
-            ticket = pending.pop(0)
-            bev = net(*batch, prepared=prefetch.take(ticket))
-        else:
-            bev = net(clouds, virtual) if lc else net(clouds)
-        loss = (bev * target).mean()
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 10.0)     # grad_clip max_norm=10 (config)
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-        if prefetch is not None:
-            prefetch.retire(ticket)
-        return loss
+    # grad_clip max_norm=10 (config); the step structure is msmdfusion_amd.distributed.TrainStep
+    step = D.TrainStep(net, params, opt, lambda bev: (bev * target).mean(), prefetch, 10.0)
+    step.prime(batch)
 
     # Setup, untimed: let torch's caching allocator reach its steady state before
-    # the W warm-up steps.  The LC path allocates on two streams (record_stream
-    # defers block reuse), and needs ~8 steps before no step calls hipMalloc any
-    # more (37 ms -> 28 ms per step, tools/lc_steps.py).
-    # (LC with the prefetcher allocates on four streams: 16.)
-    for _ in range((16 if lc else 10) if (lc or prefetch is not None) else 2):
-        step()
+    # the W warm-up steps.  The LC path allocates on four streams (record_stream
+    # defers block reuse) and needs ~16 steps before no step calls hipMalloc any more.
+    for _ in range(wl["settle"] if (lc or prefetch is not None) else 2):
+        step(batch)
     for _ in range(args.warmup):
-        step()
+        step(batch)
     if args.diag and rank == 0:     # host enqueue time vs device time, outside the timed region
         for _ in range(3):
             torch.cuda.synchronize()
             a = time.perf_counter()
-            step()
+            step(batch)
             b = time.perf_counter()
             torch.cuda.synchronize()
             c = time.perf_counter()
@@ -285,31 +245,26 @@ def main():
                   file=sys.stderr)
     # Per-launch HIP events (recorded on the launch stream) bracket every conv
     # launch of a few timed steps only: on ROCm a timing event is a barrier
-    # packet that drains the queue, so bracketing all ~85 launches of every
+    # packet that drains the queue, so bracketing all launches of every
     # step would slow the measured throughput by ~25 %.
-    prof = None if args.no_profile else []
+    prof = [] if profile else None
     sampled = set() if prof is None else {0, args.steps // 2}
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         K.PROFILE = prof if i in sampled else None
-        loss = step()
+        loss = step(batch)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     elapsed = time.perf_counter() - t0
     K.PROFILE = None
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = D.global_max(elapsed, device=dev)
     assert torch.isfinite(loss).item()
     # untimed sanity step: every parameter and every gradient of the trained modules is
     # finite (a skipped tile or a stale buffer shows up as NaN/garbage here, not in the rate)
     loss = None
-    bev = net(clouds, virtual) if lc else net(clouds)
+    bev = net(*batch)
     (bev * target).mean().backward()
     bad = [n for n, p in model.named_parameters()
            if p.requires_grad and (p.grad is None and "blocks_2D" not in n and "blocks_mix" not in n
@@ -317,41 +272,74 @@ def main():
     bad += [n for n, p in model.named_parameters() if not torch.isfinite(p).all()]
     assert not bad, "non-finite parameters / gradients after the timed steps: %s" % bad[:5]
     opt.zero_grad(set_to_none=True)
+    n_samples = args.steps * spg * world
+    res = {"value": round(n_samples / elapsed, 3), "unit": "samples/s",
+           "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+           "config": {"workload": wl["name"], "global_batch": spg * world,
+                      "parallelism": "dp%d" % world, "index_prefetch": prefetch is not None,
+                      "trainable_params": sum(p.numel() for p in params)}}
+    res["roofline"] = roofline(prof, workload) if prof else None
+    del step, net, model, opt, prefetch
+    torch.cuda.empty_cache()
+    return res
 
+
+def main():
+    args = parse()
+    from msmdfusion_amd import distributed as D
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain process: become N ranks (one per GPU) and relay the line
+        D.require_gpus(args.gpus)
+        raise SystemExit(D.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    rank, local_rank, world = D.env_world()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with `python -m torch.distributed.run "
+                         "--nproc-per-node %d bench.py --gpus %d ...` (or start bench.py plainly "
+                         "and let it spawn its ranks)" % (args.gpus, world, args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    D.require_gpus(local_rank + 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    D.init_distributed(device=dev)      # RCCL (torch backend "nccl") when world > 1
+
+    head = run_workload(args.workload, args, dev, rank, world, not args.no_profile)
+    out = None
     if rank == 0:
-        n_samples = args.steps * spg * world
-        out = {
-            "metric": ("samples/sec MSMDFusion-LC sparse fusion path fwd+bwd (nuScenes 0.075m voxel)"
-                       if lc else
-                       "samples/sec TransFusion-L voxel backbone fwd+bwd (nuScenes 0.075m voxel)"),
-            "value": round(n_samples / elapsed, 3), "unit": "samples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[2]: MSMDFusion-LC sparse path (LiDAR SparseEncoder "
-                                    "frozen + 4-scale virtual-point voxels + modality split + "
-                                    "GMA-Conv + sparse_add + downscale -> BEV 640ch), fwd+bwd+"
-                                    "AdamW, 2 x (28.7k LiDAR + 50k virtual pts)/GPU, fp32"
-                                    if lc else
-                                    "configs[1]: TransFusion-L voxel backbone (voxelize+VFE+"
-                                    "SparseEncoder->BEV), fwd+bwd+AdamW, 4 synthetic ~28.7k-pt "
-                                    "clouds/GPU, 0.075 m voxels, fp32"),
-                       "global_batch": spg * world, "parallelism": "dp%d" % world,
-                       "index_prefetch": prefetch is not None},
-        }
-        out["roofline"] = roofline(prof) if prof else None
-        if world == 1 and not args.no_cpu_baseline and not lc:
-            out["cpu_baseline"] = cpu_baseline(0)
+        out = {"metric": WORKLOADS[args.workload]["metric"], "value": head["value"],
+               "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "rccl_ranks": D.rccl_ranks(), "config": head["config"],
+               "roofline": head["roofline"]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+    if world == 1 and not args.no_also and args.workload == "lc":
+        also = run_workload("transfusion_l", args, dev, rank, world, not args.no_profile)
+        also["metric"] = WORKLOADS["transfusion_l"]["metric"]
+        if not args.no_cpu_baseline:
+            also["cpu_baseline"] = cpu_baseline("transfusion_l", budget_s=8.0)
+        out["also"] = {"configs[1]": also}
+    if rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    D.shutdown()
 
 
-def pmc_traffic(kernel_name):
+def pmc_summary_path(workload):
+    """The newest committed PMC summary of this workload (profiles/rNN_pmc_summary_<wl>.json;
+    round 1 wrote one file, for configs[1])."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary_%s.json" % workload)))
+    if not found and workload == "transfusion_l":
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    return found[-1] if found else None
+
+
+def pmc_traffic(kernel_name, workload):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if not os.path.exists(path):
-        return None, None
+    path = pmc_summary_path(workload)
+    if path is None:
+        return None, None, None
     kernels = json.load(open(path))["kernels"]
     if "NT=" in kernel_name:    # "spconv_fwd_split_kernel<NT=8>" -> "spconv_fwd_split_kernel<8, ..."
         nt = kernel_name.split("NT=")[1].rstrip(">")
@@ -361,10 +349,10 @@ def pmc_traffic(kernel_name):
     cands = sorted(k for k in kernels if k.startswith(prefix))
     key = cands[-1] if cands else None
     e = kernels.get(key, {})
-    return e.get("hbm_bytes_per_launch"), e.get("mfma_pipe_busy_frac")
+    return e.get("hbm_bytes_per_launch"), e.get("mfma_pipe_busy_frac"), os.path.relpath(path, ROOT)
 
 
-def roofline(prof):
+def roofline(prof, workload):
     """Dominant kernel = the conv kernel class with the most accumulated time.
     achieved = algorithmic flops (2 * pairs * Cin * Cout, the reference's MAC
     count mmdet3d/apis/flops_counter.py:9-12) / measured launch duration."""
@@ -395,7 +383,7 @@ def roofline(prof):
     total_ms = sum(g["ms"] for g in groups.values())
     name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
-    traffic, mfma_busy = pmc_traffic(name)
+    traffic, mfma_busy, pmc_file = pmc_traffic(name, workload)
     peak, peak_note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA (v_mfma_f32_16x16x4_f32)"
     if name.startswith("spconv_fwd_split") or name.startswith("spconv_wgrad_split"):
         from msmdfusion_amd.spconv.functional import conv_planes
@@ -410,8 +398,8 @@ def roofline(prof):
             "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic,
             "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes "
-                            "(profiles/r01_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) KiB, "
-                            "gfx950 correction), not re-measured in this run",
+                            "(%s: (2*FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction), not "
+                            "re-measured in this run" % pmc_file,
             "mfma_pipe_busy_frac_pmc": mfma_busy,
             "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2), "launches": g["launches"],
             "share_of_conv_time": round(g["ms"] / total_ms, 3),

@@ -66,6 +66,93 @@ def barrier():
         dist.barrier()
 
 
+def rccl_ranks():
+    """Ranks in the RCCL communicator the gradients are all-reduced over (0: single
+    process, no communicator)."""
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return dist.get_world_size()
+    return 0
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def require_gpus(n):
+    """--gpus N means N ranks on N distinct GPUs of this node: fail before any
+    process is spawned when fewer are visible."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit("asked for %d GPUs but %d visible (HIP_VISIBLE_DEVICES=%s)"
+                         % (n, have, os.environ.get("HIP_VISIBLE_DEVICES", "<unset>")))
+
+
+def launch_ranks(n, script, argv, port=None):
+    """Re-run `script argv` as n ranks under torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1 -- tools/dist_train.sh:8-9 does the same with
+    torch.distributed.launch) and return its exit code.  Used when a multi-GPU
+    entry point is started as a plain process."""
+    import socket
+    import subprocess
+    import sys
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           script] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+class TrainStep:
+    """One optimisation step of the data-parallel recipe, the way bench.py and
+    training run it on every rank:
+
+        submit batch i+1's index work (IndexPrefetcher) -> take batch i's ->
+        forward through the (DDP-wrapped) module with the prepared batch as a
+        keyword argument -> loss -> backward (DDP all-reduces gradient buckets over
+        RCCL underneath it) -> clip_grad_norm_ (max_norm=10: the configs'
+        grad_clip) -> optimizer step -> retire the batch.
+
+    Backend-agnostic, so the same object is driven on CPU tensors with gloo in
+    tests/test_dist_cpu.py."""
+
+    def __init__(self, net, params, optimizer, loss_fn, prefetcher=None, max_norm=10.0):
+        self.net, self.params, self.optimizer = net, list(params), optimizer
+        self.loss_fn, self.prefetcher, self.max_norm = loss_fn, prefetcher, max_norm
+        self._pending = []
+
+    def prime(self, batch):
+        """Queue the index work of the first batch (call once before the loop)."""
+        if self.prefetcher is not None:
+            self._pending.append(self.prefetcher.submit(*batch))
+
+    def __call__(self, batch, next_batch=None):
+        pf = self.prefetcher
+        ticket = None
+        if pf is not None:
+            if not self._pending:
+                self.prime(batch)
+            self._pending.append(pf.submit(*(batch if next_batch is None else next_batch)))
+            ticket = self._pending.pop(0)
+            out = self.net(*batch, prepared=pf.take(ticket))
+        else:
+            out = self.net(*batch)
+        loss = self.loss_fn(out)
+        loss.backward()
+        if self.max_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+        if ticket is not None:
+            pf.retire(ticket)
+        return loss
+
+
 def freeze_unused_fusion_blocks(multimodal_encoder):
     """requires_grad=False for the blocks the forward never calls
     (sparse_multimodal_encoder_painting.py:142-156 vs :413-428)."""

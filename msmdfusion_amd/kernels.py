@@ -28,10 +28,31 @@ def _p(t):
 
 
 def _need_cuda(*ts):
+    """Every operand on the GPU, and on the CURRENT one: the C ABI launches on the
+    current HIP device and on torch's current stream of that device, so a tensor
+    living elsewhere (single-process multi-GPU, a forgotten set_device) would be
+    touched from the wrong device and stream -- refuse instead."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("msmdfusion_amd kernels need CUDA/ROCm tensors "
                                "(there is no CPU fallback)")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError("tensor on cuda:%d but the current device is cuda:%d: wrap the "
+                               "call in torch.cuda.device(tensor.device)" % (t.device.index, cur))
+
+
+def _need_bzyx(*index_tensors):
+    """The index kernels read rows as one int4 (b,z,y,x): anything else (the
+    5-column tensors voxel_modality_split leaves, MSMDFusion.py:322-323) would be
+    read misaligned and past the end."""
+    for t in index_tensors:
+        if t.dim() != 2 or t.shape[1] != 4:
+            raise ValueError("expected [N,4] (b,z,y,x) voxel indices, got %s" % (tuple(t.shape),))
 
 
 def _ws(nbytes, device):
@@ -127,6 +148,7 @@ def conv_output_size(in_shape, ksize, stride, padding, dilation=(1, 1, 1)):
 
 def rulebook_subm(indices, batch_size, spatial_shape, ksize):
     """-> nbr[K,N] int32 (output-stationary neighbour table)."""
+    _need_bzyx(indices)
     _need_cuda(indices)
     idx = indices.contiguous().int()
     n = idx.shape[0]
@@ -141,6 +163,7 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize):
 
 def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, need_bwd=True):
     """-> (out_indices[M,4], nbr_fwd[K,M], nbr_bwd[K,N] | None, out_shape)"""
+    _need_bzyx(indices)
     _need_cuda(indices)
     idx = indices.contiguous().int()
     n = idx.shape[0]
@@ -486,6 +509,7 @@ def bn_act_backward(x, y, dy, gamma, save_mean, save_invstd, training, relu, wan
 
 # ------------------------------------------------------------------ dense / sets
 def dense_scatter(feat, indices, batch_size, spatial_shape):
+    _need_bzyx(indices)
     _need_cuda(feat, indices)
     f = feat.contiguous().float()
     n, c = f.shape
@@ -498,6 +522,7 @@ def dense_scatter(feat, indices, batch_size, spatial_shape):
 
 
 def dense_gather(dense, indices, spatial_shape):
+    _need_bzyx(indices)
     _need_cuda(dense, indices)
     dn = dense.contiguous().float()
     b, c = dn.shape[0], dn.shape[1]
@@ -511,6 +536,7 @@ def dense_gather(dense, indices, spatial_shape):
 
 def sparse_add(feat_a, idx_a, feat_b, idx_b, batch_size, spatial_shape):
     """-> (out_indices, out_feat, map_a, map_b)"""
+    _need_bzyx(idx_a, idx_b)
     _need_cuda(feat_a, idx_a, feat_b, idx_b)
     fa, fb = feat_a.contiguous().float(), feat_b.contiguous().float()
     ia, ib = idx_a.contiguous().int(), idx_b.contiguous().int()
@@ -534,6 +560,7 @@ def sparse_add(feat_a, idx_a, feat_b, idx_b, batch_size, spatial_shape):
 
 def sparse_add_index(idx_a, idx_b, batch_size, spatial_shape):
     """Index half of sparse_add -> (out_indices[m,4], map_a[na], map_b[nb])."""
+    _need_bzyx(idx_a, idx_b)
     _need_cuda(idx_a, idx_b)
     ia, ib = idx_a.contiguous().int(), idx_b.contiguous().int()
     na, nb = ia.shape[0], ib.shape[0]
@@ -568,6 +595,7 @@ def sparse_add_rows(feat_a, map_a, feat_b, map_b, n_out):
 
 def modality_split(idx_3d, idx_2d, batch_size, spatial_shape):
     """-> (mix3d[n3], mix2d[n2], pair_3d[m], pair_2d[m])"""
+    _need_bzyx(idx_3d, idx_2d)
     _need_cuda(idx_3d, idx_2d)
     a, b = idx_3d.contiguous().int(), idx_2d.contiguous().int()
     n3, n2 = a.shape[0], b.shape[0]

@@ -183,22 +183,29 @@ class SparseMultiModalEncoderPaint(nn.Module):
         only_2D_rows = (idx2_5[:, 1] == 0).nonzero().flatten()
         o2_idx = idx2_5.index_select(0, only_2D_rows)
         n_raw = o2_idx.shape[0]
+        # the neighbour search runs on the real only-2D rows, which are grouped by
+        # sample; the all-zero pad rows (:208-225) are appended AFTER them whatever
+        # their sample id, carry zero features (so their gate is irrelevant) and get
+        # "no neighbour" -- slicing the padded tensor by per-sample counts would be
+        # wrong whenever a sample other than the last one is the empty one
+        o2_bzyx_raw = o2_idx[:, zyx].contiguous()
         o2_idx, _ = self.pad_missing_batch_id(o2_idx, o2_idx.new_zeros((n_raw, 0)).float(),
                                               batch_size)
-        o2_bzyx = o2_idx[:, zyx].contiguous()
         idx3 = idx3_5[:, zyx].contiguous()
         return dict(only_3D_rows=only_3D_rows, only_2D_rows=only_2D_rows, o2_idx=o2_idx,
-                    o2_bzyx=o2_bzyx, idx3=idx3, n_pad=o2_idx.shape[0] - n_raw,
-                    counts=self.sample_counts(o2_bzyx, idx3, batch_size))
+                    o2_bzyx=o2_bzyx_raw, idx3=idx3, n_pad=o2_idx.shape[0] - n_raw,
+                    counts=self.sample_counts(o2_bzyx_raw, idx3, batch_size))
 
     def plan_stage_nn(self, plan, counts, batch_size, fps_num, radius, max_cluster_samples,
                       dist_thresh):
         """The neighbour search of a planned stage (no host read: `counts` are the
         nested lists already on the host).  Stream-agnostic: the fusion path
         enqueues it on a side stream under the LiDAR encoder's forward pass."""
-        plan["nn3"] = self.nearest_3d_of_only_2d(plan["o2_bzyx"], plan["idx3"], batch_size,
-                                                 fps_num, radius, max_cluster_samples,
-                                                 dist_thresh, counts=counts)
+        nn3 = self.nearest_3d_of_only_2d(plan["o2_bzyx"], plan["idx3"], batch_size, fps_num,
+                                         radius, max_cluster_samples, dist_thresh, counts=counts)
+        if plan["n_pad"]:
+            nn3 = torch.cat([nn3, nn3.new_full((plan["n_pad"],), -1)])
+        plan["nn3"] = nn3
         return plan
 
     def plan_stage_tensors(self, plan, idx3_5, idx2_5, syn_mix_2D, shape3, shape2, batch_size,

@@ -25,15 +25,24 @@ class IndexPrefetcher:
         """threaded: run prepare_fn on a worker thread.  Its host reads (voxel and
         pair counts) wait for the side stream with the GIL released, so the calling
         thread keeps the main stream fed meanwhile -- without it those waits come
-        straight out of the time the host has to enqueue the feature pass."""
+        straight out of the time the host has to enqueue the feature pass.
+
+        On a CPU device (the gloo tests of the multi-rank step structure) there
+        are no streams: prepare_fn runs inline or on the worker thread, and the
+        hand-over / retire events are no-ops."""
         self.prepare_fn = prepare_fn
         self.device = torch.device(device)
-        self.side = torch.cuda.Stream(device=self.device, priority=priority)
+        self.on_gpu = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device, priority=priority) if self.on_gpu \
+            else None
         self._retired = collections.deque()
         self.max_behind = 2      # steps the host may run ahead of the main stream
         self._pool = ThreadPoolExecutor(1, thread_name_prefix="msmd-index") if threaded else None
 
     def _run(self, grad, args, kw):
+        if not self.on_gpu:
+            with torch.set_grad_enabled(grad):
+                return {"value": self.prepare_fn(*args, **kw), "ready": None}
         torch.cuda.set_device(self.device)          # current device / stream / grad mode
         with torch.set_grad_enabled(grad), torch.cuda.stream(self.side):    # are per thread
             value = self.prepare_fn(*args, **kw)
@@ -51,10 +60,13 @@ class IndexPrefetcher:
     def take(self, ticket):
         if "future" in ticket:
             ticket.update(ticket.pop("future").result())
-        torch.cuda.current_stream(self.device).wait_event(ticket["ready"])
+        if ticket["ready"] is not None:
+            torch.cuda.current_stream(self.device).wait_event(ticket["ready"])
         return ticket["value"]
 
     def retire(self, ticket):
+        if not self.on_gpu:
+            return
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
         self._retired.append((done, ticket))

@@ -56,14 +56,22 @@ class SparseEncoder(nn.Module):
         planned = spconv.SparseConvTensor(
             torch.empty((coors.shape[0], 0), dtype=torch.float32, device=coors.device),
             coors.int(), self.sparse_shape, batch_size)
-        convs = [m for m in self.modules() if isinstance(m, spconv.SparseConvolution)]
-        outs = []
+        def convs(block):
+            return [m for m in block.modules() if isinstance(m, spconv.SparseConvolution)]
+
         # a frozen encoder over inputs that carry no gradient (the LC recipe) never runs
         # backward: no pair lists, no backward tilings
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        planned.plan(convs, need_grad=need_grad, strided_outputs=outs)
-        stages = [(planned.indices, list(self.sparse_shape))] + outs[:self.stage_num - 1]
-        stages.append(stages[-1])        # the last stage has no strided conv
+        # walk the module tree the way forward() does and note the voxel set after
+        # conv_input and after every encoder layer: with block_type='basicblock' the
+        # strided conv closes a stage, with 'conv_module' it opens the next one, so
+        # the sets cannot be derived from the list of strided convs alone
+        t = planned.plan(convs(self.conv_input), need_grad)
+        stages = [(t.indices, list(t.spatial_shape))]
+        for layer in self.encoder_layers:
+            t = t.plan(convs(layer), need_grad)
+            stages.append((t.indices, list(t.spatial_shape)))
+        t.plan(convs(self.conv_out), need_grad)
         return planned, stages
 
     def forward(self, voxel_features, coors, batch_size, planned=None):

@@ -134,6 +134,8 @@ class SparseConvTensor:
                  indice_dict: Optional[dict] = None, benchmark: bool = False):
         assert features.dim() == 2 and indices.dim() == 2
         assert indices.dtype == torch.int32, "indices must be int32 (b,z,y,x)"
+        assert features.shape[0] == indices.shape[0], \
+            f"{features.shape[0]} feature rows for {indices.shape[0]} voxels"
         self._features = features
         self.indices = indices
         self.spatial_shape = [int(s) for s in spatial_shape]
@@ -162,6 +164,8 @@ class SparseConvTensor:
         self._features = val
 
     def replace_feature(self, feature: torch.Tensor):
+        assert feature.shape[0] == self.indices.shape[0], \
+            f"{feature.shape[0]} feature rows for {self.indices.shape[0]} voxels"
         new = self.shadow_copy()
         new._features = feature
         return new
@@ -189,6 +193,10 @@ class SparseConvTensor:
         return self.indice_dict.get(key)
 
     def cached_rulebook(self, ksize, stride, padding, dilation, subm):
+        # after voxel_modality_split the tensors carry 5-column indices
+        # (b,mix,z,y,x: MSMDFusion.py:322-323); spconv asserts on ndim there too
+        assert self.indices.shape[1] == 4, \
+            f"sparse conv needs (b,z,y,x) indices, got {self.indices.shape[1]} columns"
         ident = (self.indices.data_ptr(), self.indices.shape[0], tuple(self.spatial_shape),
                  tuple(ksize), tuple(stride), tuple(padding), tuple(dilation), bool(subm))
         hit = self._rb_cache.get(ident)
@@ -228,6 +236,8 @@ class SparseConvTensor:
         """[B,C,D,H,W] (structure.py:55-64); channels_last returns the permuted
         view of the same buffer."""
         from .functional import dense as _dense
+        assert self.indices.shape[1] == 4, \
+            f"dense() needs (b,z,y,x) indices, got {self.indices.shape[1]} columns"
         out = _dense(self._features, self.indices, self.batch_size, self.spatial_shape)
         if channels_first:
             return out

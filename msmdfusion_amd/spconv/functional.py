@@ -41,6 +41,35 @@ def _wants_order(c_in, c_out):
     return c_out >= 64 and c_in % 16 == 0
 
 
+_F32_TILE_COUNTS = (12, 8, 6, 5, 4, 3, 2, 1)    # instantiations of msmd_spconv_fwd_f32
+
+
+def _conv_f32(x, weight, krsc, transpose, nbr, n_out, weight_flip=False, row_order=None):
+    """The fp32-MFMA kernel over any output width: its instantiations cover
+    1-6, 8 and 12 tiles of 16 output channels; other widths (97..112, 129..176,
+    > 192 channels) run as column passes over slices of the weight."""
+    if krsc:
+        c_out = weight.shape[-1] if transpose else weight.shape[0]
+    else:
+        c_out = weight.shape[1] if transpose else weight.shape[2]
+    tiles = (c_out + 15) // 16
+    if tiles in _F32_TILE_COUNTS:
+        return K.conv_forward(x, K.pack_weight(weight, transpose=transpose, krsc=krsc), nbr,
+                              n_out, c_out, weight_flip=weight_flip, row_order=row_order)
+    outs, c0 = [], 0
+    while c0 < c_out:
+        left = (c_out - c0 + 15) // 16
+        width = min(16 * next(t for t in _F32_TILE_COUNTS if t <= left), c_out - c0)
+        if krsc:
+            w = weight[..., c0:c0 + width] if transpose else weight[c0:c0 + width]
+        else:
+            w = weight[:, c0:c0 + width, :] if transpose else weight[:, :, c0:c0 + width]
+        outs.append(K.conv_forward(x, K.pack_weight(w, transpose=transpose, krsc=krsc), nbr,
+                                   n_out, width, weight_flip=weight_flip, row_order=row_order))
+        c0 += width
+    return torch.cat(outs, 1)
+
+
 _SIDE_STREAMS = {}
 
 
@@ -97,9 +126,8 @@ class _SparseConvFunction(Function):
             table, order = rb.tiling_fwd()
             return K.conv_forward_split(features, packed, table, rb.n_out, c_out, np_,
                                         row_order=order)
-        packed = K.pack_weight(weight, krsc=krsc)
-        return K.conv_forward(features, packed, rb.nbr_fwd, rb.n_out, c_out,
-                              row_order=rb.order_fwd() if _wants_order(c_in, c_out) else None)
+        return _conv_f32(features, weight, krsc, False, rb.nbr_fwd, rb.n_out,
+                         row_order=rb.order_fwd() if _wants_order(c_in, c_out) else None)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -130,14 +158,11 @@ class _SparseConvFunction(Function):
             d_feat = K.conv_forward_split(grad_out, packed_t, table, rb.n_in, c_in, np_,
                                           weight_flip=rb.is_subm, row_order=order)
         elif ctx.needs_input_grad[0]:
-            packed_t = K.pack_weight(weight, transpose=True, krsc=krsc)
             order = rb.order_bwd() if _wants_order(c_out, c_in) else None
-            if rb.is_subm:   # forward table + flipped weights == backward table
-                d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_fwd, rb.n_in, c_in,
-                                        weight_flip=True, row_order=order)
-            else:
-                d_feat = K.conv_forward(grad_out, packed_t, rb.nbr_bwd, rb.n_in, c_in,
-                                        row_order=order)
+            # SubM: forward table + flipped weights == backward table
+            d_feat = _conv_f32(grad_out, weight, krsc, True,
+                               rb.nbr_fwd if rb.is_subm else rb.nbr_bwd, rb.n_in,
+                               weight_flip=rb.is_subm, row_order=order)
         if ctx.needs_input_grad[1]:
             d_w = wgrad_done.result()
         return d_feat, d_w, None, None

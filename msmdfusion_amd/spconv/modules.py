@@ -1,10 +1,18 @@
-"""SparseModule / SparseSequential: container semantics of
-mmdet3d/ops/spconv/modules.py:44-137 (spconv-2.x keeps the same contract):
-sparse modules receive the SparseConvTensor, every other nn.Module is applied
-to .features only, and only when the tensor has at least one active voxel."""
-import sys
-from collections import OrderedDict
+"""SparseModule / SparseSequential / ToDense.
 
+Contract taken from the call sites (the legacy twin is
+mmdet3d/ops/spconv/modules.py:125-137): a SparseSequential runs its children in
+registration order; children that are SparseModules receive the
+SparseConvTensor itself, any other nn.Module sees only `.features` -- and is
+skipped altogether when the tensor has no active voxel.  Children built from
+positional arguments are named "0", "1", ... (make_sparse_convmodule's
+checkpoint keys `...0.weight`, `...1.running_mean` depend on it).
+
+The container does not interpret its children one call at a time: the child
+list is compiled once into a short program of steps (sparse call / fused
+BatchNorm1d(+ReLU) / plain feature op), recompiled only when a child is added
+or replaced, and forward() just runs the program.
+"""
 from torch import nn
 
 from .core import SparseConvTensor
@@ -23,68 +31,103 @@ def is_spconv_module(module):
     return isinstance(module, SparseModule)
 
 
+_SPARSE, _BN, _DENSE_OP = 0, 1, 2
+
+
 class SparseSequential(SparseModule):
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *children, **named_children):
         super().__init__()
-        if len(args) == 1 and isinstance(args[0], OrderedDict):
-            for key, module in args[0].items():
-                self.add_module(key, module)
-        else:
-            for idx, module in enumerate(args):
-                self.add_module(str(idx), module)
-        for name, module in kwargs.items():
-            if sys.version_info < (3, 6):
-                raise ValueError("kwargs only supported in py36+")
-            if name in self._modules:
-                raise ValueError("name exists.")
-            self.add_module(name, module)
-        self._sparity_dict = {}
+        self._program = None
+        self._density = {}
+        if len(children) == 1 and isinstance(children[0], dict):
+            named_children = dict(children[0], **named_children)
+            children = ()
+        for position, child in enumerate(children):
+            self.add_module(str(position), child)
+        for key, child in named_children.items():
+            if key in self._modules:
+                raise ValueError(f"child name {key!r} is already taken")
+            self.add_module(key, child)
 
-    def __getitem__(self, idx):
-        if not (-len(self) <= idx < len(self)):
-            raise IndexError("index {} is out of range".format(idx))
-        if idx < 0:
-            idx += len(self)
-        return list(self._modules.values())[idx]
-
-    def __len__(self):
-        return len(self._modules)
-
-    @property
-    def sparity_dict(self):
-        return self._sparity_dict
+    # -- container protocol ------------------------------------------------------
+    def add_module(self, name, module):
+        super().add_module(name, module)
+        self._program = None          # stale: recompile at the next forward
 
     def add(self, module, name=None):
         if name is None:
             name = str(len(self._modules))
             if name in self._modules:
-                raise KeyError("name exists")
+                raise KeyError(f"child name {name!r} is already taken")
         self.add_module(name, module)
 
-    def forward(self, input):
-        from .functional import bn_act
-        mods = list(self._modules.items())
-        i = 0
-        while i < len(mods):
-            k, module = mods[i]
-            i += 1
-            if is_spconv_module(module):
-                assert isinstance(input, SparseConvTensor)
-                self._sparity_dict[k] = input.sparity
-                input = module(input)
-            elif isinstance(input, SparseConvTensor):
-                if input.indices.shape[0] != 0:
-                    if isinstance(module, nn.BatchNorm1d):
-                        # [BN1d, ReLU] (make_sparse_convmodule) runs as one fused op
-                        relu = i < len(mods) and isinstance(mods[i][1], nn.ReLU)
-                        input = input.replace_feature(bn_act(input.features, module, relu=relu))
-                        i += int(relu)
-                    else:
-                        input = input.replace_feature(module(input.features))
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if isinstance(value, nn.Module):
+            self.__dict__["_program"] = None
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __iter__(self):
+        return iter(self._modules.values())
+
+    def __getitem__(self, position):
+        children = tuple(self._modules.values())
+        if isinstance(position, slice):
+            return SparseSequential(dict(tuple(self._modules.items())[position]))
+        if not -len(children) <= position < len(children):
+            raise IndexError(f"child index {position} out of range for {len(children)} children")
+        return children[position]
+
+    @property
+    def sparity_dict(self):
+        """name -> fraction of active sites seen by each sparse child at the last
+        forward (the reference spells it this way)."""
+        return self._density
+
+    # -- execution -----------------------------------------------------------------
+    def _compile(self):
+        """[(kind, name, module, fuse_relu)]; a BatchNorm1d directly followed by a
+        ReLU becomes one fused step (csrc/bn.hip: statistics + apply in two passes)."""
+        items = list(self._modules.items())
+        steps, skip = [], False
+        for pos, (name, child) in enumerate(items):
+            if skip:
+                skip = False
+                continue
+            if is_spconv_module(child):
+                steps.append((_SPARSE, name, child, False))
+            elif isinstance(child, nn.BatchNorm1d):
+                follows = items[pos + 1][1] if pos + 1 < len(items) else None
+                skip = isinstance(follows, nn.ReLU)
+                steps.append((_BN, name, child, skip))
             else:
-                input = module(input)
-        return input
+                steps.append((_DENSE_OP, name, child, False))
+        self.__dict__["_program"] = steps
+        return steps
+
+    def forward(self, x):
+        from .functional import bn_act
+        steps = self._program
+        if steps is None or sum(1 + s[3] for s in steps) != len(self._modules):
+            steps = self._compile()
+        for kind, name, child, fuse_relu in steps:
+            if kind == _SPARSE:
+                assert isinstance(x, SparseConvTensor), "sparse child needs a SparseConvTensor"
+                self._density[name] = x.sparity
+                x = child(x)
+            elif not isinstance(x, SparseConvTensor):
+                x = child(x)              # a ToDense() earlier in the chain: plain tensors now
+                if fuse_relu:
+                    x = nn.functional.relu(x)
+            elif x.indices.shape[0]:      # feature-only children are skipped on empty tensors
+                if kind == _BN:
+                    x = x.replace_feature(bn_act(x.features, child, relu=fuse_relu))
+                else:
+                    x = x.replace_feature(child(x.features))
+        return x
 
 
 class ToDense(SparseModule):

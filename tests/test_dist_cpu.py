@@ -66,6 +66,98 @@ def test_two_rank_gloo_data_parallel():
     assert ids0 == [24, 25, 26, 27] and ids1 == [28, 29, 30, 31]
 
 
+class _TinyPath(torch.nn.Module):
+    """Stands in for bench.Backbone: prepare() is index-only work (no weights),
+    forward() takes the prepared batch as a keyword argument."""
+
+    def __init__(self):
+        super().__init__()
+        self.body = torch.nn.Sequential(torch.nn.Linear(6, 12), torch.nn.ReLU(),
+                                        torch.nn.Linear(12, 4))
+
+    def prepare(self, x):
+        return x.argsort(1).float() * 0.1     # derived from the inputs alone
+
+    def forward(self, x, prepared=None):
+        extra = prepared if prepared is not None else self.prepare(x)
+        return self.body(x + extra)
+
+
+def _batches(rank, steps):
+    g = torch.Generator().manual_seed(7 + rank)
+    return [(torch.randn(5, 6, generator=g),) for _ in range(steps)]
+
+
+def _step_worker(rank, world, port, out, threaded):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from msmdfusion_amd import distributed as D
+    from msmdfusion_amd.prefetch import IndexPrefetcher
+    D.init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    model = _TinyPath()
+    net = D.wrap_data_parallel(model)
+    params = list(model.parameters())
+    opt = torch.optim.AdamW(params, lr=1e-2, weight_decay=0.01)
+    pf = IndexPrefetcher(model.prepare, "cpu", threaded=threaded)
+    step = D.TrainStep(net, params, opt, lambda y: y.pow(2).mean(), pf, max_norm=0.05)
+    data = _batches(rank, 4)
+    step.prime(data[0])
+    for i, b in enumerate(data):
+        step(b, next_batch=data[min(i + 1, len(data) - 1)])
+    flat = torch.cat([p.detach().flatten() for p in params])
+    out[rank] = (flat, D.rccl_ranks(), D.global_max(float(rank)))
+    D.shutdown()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("threaded", [False, True])
+def test_two_rank_train_step_structure(threaded):
+    """bench.py's step (prefetch ticket -> DDP forward kwarg -> clip -> AdamW) on two
+    gloo ranks == the same recipe on the rank-averaged gradients in one process."""
+    world, steps = 2, 4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_step_worker, args=(world, _free_port(), out, threaded), nprocs=world, join=True)
+    torch.manual_seed(0)
+    ref = _TinyPath()
+    params = list(ref.parameters())
+    opt = torch.optim.AdamW(params, lr=1e-2, weight_decay=0.01)
+    data = [_batches(r, steps) for r in range(world)]
+    for i in range(steps):
+        acc = None
+        for r in range(world):
+            ref.zero_grad()
+            ref(*data[r][i]).pow(2).mean().backward()
+            g = [p.grad.clone() for p in params]
+            acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+        for p, a in zip(params, acc):
+            p.grad = a / world
+        torch.nn.utils.clip_grad_norm_(params, 0.05)
+        opt.step()
+    want = torch.cat([p.detach().flatten() for p in params])
+    for r in range(world):
+        flat, ranks, tmax = out[r]
+        assert torch.allclose(flat, want, atol=1e-6), (flat - want).abs().max()
+        assert ranks == 0 and tmax == 1.0      # gloo here: no RCCL communicator
+    assert torch.equal(out[0][0], out[1][0])
+
+
+def test_bench_refuses_wrong_world(tmp_path):
+    """`bench.py --gpus N` must run N ranks or fail loudly: no GPU here, so asking for two
+    refuses before spawning, and a WORLD_SIZE that disagrees with --gpus is an error."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode != 0 and "asked for 2 GPUs" in r.stderr
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
 def test_single_process_helpers_are_noops():
     sys.path.insert(0, ROOT)
     from msmdfusion_amd import distributed as D
