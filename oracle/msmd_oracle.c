@@ -6,10 +6,12 @@
  * __graft_entry__.smoke()) can check the HIP library against them.  Nothing in
  * msmdfusion_amd/ may import, link or call it: the product path is HIP only.
  *
- * Pinning: oracle/ref_check.py compares every function here that has a
+ * Pinning: tests/test_oracle_cpu.py compares every function here that has a
  * compilable reference counterpart (voxelization, rulebooks, gather/scatter
- * conv) against the reference's own C++ built into oracle/_ref/, and against
- * the literal vectors of the reference's tests (tests/golden/).  sparse_add,
+ * conv forward and backward) against the reference's own C++ built into
+ * oracle/_ref/ (live in the build container; through the committed outputs
+ * tests/golden/reference_vectors.npz everywhere), and against the literal
+ * vectors of the reference's tests.  sparse_add,
  * dense() and the modality split have no runnable reference here (spconv 2.x
  * and numba are absent); they are pinned by hand-derived cases and by
  * cross-checks against dense torch ops -- see DESIGN.md "parity pins".

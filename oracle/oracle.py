@@ -202,7 +202,7 @@ def indice_conv_fwd(feat, filters, pairs, num, n_out, inverse=False, subm=False,
     return out
 
 
-def indice_conv_bwd(feat, filters, dout, pairs, num, inverse=False, subm=False):
+def indice_conv_bwd(feat, filters, dout, pairs, num, inverse=False, subm=False, use_ref=False):
     """-> (din [n_in,Cin], dfilters [K,Cin,Cout])"""
     f = _c(feat, np.float32)
     w = _c(filters, np.float32)
@@ -212,6 +212,12 @@ def indice_conv_bwd(feat, filters, dout, pairs, num, inverse=False, subm=False):
     kvol, cin, cout = w.shape
     din = np.zeros_like(f)
     dw = np.zeros_like(w)
+    if use_ref:
+        assert not inverse
+        ref_lib().ref_indice_conv_bwd(_f(f), f.shape[0], cin, _f(w), kvol, cout, _f(g),
+                                      g.shape[0], _i(pr), _i(nm), pr.shape[2], int(subm),
+                                      _f(din), _f(dw))
+        return din, dw
     _lib.orc_indice_conv_bwd(_f(f), f.shape[0], cin, _f(w), kvol, cout, _f(g), _i(pr), _i(nm),
                              pr.shape[2], g.shape[0], int(inverse), int(subm), _f(din), _f(dw))
     return din, dw

@@ -6,9 +6,10 @@
 //   mmdet3d/ops/voxel/src/voxelization_cpu.cpp        voxelization::hard_voxelize_cpu
 //   mmdet3d/ops/spconv/include/spconv/geometry.h      getIndicePairsSubM / getIndicePairsConv
 //   mmdet3d/ops/spconv/src/reordering.cc              SparseGatherFunctor / SparseScatterAddFunctor (CPU)
-// The per-offset loop around gather -> torch::mm -> scatter-add is the only
-// thing re-stated here (spconv_ops.h:260-361 cannot be built: it drags in
-// ATen/cuda and the GPU functor specialisations); it is marked below.
+// The per-offset loops around gather -> torch::mm -> scatter-add are the only
+// thing re-stated here (spconv_ops.h:260-361 forward, :363-456 backward: the
+// header cannot be built, it drags in ATen/cuda and the GPU functor
+// specialisations); they are marked below.
 // tensorview.h needs <cuda_runtime_api.h>; the image ships one with triton
 // (python3.10/dist-packages/triton/backends/nvidia/include) and the Makefile
 // points -I there -- no stand-in header is written.
@@ -115,6 +116,56 @@ void ref_indice_conv_fwd(const float* feat, int n_in, int cin,
     scatter(tv::CPU(), view<float>(out, {n_out, cout}),
             view<const float>(obuf.data_ptr<float>(), {hot_max + 1, cout}),
             view<const int>(pairs + ((long)k * 2 + 1) * ld, {ld}), hot, true);
+  }
+}
+
+// RESTATED LOOP (indiceConvBackward, spconv_ops.h:363-456, _inverse = 0) around the
+// reference's CPU gather / scatter-add functors and torch::mm: per offset
+//   dW[k] = gather(features)^T . gather(outGrad),
+//   dIn  += scatter(gather(outGrad) . W[k]^T);
+// the SubM centre offset is taken as two dense mms (:398-402).
+void ref_indice_conv_bwd(const float* feat, int n_in, int cin,
+                         const float* filters, int kvol, int cout,
+                         const float* out_grad, int n_out,
+                         const int32_t* pairs, const int32_t* num, int ld,
+                         int subm, float* din, float* dw) {
+  auto f = torch::TensorOptions().dtype(torch::kFloat32);
+  auto features = torch::from_blob(const_cast<float*>(feat), {n_in, cin}, f);
+  auto w = torch::from_blob(const_cast<float*>(filters), {kvol, cin, cout}, f);
+  auto g = torch::from_blob(const_cast<float*>(out_grad), {n_out, cout}, f);
+  auto in_grad = torch::from_blob(din, {n_in, cin}, f);
+  auto w_grad = torch::from_blob(dw, {kvol, cin, cout}, f);
+  in_grad.zero_();
+  w_grad.zero_();
+  int centre = 0, hot_max = 0;
+  for (int k = 0; k < kvol; ++k)
+    if (num[k] > hot_max) { hot_max = num[k]; centre = k; }
+  auto ibuf = torch::zeros({hot_max + 1, cin}, f);
+  auto obuf = torch::zeros({hot_max + 1, cout}, f);
+  if (subm) {
+    auto sub = w_grad[centre];
+    torch::mm_out(sub, features.t(), g);
+    torch::mm_out(in_grad, g, w[centre].t());
+  }
+  spconv::functor::SparseGatherFunctor<tv::CPU, float, int> gather_in, gather_out;
+  spconv::functor::SparseScatterAddFunctor<tv::CPU, float, int> scatter;
+  for (int k = 0; k < kvol; ++k) {
+    int hot = num[k];
+    if (hot <= 0 || (subm && k == centre)) continue;
+    gather_in(tv::CPU(), view<float>(ibuf.data_ptr<float>(), {hot_max + 1, cin}),
+              view<const float>(feat, {n_in, cin}),
+              view<const int>(pairs + ((long)k * 2 + 0) * ld, {ld}), hot);
+    gather_out(tv::CPU(), view<float>(obuf.data_ptr<float>(), {hot_max + 1, cout}),
+               view<const float>(out_grad, {n_out, cout}),
+               view<const int>(pairs + ((long)k * 2 + 1) * ld, {ld}), hot);
+    auto sub = w_grad[k];
+    auto ob = torch::from_blob(obuf.data_ptr<float>(), {hot, cout}, f);
+    auto ib = torch::from_blob(ibuf.data_ptr<float>(), {hot, cin}, f);
+    torch::mm_out(sub, ib.t(), ob);
+    torch::mm_out(ib, ob, w[k].t());
+    scatter(tv::CPU(), view<float>(din, {n_in, cin}),
+            view<const float>(ibuf.data_ptr<float>(), {hot_max + 1, cin}),
+            view<const int>(pairs + ((long)k * 2 + 0) * ld, {ld}), hot, true);
   }
 }
 

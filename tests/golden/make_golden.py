@@ -50,6 +50,7 @@ def main():
         out[f"rb_{name}_oshape"] = np.array(osz)
     # --- Native conv forward (reference gather / torch::mm / scatter-add)
     rng = np.random.RandomState(3)
+    rng_g = np.random.RandomState(4)      # (its own stream: the forward vectors keep their values)
     for name, subm, ks, st, pd in GEOMS[:4]:
         cin, cout = (16, 32) if subm else (32, 16)
         f = rng.randn(idx.shape[0], cin).astype(np.float32)
@@ -59,6 +60,11 @@ def main():
         n_out = out[f"rb_{name}_out"].shape[0]
         out[f"conv_{name}_feat"], out[f"conv_{name}_w"] = f, w
         out[f"conv_{name}_out"] = O.indice_conv_fwd(f, w, pr, nm, n_out, subm=subm, use_ref=True)
+        # backward through the reference's gather / scatter-add functors
+        # (indiceConvBackward, spconv_ops.h:363-456)
+        g = rng_g.randn(n_out, cout).astype(np.float32)
+        din, dw = O.indice_conv_bwd(f, w, g, pr, nm, subm=subm, use_ref=True)
+        out[f"conv_{name}_gout"], out[f"conv_{name}_din"], out[f"conv_{name}_dw"] = g, din, dw
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

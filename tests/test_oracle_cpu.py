@@ -113,6 +113,17 @@ def test_conv_vs_reference_vectors(gold, name, subm):
     np.testing.assert_allclose(out, gold[f"conv_{name}_out"], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("name,subm", [(g[0], g[1]) for g in GEOMS[:4]])
+def test_conv_backward_vs_reference_vectors(gold, name, subm):
+    """The oracle's backward == indiceConvBackward's loop (spconv_ops.h:363-456) run on
+    the reference's own gather / scatter-add functors (oracle/ref_shim.cpp)."""
+    din, dw = O.indice_conv_bwd(gold[f"conv_{name}_feat"], gold[f"conv_{name}_w"],
+                                gold[f"conv_{name}_gout"], gold[f"rb_{name}_pairs"],
+                                gold[f"rb_{name}_num"], subm=subm)
+    np.testing.assert_allclose(din, gold[f"conv_{name}_din"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dw, gold[f"conv_{name}_dw"], rtol=1e-5, atol=2e-5)
+
+
 # ---------------------------------------------------------------- (3) live reference build
 needs_ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (no /root/reference)")
 
@@ -130,6 +141,22 @@ def test_live_reference_voxelize_and_rulebooks():
         a = O.get_indice_pairs(idx, 1, S.SPARSE_SHAPE, ks, st, pd, 1, subm)
         b = O.get_indice_pairs(idx, 1, S.SPARSE_SHAPE, ks, st, pd, 1, subm, use_ref=True)
         assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3]))
+
+
+@needs_ref
+def test_live_reference_conv_backward():
+    rng = np.random.RandomState(11)
+    idx = S.random_voxel_indices(1200, 2, [9, 40, 40], seed=5)
+    for subm, ks, st, pd, cin, cout in [(True, 3, 1, 1, 24, 40), (False, 3, 2, 1, 32, 16)]:
+        oi, pr, nm, _ = O.get_indice_pairs(idx, 2, [9, 40, 40], ks, st, pd, 1, subm)
+        f = rng.randn(idx.shape[0], cin).astype(np.float32)
+        w = (rng.randn(27, cin, cout) * 0.1).astype(np.float32)
+        g = rng.randn(oi.shape[0], cout).astype(np.float32)
+        a = O.indice_conv_bwd(f, w, g, pr, nm, subm=subm)
+        b = O.indice_conv_bwd(f, w, g, pr, nm, subm=subm, use_ref=True)
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-5, atol=1e-5)
+        # (dW sums ~1000 products per element in a different order: fp32 rounding)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-4, atol=1e-4)
 
 
 # ---------------------------------------------------------------- (4) independent pins
