@@ -26,12 +26,17 @@ def conv_planes():
     return int(os.environ.get("MSMD_CONV_PLANES", "3"))
 
 
+# The split kernel gathers through a 32-bit byte offset into the feature tensor
+# (buffer loads, csrc/spconv_split.hip): tensors of 4 GiB and more take the fp32 kernels.
+SPLIT_MAX_FEATURE_BYTES = 0xFFFFFF00
+
+
 def _use_split(c_in, c_out, kvol, n_in=0):
     # c_in % 8 == 0 with a partial last k-block (the fusion stack's 80-channel layers)
     # included: 80->80 104 vs 114 us, 80->96 102 vs 135 since the split tiles (before
     # them the fp32 kernel won there, 118 vs 160).
     # Its gathers use 32-bit byte offsets: features beyond 4 GiB go the fp32 way.
-    return (conv_planes() in (1, 2, 3) and n_in * c_in * 4 < 0xFFFFFF00
+    return (conv_planes() in (1, 2, 3) and n_in * c_in * 4 < SPLIT_MAX_FEATURE_BYTES
             and K.split_supported(c_in, c_out, kvol))
 
 

@@ -1,0 +1,36 @@
+# One gpurun call: GPU tests, the default bench line, rocprofv3 kernel stats of both
+# workloads.  Everything lands under gpurun_out/$TAG/.
+#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh r02a [tests|bench|prof|pmc ...]'
+TAG=${1:-cur}; shift
+WHAT=${@:-tests bench prof}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+for w in $WHAT; do
+  case $w in
+    tests)
+      timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > $OUT/gpu_tests.log
+      tail -3 $OUT/gpu_tests.log ;;
+    tests_all)   # no -x: every failure listed
+      timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -150 > $OUT/gpu_tests.log
+      tail -3 $OUT/gpu_tests.log ;;
+    bench)
+      timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+      tail -c 600 $OUT/bench_default.json; tail -3 $OUT/bench_default.err ;;
+    prof)
+      (cd /tmp && export TMPDIR=/tmp
+       for wl in lc transfusion_l; do
+         P=$OUT/prof_$wl; mkdir -p $P
+         timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o s -- \
+           python $R/bench.py --workload $wl --no-also --no-cpu-baseline --no-profile > $P/bench.log 2>&1
+         rm -f $P/*kernel_trace.csv $P/*/*kernel_trace.csv
+         f=$(find $P -name "*kernel_stats.csv" | head -1)
+         tail -1 $P/bench.log | cut -c1-160
+         [ -n "$f" ] && python $R/tools/prof_summary.py $f $([ $wl = lc ] && echo 42 || echo 36) 40 > $P/summary.txt
+       done) ;;
+    pmc)
+      bash tools/pmc_collect.sh lc $OUT/pmc_lc
+      bash tools/pmc_collect.sh transfusion_l $OUT/pmc_transfusion_l ;;
+  esac
+done
