@@ -155,8 +155,8 @@ class SparseConvolution(SparseModule):
             out_features = Fsp.sparse_conv(features, self.weight, datas, krsc=True)
         if self.bias is not None:
             out_features = out_features + self.bias
-        out_tensor = out_tensor.replace_feature(out_features)
         out_tensor.indices = datas.out_indices
+        out_tensor = out_tensor.replace_feature(out_features)
         out_tensor.indice_dict = indice_dict
         out_tensor.spatial_shape = out_spatial_shape
         return out_tensor

@@ -171,12 +171,10 @@ class SparseConvTensor:
         return new
 
     def shadow_copy(self):
-        new = SparseConvTensor(self._features, self.indices, self.spatial_shape, self.batch_size,
-                               self.grid, self.voxel_num, self.indice_dict, self.benchmark)
-        new.benchmark_record = self.benchmark_record
-        new._timer = self._timer
-        new.thrust_allocator = self.thrust_allocator
-        new._rb_cache = self._rb_cache
+        """A second handle on the same data (callers go on to re-point .indices /
+        .features one after the other, so no row-count check here)."""
+        new = SparseConvTensor.__new__(SparseConvTensor)
+        new.__dict__.update(self.__dict__)
         return new
 
     @property
@@ -227,6 +225,7 @@ class SparseConvTensor:
             if not conv.subm:
                 t = t.shadow_copy()
                 t.indices = rb.out_indices
+                t._features = t._features.new_empty((rb.out_indices.shape[0], 0))
                 t.spatial_shape = rb.out_spatial_shape
                 if strided_outputs is not None:
                     strided_outputs.append((rb.out_indices, list(rb.out_spatial_shape)))
