@@ -244,6 +244,38 @@ int msmd_spconv_wgrad_split(const float* in_feat, int c_in, const float* d_out, 
                             int krsc_out /* != 0: d_weight is [c_out,K,c_in] */,
                             void* workspace, size_t workspace_bytes, msmd_stream_t stream);
 
+/* bf16 PLANE tensors: x[n,c] fp32 -> planes[n+1][planes][c] bf16, row n all zeros
+ * ("no pair"); x == sum of its planes exactly for planes = 3 (the split of
+ * msmd_spconv_fwd_split, done once per tensor instead of once per gathered row).
+ * c % 8 == 0.  No reference counterpart (the reference's GEMMs run on cuBLAS /
+ * tensor-core TF32); consumers: msmd_spconv_wgrad_planes. */
+size_t msmd_planes_bytes(int n_rows, int channels, int planes);
+
+int msmd_split_planes_f32(const float* x /* [n_rows,channels] */, int n_rows, int channels,
+                          int planes, void* out /* msmd_planes_bytes */, msmd_stream_t stream);
+
+/* wgrad reading plane tensors: dW[k] = sum_p in[i_p]^T (x) dout[o_p] with both operands
+ * gathered by LDS-DMA as bf16 rows and fed to the MFMA through transposing LDS reads
+ * (no per-row conversion work).  Same result as msmd_spconv_wgrad_split to the last
+ * bits of the fp32 accumulation order; c_in, c_out >= 64 and multiples of 8.
+ * replaces: sparse_conv_ext.indice_conv_backward_fp32's filter-gradient half
+ *           (spconv_ops.h:363-456 :438).
+ * indice_pairs must be sorted by output row within each offset (msmd_rulebook_pairs'
+ * order): a workgroup takes the pairs of one 2048-row range of OUTPUT rows, so that the
+ * 27 offsets of a range share their rows in one XCD's L2. */
+int msmd_spconv_wgrad_planes_supported(int c_in, int c_out);
+
+size_t msmd_spconv_wgrad_planes_workspace_bytes(int kernel_volume, int n_out, int c_in,
+                                                int c_out);
+
+int msmd_spconv_wgrad_planes(const void* in_planes /* [n_in+1,planes,c_in] bf16 */, int n_in,
+                             int c_in, const void* dout_planes /* [n_out+1,planes,c_out] */,
+                             int n_out, int c_out, const int32_t* indice_pairs /* [K,2,ld] */,
+                             const int32_t* indice_num /* [K] device */, int ld,
+                             int kernel_volume, int planes, float* d_weight,
+                             int krsc_out /* != 0: d_weight is [c_out,K,c_in] */,
+                             void* workspace, size_t workspace_bytes, msmd_stream_t stream);
+
 /* out[k][p] = nbr[k][order[p]] for p < n: the neighbour table in tile order. */
 int msmd_rulebook_permute_cols(const int32_t* nbr, int kernel_volume, int ld, int n,
                                const int32_t* order, int32_t* out /* [K,n] */,

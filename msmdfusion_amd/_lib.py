@@ -65,6 +65,12 @@ SIGNATURES = {
                                    _vp, _sz, _vp]),
     "msmd_spconv_wgrad_split_supported": (_i, [_i, _i]),
     "msmd_spconv_wgrad_split": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "msmd_planes_bytes": (_sz, [_i, _i, _i]),
+    "msmd_split_planes_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "msmd_spconv_wgrad_planes_supported": (_i, [_i, _i]),
+    "msmd_spconv_wgrad_planes_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "msmd_spconv_wgrad_planes": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz,
+                                      _vp]),
     "msmd_rulebook_permute_cols": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "msmd_bn_workspace_bytes": (_sz, [_i, _i]),
     "msmd_bn_act_fwd_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1,0 +1,547 @@
+// spconv_planes.hip -- bf16 PLANE tensors and the weight-gradient kernel that reads them.
+//
+// Why planes in HBM.  The split arithmetic (spconv_split.hip) writes every fp32 value
+// as the exact sum of three bf16 values.  The forward kernel does that split in
+// registers, amortised over all of c_out.  The weight gradient cannot: its contraction
+// runs over PAIRS, every gathered row is re-split for each of the ~14 offsets it takes
+// part in and for each channel slab -- 864 VALU operations beside 96 MFMAs per 32-pair
+// step (r01: MFMA pipe 28 % busy, VALU-bound).  Here a tensor is split ONCE
+// (msmd_split_planes_f32: HBM-bound, 4 B read + 6 B written per element) into
+//     planes[row][plane][channel]  bf16,  rows 0 .. n, row n = zeros ("no pair")
+// and the weight-gradient kernel gathers bf16 rows straight into LDS by LDS-DMA and
+// feeds the matrix cores from there through the transposing LDS read: no VALU work on
+// the operands at all.
+//
+// dW[k][ci][co] = sum_p in[i_p][ci] * dout[o_p][co]: the pair index p is the MFMA's
+// contraction (32 pairs per v_mfma_f32_16x16x32_bf16), but memory is pair-major /
+// channel-contiguous -- both operands need a transpose.  ds_read_b64_tr_b16 does it:
+// each 16-lane group reads a [4 pairs][16 channels] block, lane i supplying the 8-byte
+// address of (row i>>2, channel quad i&3) and receiving channel i of the 4 rows
+// (row stride free; checked on the device by tools/scratch/tr_probe.hip).
+//
+// Work decomposition: workgroup = (chunk of kRowsPerChunk consecutive OUTPUT ROWS, offset
+// k, slab of 128 c_in x 64 c_out channels), XCD-aware block order as the other wgrad
+// kernels (common.hpp): block b runs on XCD b % 8, every XCD gets whole chunks and walks
+// their (k, slab) workgroups consecutively.  The chunk is a range of output rows, not of
+// pair positions (the pair lists are sorted by output row, so it is still one contiguous
+// sub-range per offset: pair_ranges_kernel): all 27 offsets of a chunk then gather the
+// SAME dout rows and the same few neighbourhoods of input rows, which stay in that XCD's
+// 4 MiB L2 -- with chunks of pair positions (r01) chunk c of a corner offset and of the
+// centre offset cover different rows and every gather went to HBM (L2 hit rate 22 %).  Its 4
+// waves own disjoint output tiles (2 x 2 arrangement, up to 4 x 2 tiles of 16 x 16 each,
+// partial slabs split evenly) -- no cross-wave reduction.  A STAGE = 32 pairs = one MFMA
+// contraction step; its operands (36 KiB at 3 planes) are gathered by LDS-DMA into one
+// of two buffers while the previous stage is multiplied: one barrier per stage.
+// Partials per (k, chunk) + the fixed-order reduction of spconv.hip: deterministic.
+//
+// LDS image of one DMA op (1 KiB = 8 pairs x 64 channels of one plane):
+//   [tile a = 16 channels][slot][32 B],  slot = (pair + 4 * (group & 1)) & 7
+// so that the two 16-lane groups a transposing read services together (pairs 8g..8g+3
+// of groups g, g+1) touch all 64 banks exactly once.
+#include "common.hpp"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace msmd {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+// products kept for NP planes, smallest terms first (as spconv_split.hip)
+template <int NP>
+struct Prod;
+template <>
+struct Prod<1> {
+  static constexpr int n = 1;
+  static constexpr int a[1] = {0};
+  static constexpr int b[1] = {0};
+};
+template <>
+struct Prod<2> {
+  static constexpr int n = 3;
+  static constexpr int a[3] = {1, 0, 0};
+  static constexpr int b[3] = {0, 1, 0};
+};
+template <>
+struct Prod<3> {
+  static constexpr int n = 6;
+  static constexpr int a[6] = {2, 0, 1, 1, 0, 0};
+  static constexpr int b[6] = {0, 2, 1, 0, 1, 0};
+};
+
+// ---------------------------------------------------------------- fp32 -> planes --
+// planes[(row * NP + p) * c + ch] = plane p of x[row][ch]; row n is the zero row.
+// One thread = 8 channels (2 x 16-byte loads, NP x 16-byte stores).
+template <int NP>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int n,
+                                                           int c, u32x4* __restrict__ planes) {
+  const int c8 = c >> 3;
+  const long total = (long)(n + 1) * c8;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int row = (int)(e / c8), q = (int)(e - (long)row * c8);
+    u32x4 out[NP];
+    if (row < n) {
+      const f32x4* src = (const f32x4*)(x + (size_t)row * c + 8 * q);
+      const f32x4 lo = src[0], hi = src[1];
+      float r[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f32x2 v = {r[2 * t], r[2 * t + 1]};
+          const bf16x2 h = __builtin_convertvector(v, bf16x2);   // round to nearest even
+          out[p][t] = __builtin_bit_cast(unsigned int, h);
+          if (p + 1 < NP) {
+            const f32x2 back = __builtin_convertvector(h, f32x2);
+            r[2 * t] = v[0] - back[0];       // exact
+            r[2 * t + 1] = v[1] - back[1];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) out[p] = (u32x4){0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) planes[((size_t)row * NP + p) * c8 + q] = out[p];
+  }
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------ wgrad --
+constexpr int kSlab = 128;        // channels per workgroup slab, both sides (8 tiles of 16)
+constexpr int kWA = 4, kWB = 2;   // output tiles per wave at most (8 waves: 2 x 4 arrangement)
+constexpr int kBuffers = 3;       // stage ring: two stages of gathers in flight per workgroup
+
+template <int NP>
+__global__ __launch_bounds__(512) void spconv_wgrad_planes_kernel(
+    const unsigned short* __restrict__ pa, int cin, int n_in,
+    const unsigned short* __restrict__ pb, int cout, int n_out,
+    const int32_t* __restrict__ pairs, const int32_t* __restrict__ ranges /* [K][nchunks+1] */,
+    int ld, int nchunks, int kvol, float* __restrict__ partial /* [K][nchunks][cin][cout] */,
+    int dbg /* experiments only: 2 no gathers, 4 no MFMAs, 8 rows folded onto 1024 */) {
+  using P = Prod<NP>;
+  // one stage buffer: per side [half 2][plane NP][group 4] KiB; A then B
+  constexpr int kSide = 2 * NP * 4 * 1024, kBuf = 2 * kSide;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+  const int slabs_b = (cout + kSlab - 1) / kSlab;
+  int k, chunk, slab;
+  if (!wgrad_work(nchunks, kvol, ((cin + kSlab - 1) / kSlab) * slabs_b, chunk, k, slab)) return;
+  const int p_begin = ranges[(size_t)k * (nchunks + 1) + chunk];
+  const int cnt = ranges[(size_t)k * (nchunks + 1) + chunk + 1] - p_begin;
+  if (cnt <= 0) return;       // (the reduction skips empty (k, chunk) cells)
+  const int n_stages = (cnt + 31) >> 5;
+  const int a0 = (slab / slabs_b) * kSlab, b0 = (slab % slabs_b) * kSlab;
+  const int remA = cin - a0, remB = cout - b0;
+  const int nA = remA >= kSlab ? 8 : (remA + 15) >> 4;    // valid 16-channel tiles
+  const int nB = remB >= kSlab ? 8 : (remB + 15) >> 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7
+  const int wa = wave >> 2, wb = wave & 3;
+  // this wave's output tiles: the valid A tiles split in 2, the valid B tiles in 4
+  const int hA = (nA + 1) >> 1;
+  const int ta0 = wa ? hA : 0, ta1 = wa ? nA : hA;
+  const int qB = nB >> 2, rB = nB & 3;
+  const int tb0 = wb * qB + (wb < rB ? wb : rB), tb1 = tb0 + qB + (wb < rB ? 1 : 0);
+  const bool has_tiles = ta1 > ta0 && tb1 > tb0;
+
+  // ---- gather side: waves 0-3 stage the A rows, waves 4-7 the B rows, wave (w & 3)
+  // the pairs [8 (w & 3), +8) of every stage ----
+  // One DMA op = 8 pairs x 64 channels of one plane = 1 KiB, lane-linear in LDS.  Lanes
+  // 8p .. 8p+7 fetch the 128 contiguous bytes of pair p's row (one full line per 8 lanes),
+  // but in a permuted piece order: position j of the LDS row holds piece j ^ x(p, g),
+  // x = 2 * ((p >> 1) & 1) + 4 * (g & 1) -- the XOR keeps a tile's two 16-byte pieces
+  // adjacent and spreads the 8 rows a transposing read touches together (rows 4q..4q+3 of
+  // two 16-lane groups) over all 64 banks.
+  const int g_side = wave >> 2, g_grp = wave & 3;
+  const int g_row = lane >> 3, g_pos = lane & 7;
+  const int g_piece = g_pos ^ (2 * ((g_row >> 1) & 1) + 4 * (g_grp & 1));
+  // Pair indices: every lane loads, ONCE and before the pipeline starts, the row indices
+  // its row group needs for stages s = 8 j + (lane & 7), j = 0..7 (a chunk has at most
+  // 2048 pairs per offset = 64 stages); stage s then takes its index from lane (s & 7) of
+  // the group (v_readlane).  No index load is in flight once the DMA ring runs, so the
+  // vector memory queue holds nothing but this wave's DMA ops and its counted waits are
+  // exact (scalar loads inside the loop had their ~1 us latency exposed at every stage).
+  const int32_t* plist = pairs + ((size_t)k * 2 + g_side) * ld + p_begin;
+  const int c_side = g_side ? cout : cin, n_side = g_side ? n_out : n_in;
+  const unsigned short* p_side = g_side ? pb : pa;
+  const int ch0 = (g_side ? b0 : a0) + 8 * g_piece;     // + 64 for the second half
+  const size_t row_elems = (size_t)NP * c_side;
+  const int halves = (g_side ? nB : nA) > 4 ? 2 : 1;
+  int rows_blk[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int e = 32 * (8 * j + g_pos) + 8 * g_grp + g_row;
+    int v = e < cnt ? plist[e] : n_side;          // "no pair" -> the zero row
+    rows_blk[j] = (dbg & 8) ? (v & 1023) : v;
+  }
+  auto row_of = [&](int s) -> int {   // this lane's row of stage s (s < 64)
+    int cur = rows_blk[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) cur = (s >> 3) == j ? rows_blk[j] : cur;   // uniform select
+    // (gfx9 has no DPP8: 8 v_readlane + a select chain, VALU only)
+    int mine = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int v = __builtin_amdgcn_readlane(cur, 8 * r + (s & 7));
+      mine = g_row == r ? v : mine;
+    }
+    return mine;
+  };
+  auto issue_stage = [&](int s, int row) {
+    if (dbg & 2) return;
+    char* buf = smem + (s % kBuffers) * kBuf + g_side * kSide;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h >= halves) break;
+      const int ch = ch0 + 64 * h;
+      const bool ok = ch < c_side;     // channels past the side's width: the zero row
+      const unsigned short* src =
+          p_side + (ok ? (size_t)row * row_elems + ch : (size_t)n_side * row_elems);
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        __builtin_amdgcn_global_load_lds((glb_void*)(src + (ok ? (size_t)p * c_side : 0)),
+                                         (lds_void*)(buf + ((h * NP + p) * 4 + g_grp) * 1024),
+                                         16, 0, 0);
+    }
+  };
+  // DMA ops still allowed in flight when stage s must have landed = those of stage s+1
+  auto wait_stage = [&](bool next_in_flight) {
+    if (!next_in_flight || (dbg & 2))
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (halves == 2)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+  };
+
+  // ---- multiply side: lane (i, g) reads rows 4q .. 4q+3 (q = 0, 1) of group g's op ----
+  // byte offset, inside one side of a stage buffer, of this lane's 8 bytes of tile t, plane 0:
+  //   (t >> 2) * NP * 4096 + g * 1024 + row * 128 + ((32 (t & 3)) ^ (16 x(row, g))) + 8 (i & 3)
+  const int m_i = lane & 15, m_g = lane >> 4;
+  int offA[kWA][2], offB[kWB][2];   // loop-invariant, this wave's tiles
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = 4 * q + (m_i >> 2);
+    const int x16 = 16 * (2 * ((row >> 1) & 1) + 4 * (m_g & 1));
+    const int base = m_g * 1024 + row * 128 + 8 * (m_i & 3);
+#pragma unroll
+    for (int a = 0; a < kWA; ++a) {
+      const int t = ta0 + a;
+      offA[a][q] = (t >> 2) * (NP * 4096) + base + ((32 * (t & 3)) ^ x16);
+    }
+#pragma unroll
+    for (int b = 0; b < kWB; ++b) {
+      const int t = tb0 + b;
+      offB[b][q] = kSide + (t >> 2) * (NP * 4096) + base + ((32 * (t & 3)) ^ x16);
+    }
+  }
+
+  f32x4 acc[kWA][kWB];
+#pragma unroll
+  for (int a = 0; a < kWA; ++a)
+#pragma unroll
+    for (int b = 0; b < kWB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // The transposing reads are issued from inline asm: hipcc sees an LDS-DMA in flight
+  // (stages s+1, s+2) and would put `s_waitcnt vmcnt(0)` in front of the first LDS read it
+  // knows about -- every stage would wait for the gathers issued a moment earlier and
+  // nothing would overlap.  LDS returns in order: one lgkmcnt(0) after the last read, and
+  // empty asm statements tie the operand registers to it so no MFMA can move above.
+  auto read_half = [&](unsigned addr, int imm) -> u32x2 {   // imm: compile-time after unrolling
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(imm));
+    return v;
+  };
+  // one stage of this wave: NA x NB tiles (compile-time: straight-line code; a
+  // predicate per MFMA put every one of them into its own basic block)
+  auto multiply = [&](unsigned buf /* LDS byte address of the stage buffer */, auto na_c,
+                      auto nb_c) {
+    constexpr int NA = decltype(na_c)::value, NB = decltype(nb_c)::value;
+    u32x2 ra[NA][NP][2], rb[NB][NP][2];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const unsigned addr = (dbg & 16) ? buf + 8u * lane + 512u * q : buf + (unsigned)offA[a][q];
+        if constexpr (NP > 0) ra[a][0][q] = read_half(addr, 0);
+        if constexpr (NP > 1) ra[a][1][q] = read_half(addr, 4096);
+        if constexpr (NP > 2) ra[a][2][q] = read_half(addr, 8192);
+      }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const unsigned addr = (dbg & 16) ? buf + 8u * lane + 512u * q : buf + (unsigned)offB[b][q];
+        if constexpr (NP > 0) rb[b][0][q] = read_half(addr, 0);
+        if constexpr (NP > 1) rb[b][1][q] = read_half(addr, 4096);
+        if constexpr (NP > 2) rb[b][2][q] = read_half(addr, 8192);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(ra[a][p][0]), "+v"(ra[a][p][1]));
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(rb[b][p][0]), "+v"(rb[b][p][1]));
+    u32x4 opa[NA][NP], opb[NB][NP];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        opa[a][p] = (u32x4){ra[a][p][0][0], ra[a][p][0][1], ra[a][p][1][0], ra[a][p][1][1]};
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        opb[b][p] = (u32x4){rb[b][p][0][0], rb[b][p][0][1], rb[b][p][1][0], rb[b][p][1][1]};
+#pragma unroll
+    for (int t = 0; t < P::n; ++t)
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[a][b] = mfma_bf16(opa[a][P::a[t]], opb[b][P::b[t]], acc[a][b]);
+  };
+  const unsigned smem_base = (unsigned)(size_t)(lds_void*)smem;   // LDS byte address
+  const int my_na = ta1 - ta0, my_nb = tb1 - tb0;     // 0..4 x 0..2, wave-uniform
+  const int shape = has_tiles && !(dbg & 4) ? my_na * 4 + my_nb : 0;
+
+  // ring of kBuffers stage buffers: stages s+1 and s+2 are in flight while s is multiplied
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the index loads: none in flight below)
+  issue_stage(0, row_of(0));
+  if (n_stages > 1) issue_stage(1, row_of(1));
+  int row_next = n_stages > 2 ? row_of(2) : n_side;
+  for (int s = 0; s < n_stages; ++s) {
+    // this wave's pieces of stage s have landed; after the barrier everybody's have, and
+    // every wave is past its reads of stage s-1, whose buffer stage s+2 goes into
+    wait_stage(s + 1 < n_stages);
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < n_stages) {
+      issue_stage(s + 2, row_next);
+      if (s + 3 < n_stages) row_next = row_of(s + 3);
+    }
+    const unsigned buf = smem_base + (unsigned)((s % kBuffers) * kBuf);
+#define MSMD_SHAPE(A_, B_)                                                              \
+  case (A_) * 4 + (B_):                                                                  \
+    multiply(buf, std::integral_constant<int, A_>{}, std::integral_constant<int, B_>{}); \
+    break;
+    switch (shape) {
+      MSMD_SHAPE(4, 2) MSMD_SHAPE(4, 1) MSMD_SHAPE(3, 2) MSMD_SHAPE(3, 1) MSMD_SHAPE(2, 2)
+      MSMD_SHAPE(2, 1) MSMD_SHAPE(1, 2) MSMD_SHAPE(1, 1)
+      default: break;
+    }
+#undef MSMD_SHAPE
+  }
+  // ---- epilogue: D of tile (a, b): lane (n = i, g), reg r -> ci = 16a + 4g + r, co = 16b + n
+  float* dst = partial + ((size_t)k * nchunks + chunk) * cin * cout;
+#pragma unroll
+  for (int a = 0; a < kWA; ++a)
+#pragma unroll
+    for (int b = 0; b < kWB; ++b) {
+      if (ta0 + a >= ta1 || tb0 + b >= tb1) continue;
+      const int co = b0 + 16 * (tb0 + b) + m_i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = a0 + 16 * (ta0 + a) + 4 * m_g + r;
+        if (ci < cin && co < cout) dst[(size_t)ci * cout + co] = acc[a][b][r];
+      }
+    }
+}
+
+// ranges[k][c] = first pair of offset k whose output row is >= c * rows (c = 0 .. nchunks);
+// the lists are sorted by output row (msmd_rulebook_pairs).
+__global__ __launch_bounds__(256) void pair_ranges_kernel(const int32_t* __restrict__ pairs,
+                                                          const int32_t* __restrict__ num, int ld,
+                                                          int kvol, int rows, int nchunks,
+                                                          int32_t* __restrict__ ranges) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= kvol * (nchunks + 1)) return;
+  const int k = e / (nchunks + 1), c = e - k * (nchunks + 1);
+  const int32_t* po = pairs + ((size_t)k * 2 + 1) * ld;
+  const long target = (long)c * rows;
+  int lo = 0, hi = num[k];
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (po[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  ranges[e] = lo;
+}
+
+// dw = sum over the non-empty chunks of the per-(k, chunk) partials, in chunk order
+// (fixed: deterministic); 8 loads in flight per thread.
+__global__ __launch_bounds__(256) void reduce_ranges_kernel(const float* __restrict__ partial,
+                                                            const int32_t* __restrict__ ranges,
+                                                            int nchunks, int per_k, int cin,
+                                                            int cout, int kvol, int krsc,
+                                                            float* __restrict__ dw) {
+  const int k = blockIdx.y;
+  const int32_t* rg = ranges + (size_t)k * (nchunks + 1);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < per_k; e += gridDim.x * 256) {
+    const float* src = partial + (size_t)k * nchunks * per_k + e;
+    float s = 0.f;
+    for (int c0 = 0; c0 < nchunks; c0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + u;
+        v[u] = (c < nchunks && rg[c + 1] > rg[c]) ? src[(size_t)c * per_k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    if (krsc) {  // d_weight is [c_out][K][c_in] (the module's parameter layout)
+      const int ci = e / cout, co = e - ci * cout;
+      dw[((size_t)co * kvol + k) * cin + ci] = s;
+    } else {
+      dw[(size_t)k * per_k + e] = s;
+    }
+  }
+}
+
+// output rows per chunk (MSMD_WGRAD_ROWS overrides, experiments)
+inline int rows_per_chunk() {   // <= 2048: a workgroup keeps 64 stages of indices in registers
+  static const int v = [] {
+    const char* e = getenv("MSMD_WGRAD_ROWS");
+    const int r = e ? atoi(e) : 2048;
+    return r >= 64 && r <= 2048 ? r : 2048;
+  }();
+  return v;
+}
+#define kRowsPerChunk rows_per_chunk()
+
+template <int NP>
+int launch_wgrad_planes(const void* pa, int cin, int n_in, const void* pb, int cout, int n_out,
+                        const int32_t* pairs, const int32_t* ranges, int ld, int nchunks, int kvol,
+                        float* ws, hipStream_t st) {
+  constexpr size_t smem = (size_t)kBuffers * 2 * (2 * NP * 4 * 1024);
+  auto kern = spconv_wgrad_planes_kernel<NP>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  const int slabs = ceil_div(cin, kSlab) * ceil_div(cout, kSlab);
+  MSMD_LAUNCH(kern, dim3(wgrad_grid(nchunks, kvol, slabs)), dim3(512), smem, st,
+              (const unsigned short*)pa, cin, n_in, (const unsigned short*)pb, cout, n_out, pairs,
+              ranges, ld, nchunks, kvol, ws, []{ const char* e = getenv("MSMD_DBG"); return e ? atoi(e) : 0; }());
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace msmd
+
+using namespace msmd;
+
+MSMD_EXPORT size_t msmd_planes_bytes(int n_rows, int channels, int planes) {
+  return (size_t)(n_rows > 0 ? n_rows + 1 : 1) * (size_t)planes * (size_t)channels * 2;
+}
+
+MSMD_EXPORT int msmd_split_planes_f32(const float* x, int n_rows, int channels, int planes,
+                                      void* out, msmd_stream_t stream) {
+  if (n_rows < 0 || channels < 8 || (channels & 7) || planes < 1 || planes > 3 || !out ||
+      (n_rows > 0 && !x))
+    return MSMD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)(n_rows + 1) * (channels >> 3);
+  int nblk = (int)((total + 255) / 256);
+  if (nblk > 8192) nblk = 8192;
+  if (planes == 3)
+    MSMD_LAUNCH(split_planes_kernel<3>, dim3(nblk), dim3(256), 0, st, x, n_rows, channels,
+                (u32x4*)out);
+  else if (planes == 2)
+    MSMD_LAUNCH(split_planes_kernel<2>, dim3(nblk), dim3(256), 0, st, x, n_rows, channels,
+                (u32x4*)out);
+  else
+    MSMD_LAUNCH(split_planes_kernel<1>, dim3(nblk), dim3(256), 0, st, x, n_rows, channels,
+                (u32x4*)out);
+  return launch_status();
+}
+
+MSMD_EXPORT int msmd_spconv_wgrad_planes_supported(int c_in, int c_out) {
+  // 16-byte pieces of 8 bf16 channels; below 64 channels the fp32 kernel's narrow slabs win
+  return c_in >= 64 && c_out >= 64 && c_in % 8 == 0 && c_out % 8 == 0;
+}
+
+namespace {
+struct PlanesWs {
+  int32_t* ranges;
+  float* partial;
+};
+template <typename A>
+void carve_planes(A& a, PlanesWs* w, int kvol, int nchunks, int per_k) {
+  int32_t* r = a.template take<int32_t>((size_t)kvol * (nchunks + 1));
+  float* p = a.template take<float>((size_t)kvol * nchunks * per_k);
+  if (w) *w = PlanesWs{r, p};
+}
+}  // namespace
+
+MSMD_EXPORT size_t msmd_spconv_wgrad_planes_workspace_bytes(int kernel_volume, int n_out, int c_in,
+                                                            int c_out) {
+  if (kernel_volume < 1 || n_out < 0 || c_in < 1 || c_out < 1) return 0;
+  ArenaSize a;
+  carve_planes(a, (PlanesWs*)nullptr, kernel_volume, ceil_div(n_out > 0 ? n_out : 1, kRowsPerChunk),
+               c_in * c_out);
+  return a.off;
+}
+
+MSMD_EXPORT int msmd_spconv_wgrad_planes(const void* in_planes, int n_in, int c_in,
+                                         const void* dout_planes, int n_out, int c_out,
+                                         const int32_t* indice_pairs, const int32_t* indice_num,
+                                         int ld, int kernel_volume, int planes, float* d_weight,
+                                         int krsc_out, void* workspace, size_t workspace_bytes,
+                                         msmd_stream_t stream) {
+  if (!msmd_spconv_wgrad_planes_supported(c_in, c_out) || planes < 1 || planes > 3)
+    return MSMD_ERR_UNSUPPORTED;
+  if (kernel_volume < 1 || ld < 0 || n_in < 0 || n_out < 0 || !d_weight || !indice_num)
+    return MSMD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int per_k = c_in * c_out;
+  if (ld == 0 || n_out == 0) {
+    hipMemsetAsync(d_weight, 0, sizeof(float) * (size_t)kernel_volume * per_k, st);
+    return launch_status();
+  }
+  if (!in_planes || !dout_planes || !indice_pairs) return MSMD_ERR_INVALID_ARG;
+  const int nchunks = ceil_div(n_out, kRowsPerChunk);
+  Arena a(workspace, workspace_bytes);
+  PlanesWs w;
+  carve_planes(a, &w, kernel_volume, nchunks, per_k);
+  if (!a.ok()) return MSMD_ERR_WORKSPACE;
+  MSMD_LAUNCH(pair_ranges_kernel, dim3(ceil_div(kernel_volume * (nchunks + 1), 256)), dim3(256), 0,
+              st, indice_pairs, indice_num, ld, kernel_volume, kRowsPerChunk, nchunks, w.ranges);
+  int rc;
+  if (planes == 3)
+    rc = launch_wgrad_planes<3>(in_planes, c_in, n_in, dout_planes, c_out, n_out, indice_pairs,
+                                w.ranges, ld, nchunks, kernel_volume, w.partial, st);
+  else if (planes == 2)
+    rc = launch_wgrad_planes<2>(in_planes, c_in, n_in, dout_planes, c_out, n_out, indice_pairs,
+                                w.ranges, ld, nchunks, kernel_volume, w.partial, st);
+  else
+    rc = launch_wgrad_planes<1>(in_planes, c_in, n_in, dout_planes, c_out, n_out, indice_pairs,
+                                w.ranges, ld, nchunks, kernel_volume, w.partial, st);
+  if (rc != MSMD_OK) return rc;
+  int rb = ceil_div(per_k, 256);
+  if (rb > 64) rb = 64;
+  MSMD_LAUNCH(reduce_ranges_kernel, dim3(rb, kernel_volume), dim3(256), 0, st,
+              (const float*)w.partial, (const int32_t*)w.ranges, nchunks, per_k, c_in, c_out,
+              kernel_volume, krsc_out, d_weight);
+  return launch_status();
+}

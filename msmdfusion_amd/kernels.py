@@ -467,6 +467,45 @@ def conv_wgrad_split(feat, d_out, pairs, num, planes=3, krsc_shape=None):
     return dw
 
 
+# ---------------------------------------------- bf16 plane tensors (split once per tensor)
+def split_planes(x, planes=3):
+    """x [n,c] fp32 -> bf16 planes [n+1, planes, c] (row n = zeros); x == planes.sum(1)
+    exactly for planes = 3.  c % 8 == 0."""
+    _need_cuda(x)
+    xx = x.contiguous().float()
+    n, c = xx.shape
+    out = torch.empty((n + 1, int(planes), c), dtype=torch.bfloat16, device=xx.device)
+    check(lib.msmd_split_planes_f32(_p(xx), n, c, int(planes), _p(out), _stream()),
+          "msmd_split_planes_f32")
+    return out
+
+
+def wgrad_planes_supported(c_in, c_out):
+    return bool(lib.msmd_spconv_wgrad_planes_supported(int(c_in), int(c_out)))
+
+
+def conv_wgrad_planes(in_planes, dout_planes, pairs, num, krsc_shape=None):
+    """conv_wgrad from plane tensors (split_planes) of the features and of grad_out."""
+    _need_cuda(in_planes, dout_planes, pairs, num)
+    assert in_planes.dtype == dout_planes.dtype == torch.bfloat16
+    assert in_planes.is_contiguous() and dout_planes.is_contiguous()
+    assert in_planes.shape[1] == dout_planes.shape[1]
+    kvol, _, ld = pairs.shape
+    n_in, np_, c_in = in_planes.shape[0] - 1, in_planes.shape[1], in_planes.shape[2]
+    n_out, c_out = dout_planes.shape[0] - 1, dout_planes.shape[2]
+    dw = torch.empty((kvol, c_in, c_out) if krsc_shape is None else tuple(krsc_shape),
+                     dtype=torch.float32, device=in_planes.device)
+    nbytes = lib.msmd_spconv_wgrad_planes_workspace_bytes(kvol, n_out, c_in, c_out)
+    ws = _ws(nbytes, in_planes.device)
+    ev = _prof_begin()
+    check(lib.msmd_spconv_wgrad_planes(_p(in_planes), n_in, c_in, _p(dout_planes), n_out, c_out,
+                                       _p(pairs), _p(num), ld, kvol, np_, _p(dw),
+                                       int(krsc_shape is not None), _p(ws), nbytes, _stream()),
+          "msmd_spconv_wgrad_planes")
+    _prof_end("spconv_wgrad_planes", ev, num=num, c_in=c_in, c_out=c_out)
+    return dw
+
+
 # ------------------------------------------------------------------ BN (+residual)(+ReLU)
 def bn_act_forward(x, residual, gamma, beta, running_mean, running_var, training, momentum, eps,
                    relu):
