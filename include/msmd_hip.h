@@ -229,7 +229,18 @@ int msmd_spconv_fwd_split(const float* in_feat /* [n_in,c_in] */, int n_in, int 
                           int32_t* tile_counter /* [sync_ints] */, int sync_ints,
                           float* out_feat /* [n_out,c_out] */, int c_out, int planes,
                           void* workspace, size_t workspace_bytes,
+                          const int32_t* tile_prefix /* msmd_rulebook_tile_prefix of `nbr`,
+                                                        or NULL: dynamic tile scheduler */,
                           msmd_stream_t stream);
+
+/* Stream-K work table of a neighbour table (in the order the conv kernel tiles it):
+ * prefix[t] = number of (row tile, active offset) work items before tile t, prefix[n_tiles]
+ * = all of them (n_tiles = ceil(n_rows / rows_per_tile); an empty tile counts 1).  With it
+ * msmd_spconv_fwd_split gives every workgroup the same share of the launch (see
+ * csrc/spconv_split.hip); no reference counterpart. */
+int msmd_rulebook_tile_prefix(const int32_t* nbr /* [K,ld] */, int kernel_volume, int ld,
+                              int n_rows, int rows_per_tile,
+                              int32_t* prefix /* [n_tiles + 1] */, msmd_stream_t stream);
 
 /* wgrad with the same operand splitting (both operands are read as fp32 and
  * split in registers); c_in, c_out >= 64 and multiples of 4.  Workspace as

@@ -226,6 +226,33 @@ __device__ unsigned int g_ktrace_n;
 #define KP_MARK(i)
 #endif
 
+// Number of entries of the ascending array a[0..n) that are <= x, by 64-ary search:
+// the whole wave loads 64 probes at a time (2-3 dependent loads for n <= 8192 instead of
+// 13 for a binary search).  Same result in every lane.
+// (the array searched is a[idx] + c0 * idx: stream-K's per-tile overhead term)
+__device__ __forceinline__ int count_le(const int32_t* __restrict__ a, int n, int x, int c0,
+                                        int lane) {
+  int lo = 0, hi = n;   // the answer (first index with value > x) lies in [lo, hi]
+  while (hi - lo > 64) {
+    const int step = (hi - lo + 63) >> 6;
+    const int idx = lo + lane * step;
+    const int v = idx < hi ? a[idx] + c0 * idx : 0x7fffffff;
+    const int c = __builtin_popcountll(__ballot(v <= x));   // probes 0 .. c-1 are <= x
+    if (c == 0) {
+      hi = lo;          // a[lo] > x already
+    } else {
+      const int nlo = lo + (c - 1) * step + 1;
+      const int nhi = lo + c * step < hi ? lo + c * step : hi;
+      lo = nlo;
+      hi = nhi;
+    }
+  }
+  const int idx = lo + lane;
+  const int v = idx < hi ? a[idx] + c0 * idx : 0x7fffffff;
+  return lo + __builtin_popcountll(__ballot(v <= x));
+}
+constexpr int kSkMinRanks = 8;   // stream-K: smallest segment (ranks) worth a workgroup
+
 // ------------------------------------------------------- forward / dgrad --
 // One workgroup = 4 waves x 32 output rows (two 16-row MFMA groups per wave) x
 // all of c_out; persistent, drawing 128-row tiles from a global counter.
@@ -253,34 +280,45 @@ __device__ unsigned int g_ktrace_n;
 // belongs to output row order[p] (msmd_rulebook_permute_cols), so a tile's
 // slice is 512 contiguous bytes per offset.
 template <int NT, int UB, int NP>
-__global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
+__global__ __launch_bounds__(256, 2) void spconv_fwd_split_kernel(
     const float* __restrict__ in, int n_in, int cin, const u32x4* __restrict__ wp,
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
     const int32_t* __restrict__ order, int* __restrict__ tile_counter, float* __restrict__ out,
-    int ldo, int cout, int nt_total, int mt0, int n_split, int n_parts,
-    f32x4* __restrict__ scratch,
-    int* __restrict__ flags, int dbg) {
-  // Scheduling units.  A 128-row tile whose rows are connected through all 27 offsets is
-  // ~108 items of work -- about what a workgroup slot's fair share of the whole launch is
-  // when there are fewer than two tiles per slot, so the slots that draw a second tile
-  // set the launch time and half the chip idles (tools/ktrace.py).  The first `n_split`
-  // row tiles (the heaviest: rows are mask-sorted) are therefore P = `n_parts` units each,
-  // splitting the tile's active offsets into P groups by rank: groups 1..P-1 leave their
-  // accumulators in `scratch` (same lane layout, 16-byte stores) and raise flags[tile];
-  // group 0 adds them to its own, in group order, before the one store of the output
-  // rows.  Nothing is gathered or streamed twice, no atomics on `out`, no zero fill, and
-  // the sum order is fixed.  With H = n_split:
-  //   unit u <  P H     group P-1 - u / H of tile u % H   (so group 0 is drawn last)
-  //   u >= P H          tile u - (P-1) H, whole
-  // (Handing a tile's groups out back to back -- strictly descending unit cost -- was
-  // measured slower, 342 us against 296: the final group then finishes together with
-  // the partial ones and spins for them; with all partial groups first their sums are
-  // long there.)
-  // Tickets are handed out in this order: a group 0 is drawn after the tile's other
-  // groups, whose workgroups are resident and never wait -- the wait in its epilogue
-  // cannot deadlock.
+    int ldo, int cout, int nt_total, int mt0, f32x4* __restrict__ scratch,
+    int* __restrict__ flags, const int32_t* __restrict__ tile_start, int sk_c0, int dbg) {
+  // Scheduling.  Without `tile_start`: persistent workgroups draw whole 128-row tiles from
+  // a global counter (tiles arrive heaviest first: LPT list scheduling), every tile is one
+  // unit and the result does not depend on the tiling order at all.  A tile whose rows are
+  // connected through all 27 offsets is ~108 items of work -- about a workgroup slot's fair
+  // share of the whole launch when there are fewer than two tiles per slot: the slots that
+  // draw a second tile set the launch time and half the chip idles (tools/ktrace.py).
+  // r01 cut the heaviest tiles into two units; stream-K below replaces that.
   // `out` points at this pass's first output channel (tile mt0 of nt_total in the
   // packed weights), rows are ldo floats apart, `cout` channels are stored.
+  //
+  // STREAM-K scheduling (`tile_start` given).  The launch's
+  // work is the sequence of (row tile, active offset) RANKS, tile after tile in tiling
+  // order; tile_start[t] = rank at which tile t begins (prefix sum of max(|offset mask of
+  // the tile|, 1): msmd_rulebook_tile_prefix), tile_start[T] = W ranks in all.  Workgroup
+  // number g (its ticket) takes the contiguous range [g S, (g+1) S), S = ceil(W / grid)
+  // -- the same share for everybody, so nobody draws a second 108-item tile while half
+  // the chip idles (r01: 34 % of the slot-time idle on the 128-channel layers) and no
+  // heaviest-first order is needed.  A range cuts through tiles: the workgroup that holds
+  // a tile's LAST rank owns it and stores its rows; every other workgroup touching the
+  // tile leaves its accumulators in scratch[its ticket] and raises flags[its ticket].
+  // A workgroup walks its range from the HIGHEST tile down: the one tile it can only
+  // contribute to is its first piece of work (done long before the owner -- the next
+  // ticket -- reaches that tile at the END of its own range), and an owner only ever
+  // waits for LOWER tickets, which are resident and running by construction: no
+  // deadlock whatever else occupies the chip.  Contributions are added in ticket order:
+  // deterministic.  grid - 1 exchanges of one tile's accumulators per launch (32 MB at
+  // 512 x 128 channels) instead of one per split tile (157 MB).
+  // A tile visit also has a fixed cost (table staging, pipeline fill, the stores): each
+  // tile is charged `sk_c0` extra units in FRONT of its ranks, i.e. tile t occupies
+  // [tile_start[t] + c0 t, tile_start[t+1] + c0 (t+1)) of the sequence and its ranks start
+  // c0 into that.  Without it the segments of the light-mask tiles (few ranks each, many
+  // tiles) took 4x as long as those of the dense ones on the 32-channel layers.  A range
+  // that only touches a tile's overhead zone does not visit the tile.
   constexpr int R = 2, kRows = 4 * R * 16;
   constexpr int kUnitU = NP * NT * 64;  // 16-byte units of one unit's weights (in LDS)
   constexpr int kWU = UB * kUnitU;
@@ -299,11 +337,11 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int kbt = (cin + 31) >> 5;      // the last k-block may be partial (c_in % 8 == 0)
-  const int n_tiles = (n_out + kRows - 1) / kRows + (n_parts - 1) * n_split;   // units ("tiles")
-  auto row_tile = [&](int u) { return u < n_parts * n_split ? u % n_split : u - (n_parts - 1) * n_split; };
+  const int n_tiles = (n_out + kRows - 1) / kRows;
   // every workgroup draws 1 + (tiles it processed) tickets: the draw that returns
   // this value is the last one of the launch and puts the counter back to 0
-  const int last_ticket = n_tiles + (int)gridDim.x - 1;
+  // (stream-K: one ticket per workgroup, the last one is number grid - 1)
+  const int last_ticket = tile_start ? (int)gridDim.x - 1 : n_tiles + (int)gridDim.x - 1;
   int lr[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) lr[r] = (wave * R + r) * 16 + j;
@@ -317,7 +355,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     const int n_e = (kvol + (order ? 1 : 0)) * kRows;
     for (int e0 = wave * 64; e0 < n_e; e0 += 256) {
       const int e = e0 + lane, k = e >> 7;
-      int p = row_tile(T) * kRows + (e & (kRows - 1));
+      int p = T * kRows + (e & (kRows - 1));
       p = p < n_out ? p : n_out - 1;
       const int32_t* src = k < kvol ? nbr + (size_t)k * ld + p : order + p;
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + e0), 4, 0, 0);
@@ -336,14 +374,42 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
   }
   __syncthreads();   // nothing in flight yet: the fence costs nothing here
   int tile = __builtin_amdgcn_readfirstlane(ctl[2]);
-  if (tile >= n_tiles) return;
+  const bool sk = tile_start != nullptr;
+  const int n_row_tiles = (n_out + kRows - 1) / kRows;
+  int sk_seg = 0, sk_S = 1, sk_g0 = 0, sk_g1 = 0, sk_lo_tile = 0;
+  if (sk) {   // the ticket is this workgroup's segment of the rank sequence
+    sk_seg = tile;
+    const int W = tile_start[n_row_tiles] + sk_c0 * n_row_tiles;
+    sk_S = (W + (int)gridDim.x - 1) / (int)gridDim.x;
+    sk_S = sk_S < sk_c0 + kSkMinRanks ? sk_c0 + kSkMinRanks : sk_S;
+    sk_g0 = sk_seg * sk_S;
+    sk_g1 = sk_g0 + sk_S < W ? sk_g0 + sk_S : W;
+    if (sk_g0 >= W) return;
+    // tiles of the first and the last rank (64-ary searches, uniform across the block)
+    sk_lo_tile = count_le(tile_start, n_row_tiles, sk_g0, sk_c0, lane) - 1;
+    tile = count_le(tile_start, n_row_tiles, sk_g1 - 1, sk_c0, lane) - 1;
+    // a range that ends inside its highest tile's overhead zone does not visit that tile
+    // (the lowest tile's piece is never empty: the range starts before the tile's end)
+    if (sk_g1 <= tile_start[tile] + sk_c0 * (tile + 1)) --tile;
+    if (tile < sk_lo_tile) return;
+  } else if (tile >= n_tiles) {
+    return;
+  }
+  const int tile_lim = sk ? 0x40000000 : n_tiles;   // "no next tile" from here up
   stage_table(tile, 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   for (;;) {
     int nxt_v = 0;
-    if (tid == 0) nxt_v = atomicAdd(tile_counter, 1);  // consumed during item 1
+    if (tid == 0)   // consumed during item 1
+      nxt_v = sk ? (tile > sk_lo_tile ? tile - 1 : tile_lim) : atomicAdd(tile_counter, 1);
+    int sk_ts = 0, sk_tw = 0;
+    if (sk) {
+      const int t0s = tile_start[tile];
+      sk_tw = tile_start[tile + 1] - t0s;
+      sk_ts = t0s + sk_c0 * (tile + 1);        // where the tile's ranks start
+    }
     const int* tab = nbt + tb * tstride;
     {  // offsets any row of this tile is connected through
       unsigned m = 0;
@@ -356,14 +422,13 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the tile-id atomic too)
     __builtin_amdgcn_s_barrier();
     unsigned mask = __builtin_amdgcn_readfirstlane(ctl[tb]);
-    // group of this unit: -1 = whole tile, 0 = final, 1..P-1 = partial
-    const int grp = tile < n_parts * n_split ? n_parts - 1 - tile / n_split : -1;
-    if (grp >= 0) {   // active offsets of rank [grp pc / P, (grp+1) pc / P)
-      const int pc = __builtin_popcount(mask);
-      const int lo = grp * pc / n_parts, hi = (grp + 1) * pc / n_parts;
+    // stream-K: ranks [sk_lo, sk_hi) of the tile's sk_tw active offsets are this workgroup's
+    const int sk_lo = sk ? (sk_g0 > sk_ts ? sk_g0 - sk_ts : 0) : 0;
+    const int sk_hi = sk ? (sk_g1 - sk_ts < sk_tw ? sk_g1 - sk_ts : sk_tw) : 0;
+    if (sk) {
       unsigned sel = 0, rest = mask;
-      for (int c = 0; c < hi; ++c) {
-        if (c >= lo) sel |= rest & -rest;
+      for (int c = 0; c < sk_hi && rest; ++c) {
+        if (c >= sk_lo) sel |= rest & -rest;
         rest &= rest - 1;
       }
       mask = sel;
@@ -501,7 +566,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     u32x4 cv0[R][NP], cv1[R][NP];     // bf16 planes (units g, g+1)
     int vr0 = -1, vr1 = -1;
     bool staged = false;
-    int nxt = n_tiles;
+    int nxt = tile_lim;
     // ---- prologue: weights of item 0, rows of units 0 and 1, indices of unit 2,
     // planes of unit 0
     issue_w(0);
@@ -546,7 +611,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     if ((IT) == 1 && tid == 0) {                                                       \
       ctl[2] = nxt_v;                                                                  \
       ctl[tb ^ 1] = 0;                                                                 \
-      if (nxt_v == last_ticket) *tile_counter = 0;                                     \
+      if (!sk && nxt_v == last_ticket) *tile_counter = 0;                              \
     }                                                                                  \
     KP_MARK(6);                                                                        \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
@@ -555,7 +620,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     KP_MARK(1);                                                                        \
     if ((IT) == 1) {                                                                   \
       nxt = __builtin_amdgcn_readfirstlane(ctl[2]);                                    \
-      if (nxt < n_tiles) stage_table(nxt, tb ^ 1);                                     \
+      if (nxt < tile_lim) stage_table(nxt, tb ^ 1);                                    \
       staged = true;                                                                   \
     }                                                                                  \
     issue_w((IT) + 1);                                                                 \
@@ -599,14 +664,15 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
     // ring registers as epilogue temporaries: drain them first.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- epilogue: lane (j,q) holds out[row j][16n + 4q .. +3] ----
-    const int rt = row_tile(tile);
+    const int rt = tile;
+    constexpr int kSlotU = 4 * R * NT * 64;   // one tile's accumulators, f32x4 units
     // The exchange goes through agent-scope (sc1) accesses to the scratch lines and the
     // flag only: coherent across the XCDs' L2s on their own.  Fences would do it too,
     // but an agent-scope release writes back the whole L2 and an acquire invalidates it
     // -- the weights and the table live there (measured: 62 -> 192 us on a 32-channel layer).
-    if (grp > 0) {   // partial sums -> scratch, then signal (one count per wave)
-      unsigned long long* sp = (unsigned long long*)(
-          scratch + ((size_t)rt * (n_parts - 1) + grp - 1) * (4 * R * NT * 64) + lane);
+    if (sk && sk_hi < sk_tw) {
+      // a piece of a tile another workgroup owns: accumulators -> scratch[ticket], signal
+      unsigned long long* sp = (unsigned long long*)(scratch + (size_t)sk_seg * kSlotU + lane);
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -618,16 +684,16 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
         }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // written through before the signal
       if (lane == 0)
-        __hip_atomic_fetch_add(&flags[rt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&flags[sk_seg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      if (grp == 0) {   // wait for the four waves of every other group, add their sums
-        while (__hip_atomic_load(&flags[rt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-               4 * (n_parts - 1))
-          __builtin_amdgcn_s_sleep(4);
-        asm volatile("" ::: "memory");
-        for (int gq = 1; gq < n_parts; ++gq) {
-          unsigned long long* sp = (unsigned long long*)(
-              scratch + ((size_t)rt * (n_parts - 1) + gq - 1) * (4 * R * NT * 64) + lane);
+      // owner (or a whole tile): first add the pieces of the lower tickets that hold the
+      // tile's first ranks, in ticket order
+      if (sk && sk_lo > 0) {
+        for (int c = sk_ts / sk_S; c < sk_seg; ++c) {
+          while (__hip_atomic_load(&flags[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4)
+            __builtin_amdgcn_s_sleep(4);
+          asm volatile("" ::: "memory");
+          unsigned long long* sp = (unsigned long long*)(scratch + (size_t)c * kSlotU + lane);
 #pragma unroll
           for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -638,8 +704,15 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
               v[1] = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               acc[r][n] += __builtin_bit_cast(f32x4, v);
             }
+          if (lane == 0) {   // the last of the four reading waves re-arms the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (__hip_atomic_fetch_add(&flags[c], 1, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT) == 7)
+              __hip_atomic_store(&flags[c], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
+      // ---- lane (j,q) holds out[row j][16n + 4q .. +3] ----
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int p = rt * kRows + lr[r];
@@ -650,28 +723,22 @@ __global__ __launch_bounds__(256) void spconv_fwd_split_kernel(
         for (int n = 0; n < NT; ++n)
           if (16 * n + 4 * q < cout) *(f32x4*)(o + 16 * n) = acc[r][n];
       }
-      if (grp == 0 && lane == 0) {   // the last reader re-arms the flag for the next launch
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (its scratch reads have landed)
-        if (__hip_atomic_fetch_add(&flags[rt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-            4 * n_parts - 1)
-          __hip_atomic_store(&flags[rt], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
     }
     // ---- next tile ----
     if (!staged) {
       if (tid == 0) {
         ctl[2] = nxt_v;
         ctl[tb ^ 1] = 0;
-        if (nxt_v == last_ticket) *tile_counter = 0;
+        if (!sk && nxt_v == last_ticket) *tile_counter = 0;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       nxt = __builtin_amdgcn_readfirstlane(ctl[2]);
-      if (nxt < n_tiles) stage_table(nxt, tb ^ 1);
+      if (nxt < tile_lim) stage_table(nxt, tb ^ 1);
     }
     // drains the trailing (null-unit) gathers and weight DMA, lands the table
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (nxt >= n_tiles) break;
+    if (nxt >= tile_lim) break;
     __builtin_amdgcn_s_barrier();
     tile = nxt;
     tb ^= 1;
@@ -687,14 +754,23 @@ template <int NT, int UB, int NP>
 int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                      int ld, int n_out, int kvol, int flip, const int32_t* order,
                      int* tile_counter, float* out, int ldo, int cout, int nt_total, int mt0,
-                     int n_split, int n_parts, void* scratch, int* flags, hipStream_t st) {
+                     void* scratch, int* flags, const int32_t* tile_start, int sk_grid,
+                     hipStream_t st) {
+  // stream-K: a tile visit's fixed cost in units (offset x k-block) of this instantiation,
+  // charged per tile in ranks of ceil(cin / 32) units each (MSMD_SK_OVH overrides)
+  static const int ovh_env = env_int2("MSMD_SK_OVH", -1);
+  // (swept 0..48 on the bench layers: 8 is within 2 % of the best for every width)
+  const int ovh_units = ovh_env >= 0 ? ovh_env : 8;
+  const int kbt = (cin + 31) / 32;
+  const int sk_c0 = (ovh_units + kbt - 1) / kbt;
   constexpr int kRows = 128;
   const size_t smem = sizeof(u32x4) * 2 * UB * NP * NT * 64 +
                       sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 8);
-  const int n_tiles = ceil_div(n_out, kRows) + (n_parts - 1) * n_split;
+  const int n_tiles = ceil_div(n_out, kRows);
   int nblk = n_tiles;
   const int slots = 256 * split_slots_per_cu();
   if (nblk > slots) nblk = slots;
+  if (tile_start) nblk = sk_grid;     // stream-K: one segment per workgroup
   auto kern = spconv_fwd_split_kernel<NT, UB, NP>;
   static size_t attr_smem = 0;  // per instantiation
   if (smem > attr_smem) {
@@ -702,19 +778,24 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
     attr_smem = smem;
   }
   MSMD_LAUNCH(kern, dim3(nblk), dim3(256), smem, st, in, n_in, cin, (const u32x4*)wp, nbr, ld,
-              n_out, kvol, flip, order, tile_counter, out, ldo, cout, nt_total, mt0, n_split,
-              n_parts, (f32x4*)scratch, flags, env_int2("MSMD_DBG", 0));
+              n_out, kvol, flip, order, tile_counter, out, ldo, cout, nt_total, mt0,
+              (f32x4*)scratch, flags, tile_start, sk_c0, env_int2("MSMD_DBG", 0));
   return launch_status();
 }
 
-// exchange buffer of the split tiles: one pass's accumulators of `n_split` row tiles
-constexpr int kMaxParts = 4;
-size_t fwd_split_ws_bytes(int n_split, int cout, int n_parts = kMaxParts) {
+// stream-K: workgroups (= segments = exchange slots) of a launch over `row_tiles` tiles,
+// and the exchange buffer: one pass's accumulators of one tile per workgroup
+int sk_grid_size(int row_tiles, int kvol) {
+  const long ranks_max = (long)row_tiles * kvol;
+  const long slots = 256L * split_slots_per_cu();
+  return (int)(ranks_max < slots ? ranks_max : slots);
+}
+size_t fwd_sk_ws_bytes(int row_tiles, int kvol, int cout) {
   const int nt_total = (cout + 15) / 16;
   const int n_pass = (nt_total + 7) / 8;
   int per = (nt_total + n_pass - 1) / n_pass;
   per = per > 6 ? 8 : per > 4 ? 6 : per > 2 ? 4 : 2;      // the instantiation's NT
-  return (size_t)n_split * (n_parts - 1) * 128 * 16 * per * sizeof(float);
+  return (size_t)sk_grid_size(row_tiles, kvol) * 128 * 16 * per * sizeof(float);
 }
 
 // c_out is covered in passes of at most 128 channels (8 tiles of 16; a pass's
@@ -723,34 +804,21 @@ template <int NP>
 int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                        int ld, int n_out, int kvol, int flip, const int32_t* order,
                        int* tile_counter, int sync_ints, float* out, int cout, void* ws,
-                       size_t ws_bytes, hipStream_t st) {
+                       size_t ws_bytes, const int32_t* tile_prefix, hipStream_t st) {
   const int nt_total = (cout + 15) / 16;
   const int n_pass = (nt_total + 7) / 8;
   const int per = (nt_total + n_pass - 1) / n_pass;   // tiles per pass
-  // Split tiles (see the kernel): only where the row tiles alone are too few to balance
-  // the slots, and only if the caller provided the exchange buffers.  All passes of a
-  // launch sequence reuse them (stream order; the flags re-arm themselves).
-  // MSMD_SPLIT_TILES: percent of the row tiles to split (-1 = automatic).
-  static const int split_pct = env_int2("MSMD_SPLIT_TILES", -1);
   const int row_tiles = ceil_div(n_out, 128);
-  const int slots = 256 * split_slots_per_cu();
-  int n_split = 0;
-  if (split_pct < 0) {
-    // worth it when a dense tile is long (its MFMA work ~ kvol * k-blocks * NT) and the
-    // row tiles are few: 128->128 425 -> 330 us, 64->128 214 -> 208; the 32-/64-channel
-    // layers' tiles are short enough to balance on their own and only pay for the
-    // exchange (32->32 62 -> 78 us)
-    const int nt_pass = per > 6 ? 8 : per > 4 ? 6 : per > 2 ? 4 : 2;
-    // (with the rank-ordered tiling 64->128 is 188 us whole, 193 split: the bar is 486 now)
-    if (row_tiles < 3 * slots && kvol * ((cin + 31) / 32) * nt_pass >= 486) n_split = row_tiles;
-  } else {
-    n_split = (int)((long)row_tiles * (split_pct > 100 ? 100 : split_pct) / 100);
+  // Stream-K (see the kernel) whenever the caller passed the tile prefix and the exchange
+  // buffers cover one slot / one flag per workgroup; MSMD_STREAMK=0 falls back to the
+  // dynamic tile scheduler above (experiments).
+  static const int sk_on = env_int2("MSMD_STREAMK", 1);
+  const int sk_grid = sk_grid_size(row_tiles, kvol);
+  const int32_t* tile_start = nullptr;
+  if (sk_on && tile_prefix && ws && ws_bytes >= fwd_sk_ws_bytes(row_tiles, kvol, cout) &&
+      sync_ints >= 1 + sk_grid) {
+    tile_start = tile_prefix;
   }
-  static const int parts_env = env_int2("MSMD_SPLIT_PARTS", 0);   // 0 = automatic
-  int n_parts = parts_env >= 2 && parts_env <= kMaxParts ? parts_env : 2;
-  if (!ws || ws_bytes < fwd_split_ws_bytes(n_split, cout, n_parts) || sync_ints < 1 + n_split)
-    n_split = 0;
-  if (!n_split) n_parts = 1;
   int* flags = tile_counter + 1;
   for (int ps = 0; ps < n_pass; ++ps) {
     const int mt0 = ps * per;
@@ -760,8 +828,8 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
     int rc;
 #define MSMD_GO(NT_, UB_)                                                                      \
   rc = launch_fwd_split<NT_, UB_, NP>(in, n_in, cin, wp, nbr, ld, n_out, kvol, flip, order,   \
-                                      tile_counter, o, cout, width, nt_total, mt0, n_split, n_parts, ws, \
-                                      flags, st)
+                                      tile_counter, o, cout, width, nt_total, mt0, ws, flags,     \
+                                      tile_start, sk_grid, st)
     if (tiles > 6) { MSMD_GO(8, 1); }
     else if (tiles > 4) { MSMD_GO(6, 1); }
     else if (tiles > 2) { MSMD_GO(4, 2); }
@@ -781,6 +849,51 @@ __global__ __launch_bounds__(256) void permute_cols_kernel(const int32_t* __rest
   if (p >= n) return;
   const int row = order[p];
   for (int k = 0; k < kvol; ++k) out[(size_t)k * n + p] = nbr[(size_t)k * ld + row];
+}
+
+// Stream-K work table: weight[t] = max(|union of the offset masks of tile t's rows|, 1),
+// tile t = columns [t * rows, (t+1) * rows) of the table; prefix[t] = sum of the weights
+// before t, prefix[n_tiles] = total.  One block per tile, then a one-block scan.
+__global__ __launch_bounds__(128) void tile_weight_kernel(const int32_t* __restrict__ nbr,
+                                                          int kvol, int ld, int n, int rows,
+                                                          int32_t* __restrict__ weight) {
+  __shared__ unsigned m;
+  if (threadIdx.x == 0) m = 0;
+  __syncthreads();
+  unsigned v = 0;
+  for (int p = blockIdx.x * rows + threadIdx.x; p < (blockIdx.x + 1) * rows && p < n;
+       p += blockDim.x)
+    for (int k = 0; k < kvol; ++k)
+      if (nbr[(size_t)k * ld + p] >= 0) v |= 1u << k;
+  if (v) atomicOr(&m, v);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int pc = __builtin_popcount(m);
+    weight[blockIdx.x] = pc > 0 ? pc : 1;
+  }
+}
+__global__ __launch_bounds__(1024) void tile_prefix_kernel(int32_t* __restrict__ a, int n) {
+  // in place: a[0..n) weights -> a[0..n] exclusive prefix (a has n + 1 entries)
+  __shared__ int part[1024];
+  const int per = (n + 1023) / 1024, t = threadIdx.x;
+  const int b = t * per, e = b + per < n ? b + per : n;
+  int s = 0;
+  for (int i = b; i < e; ++i) s += a[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;    // exclusive prefix of this thread's slice
+  for (int i = b; i < e; ++i) {
+    const int w = a[i];
+    a[i] = run;
+    run += w;
+  }
+  if (t == 1023) a[n] = part[1023];
 }
 
 // ------------------------------------------------------------------ wgrad --
@@ -986,7 +1099,7 @@ MSMD_EXPORT int msmd_spconv_fwd_split_supported(int cin, int cout, int kvol) {
 }
 
 MSMD_EXPORT size_t msmd_spconv_fwd_split_workspace_bytes(int n_out, int cout) {
-  return fwd_split_ws_bytes(ceil_div(n_out > 0 ? n_out : 0, 128), cout);
+  return fwd_sk_ws_bytes(ceil_div(n_out > 0 ? n_out : 0, 128), kMaxK, cout);
 }
 
 MSMD_EXPORT int msmd_spconv_fwd_split(const float* planes, int n_in, int cin, const void* packed,
@@ -994,7 +1107,7 @@ MSMD_EXPORT int msmd_spconv_fwd_split(const float* planes, int n_in, int cin, co
                                       int weight_flip, const int32_t* row_order,
                                       int32_t* tile_counter, int sync_ints, float* out, int cout,
                                       int np, void* workspace, size_t workspace_bytes,
-                                      msmd_stream_t stream) {
+                                      const int32_t* tile_prefix, msmd_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!msmd_spconv_fwd_split_supported(cin, cout, kvol) || np < 1 || np > 3)
     return MSMD_ERR_UNSUPPORTED;
@@ -1003,11 +1116,29 @@ MSMD_EXPORT int msmd_spconv_fwd_split(const float* planes, int n_in, int cin, co
   // the gathers address the features through a 32-bit buffer offset
   if ((size_t)n_in * cin * sizeof(float) >= (size_t)kOobOffset) return MSMD_ERR_RANGE;
 #define MSMD_ARGS planes, n_in, cin, packed, nbr, ld, n_out, kvol, weight_flip, row_order, \
-                  tile_counter, sync_ints, out, cout, workspace, workspace_bytes, st
+                  tile_counter, sync_ints, out, cout, workspace, workspace_bytes, tile_prefix, st
   if (np == 3) return dispatch_fwd_split<3>(MSMD_ARGS);
   if (np == 2) return dispatch_fwd_split<2>(MSMD_ARGS);
   return dispatch_fwd_split<1>(MSMD_ARGS);
 #undef MSMD_ARGS
+}
+
+MSMD_EXPORT int msmd_rulebook_tile_prefix(const int32_t* nbr, int kvol, int ld, int n_rows,
+                                          int rows_per_tile, int32_t* prefix,
+                                          msmd_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (kvol < 1 || kvol > kMaxK || n_rows < 0 || ld < n_rows || rows_per_tile < 1 || !prefix ||
+      (n_rows > 0 && !nbr))
+    return MSMD_ERR_INVALID_ARG;
+  const int n_tiles = ceil_div(n_rows, rows_per_tile);
+  if (n_tiles == 0) {
+    hipMemsetAsync(prefix, 0, sizeof(int32_t), st);
+    return launch_status();
+  }
+  MSMD_LAUNCH(tile_weight_kernel, dim3(n_tiles), dim3(128), 0, st, nbr, kvol, ld, n_rows,
+              rows_per_tile, prefix);
+  MSMD_LAUNCH(tile_prefix_kernel, dim3(1), dim3(1024), 0, st, prefix, n_tiles);
+  return launch_status();
 }
 
 MSMD_EXPORT int msmd_rulebook_permute_cols(const int32_t* nbr, int kvol, int ld, int n,

@@ -397,14 +397,29 @@ def permute_cols(nbr, order):
     return out
 
 
+def tile_prefix(nbr):
+    """Stream-K work table of a neighbour table given in the order the conv kernel tiles
+    it (tile order when a row order is used): int32 [n_tiles + 1], see
+    msmd_rulebook_tile_prefix."""
+    _need_cuda(nbr)
+    kvol, n = nbr.shape
+    t = nbr.contiguous()
+    out = torch.empty(((n + TILE_ROWS - 1) // TILE_ROWS + 1,), dtype=torch.int32, device=t.device)
+    check(lib.msmd_rulebook_tile_prefix(_p(t), kvol, n, n, TILE_ROWS, _p(out), _stream()),
+          "msmd_rulebook_tile_prefix")
+    return out
+
+
 def conv_forward_split(feat, packed_weight, nbr, n_out, c_out, planes=3, weight_flip=False,
-                       row_order=None, split_tiles=True):
+                       row_order=None, split_tiles=True, tile_prefix=None):
     """conv_forward at bf16 MFMA rate with fp32-equivalent results: fp32 features
     are split into `planes` bf16 planes in registers, weights are pre-split
     (pack_weight_split).  With row_order, `nbr` must be in tile order (permute_cols).
     split_tiles=False withholds the exchange buffer: every 128-row tile is then one
     scheduling unit and the result does not depend on the tiling order at all (with
-    it, heavy tiles are summed as two halves: same value to the last bit or two)."""
+    it, tiles that a scheduling boundary cuts are summed in pieces: same value to the
+    last bit or two).  tile_prefix (tile_prefix(nbr), with the exchange buffer): stream-K
+    scheduling -- every workgroup gets the same share of the launch's work."""
     _need_cuda(feat, packed_weight, nbr)
     f = feat.contiguous().float()
     n_in, c_in = f.shape
@@ -418,7 +433,7 @@ def conv_forward_split(feat, packed_weight, nbr, n_out, c_out, planes=3, weight_
                                     int(n_out), kvol, int(bool(weight_flip)), _p(row_order),
                                     _p(counter), counter.numel(), _p(out), int(c_out),
                                     int(planes), _p(ws), 0 if ws is None else ws.numel(),
-                                    _stream()),
+                                    _p(tile_prefix) if split_tiles else None, _stream()),
           "msmd_spconv_fwd_split")
     _prof_end("spconv_fwd_split", ev, nbr=nbr, c_in=c_in, c_out=int(c_out), n_in=n_in,
               n_out=int(n_out))

@@ -35,6 +35,8 @@ class IndiceData:
         self._order_bwd = None
         self._tiled_fwd = None
         self._tiled_bwd = None
+        self._prefix_fwd = None
+        self._prefix_bwd = None
 
     @property
     def n_in(self):
@@ -61,12 +63,12 @@ class IndiceData:
             from .functional import _use_split, _wants_order
             kvol = self.nbr_fwd.shape[0]
             if _use_split(c_in, c_out, kvol, self.n_in):
-                self.tiling_fwd()
+                self.prefix_fwd()
             elif _wants_order(c_in, c_out):
                 self.order_fwd()
             if need_grad:       # dgrad: the same kernel over the mirrored problem
                 if _use_split(c_out, c_in, kvol, self.n_out):
-                    self.tiling_bwd()
+                    self.prefix_bwd()
                 elif _wants_order(c_out, c_in):
                     self.order_bwd()
         return self
@@ -100,6 +102,20 @@ class IndiceData:
             order, table = K.rulebook_tiling(self.nbr_fwd)
             self._order_fwd, self._tiled_fwd = (order,), (table,)
         return self._tiled_fwd[0], self._order_fwd[0]
+
+    def prefix_fwd(self):
+        """Stream-K work table of the forward tiling (K.tile_prefix): with it every
+        workgroup of the split kernel takes the same share of the launch."""
+        if self._prefix_fwd is None:
+            self._prefix_fwd = K.tile_prefix(self.tiling_fwd()[0])
+        return self._prefix_fwd
+
+    def prefix_bwd(self):
+        if self.is_subm:
+            return self.prefix_fwd()
+        if self._prefix_bwd is None:
+            self._prefix_bwd = K.tile_prefix(self.tiling_bwd()[0])
+        return self._prefix_bwd
 
     def tiling_bwd(self):
         if self.is_subm:      # forward table + flipped weights == backward table

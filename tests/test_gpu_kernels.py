@@ -267,6 +267,13 @@ def test_split_conv_subm(dev, cin, cout, planes):
         assert (out_s - whole).abs().max().item() <= 2e-6 * scale
         assert torch.equal(out_s, K.conv_forward_split(fd, ws, tab, n, cout, planes,
                                                        row_order=order))
+        # stream-K: tiles cut at segment boundaries are summed in pieces, in ticket order
+        pre = K.tile_prefix(tab)
+        out_k = K.conv_forward_split(fd, ws, tab, n, cout, planes, row_order=order,
+                                     tile_prefix=pre)
+        assert (out_k - whole).abs().max().item() <= 2e-6 * scale
+        assert torch.equal(out_k, K.conv_forward_split(fd, ws, tab, n, cout, planes,
+                                                       row_order=order, tile_prefix=pre))
     # KRSC weights pack to the same image
     w_krsc = wd.permute(2, 0, 1).contiguous().view(cout, 3, 3, 3, cin)
     assert torch.equal(ws, K.pack_weight_split(w_krsc, planes, krsc=True))
@@ -483,6 +490,51 @@ def test_split_conv_under_cu_contention(dev):
             assert torch.equal(o, ref)
         assert int(K._tile_counter(f.device).abs().sum().item()) == 0    # counter and flags
     torch.cuda.synchronize()
+    # the same under stream-K scheduling: an owner waits only for lower tickets, which are
+    # resident by construction -- late workgroups cannot deadlock it, and the counter and
+    # every exchange flag are back at 0 after each launch
+    pre = K.tile_prefix(nbr_t)
+    ref_k = K.conv_forward_split(f, ws, nbr_t, n, 64, 3, row_order=order, tile_prefix=pre)
+    assert (ref_k - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    torch.cuda.synchronize()
+    for rep in range(6):
+        with torch.cuda.stream(hog):
+            for _ in range(4):
+                a = torch.mm(a, a) * 1e-4
+        outs = [K.conv_forward_split(f, ws, nbr_t, n, 64, 3, row_order=order, tile_prefix=pre)
+                for _ in range(4)]
+        for o in outs:
+            assert torch.equal(o, ref_k)
+        assert int(K._tile_counter(f.device).abs().sum().item()) == 0
+    torch.cuda.synchronize()
+
+
+def test_tile_prefix(dev):
+    """msmd_rulebook_tile_prefix == prefix sums of max(|union of the rows' offset masks|, 1)
+    per 128-row tile (numpy), including a partial last tile and an all-empty tile."""
+    from msmdfusion_amd import kernels as K
+    shape = [11, 64, 64]
+    idx = S.random_voxel_indices(1500, 2, shape, seed=8)
+    nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
+    order = K.row_mask_order(nbr)
+    tab = K.permute_cols(nbr, order)
+    tab[:, 256:384] = -1                   # one tile without any neighbour
+    got = K.tile_prefix(tab).cpu().numpy()
+    tn = tab.cpu().numpy()
+    n = tn.shape[1]
+    w = []
+    for t0 in range(0, n, 128):
+        m = (tn[:, t0:t0 + 128] >= 0).any(1).sum()
+        w.append(max(int(m), 1))
+    assert np.array_equal(got, np.concatenate([[0], np.cumsum(w)]))
+    assert w[2] == 1
+    # such a tile's rows still come out as zeros under stream-K
+    f = torch.randn(n, 32, device=dev)
+    ws = K.pack_weight_split(torch.randn(27, 32, 32, device=dev) * 0.1, 3)
+    out = K.conv_forward_split(f, ws, tab, n, 32, 3, row_order=order, tile_prefix=K.tile_prefix(tab))
+    whole = K.conv_forward_split(f, ws, tab, n, 32, 3, row_order=order, split_tiles=False)
+    assert (out - whole).abs().max().item() <= 2e-6 * whole.abs().max().item()
+    assert not out[order[256:384].long()].abs().any()
 
 
 def test_split_conv_edges(dev):

@@ -363,7 +363,7 @@ def test_large_feature_fallback_branch(dev, monkeypatch):
                                    C.c_void_p(K.pack_weight_split(wd, 3).data_ptr()),
                                    C.c_void_p(nbr.data_ptr()), n, n, 27, 0, None,
                                    C.c_void_p(counter.data_ptr()), 8, C.c_void_p(o.data_ptr()), c,
-                                   3, None, 0, None)
+                                   3, None, 0, None, None)
     assert rc == -5     # MSMD_ERR_RANGE
 
 

@@ -12,6 +12,7 @@ from msmdfusion_amd import synthetic as S
 from msmdfusion_amd.voxelize import Voxelization
 dev = torch.device("cuda:0")
 want = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+sk = len(sys.argv) > 2 and sys.argv[2] == "sk"     # stream-K scheduling
 vox = Voxelization(S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, (120000, 160000))
 clouds = [torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in range(4)]
 coors = [F.pad(c, (1, 0), value=b) for b, (_, c, _) in enumerate(vox.forward_batch(clouds, fused_mean=True))]
@@ -25,11 +26,12 @@ for i, (pad, c) in enumerate([(1, 32), (1, 64), ([0, 1, 1], 128)]):
     nbr = K.rulebook_subm(idx, 4, shape, 3); n = idx.shape[0]
     f = torch.randn(n, c, device=dev); ws = K.pack_weight_split(torch.randn(27, c, c, device=dev) * 0.05, 3)
     o, nt = K.rulebook_tiling(nbr)
+    pre = K.tile_prefix(nt) if sk else None
     for _ in range(3):
-        K.conv_forward_split(f, ws, nt, n, c, 3, row_order=o)
+        K.conv_forward_split(f, ws, nt, n, c, 3, row_order=o, tile_prefix=pre)
     buf = np.zeros((16384, 8), dtype=np.uint64)
     h.msmd_debug_ktrace(buf.ctypes.data, 16384)
-    K.conv_forward_split(f, ws, nt, n, c, 3, row_order=o)
+    K.conv_forward_split(f, ws, nt, n, c, 3, row_order=o, tile_prefix=pre)
     cnt = h.msmd_debug_ktrace(buf.ctypes.data, 16384)
     t = buf[:cnt].astype(np.int64)
     hw, xcc, blk, tile, t0, t1, items, mask = t.T

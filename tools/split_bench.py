@@ -85,8 +85,16 @@ def main():
             ts = timed(lambda: K.conv_forward_split(f, ws, nbr_t, n, cout, args.planes,
                                                     row_order=order))
             line += " | split%d %.0f us %.1f TF" % (args.planes, ts, flops / ts / 1e6)
+            pre = K.tile_prefix(nbr_t)
+            tk = timed(lambda: K.conv_forward_split(f, ws, nbr_t, n, cout, args.planes,
+                                                    row_order=order, tile_prefix=pre))
+            line += " | stream-K %.0f us %.1f TF (frac %.3f)" % (tk, flops / tk / 1e6,
+                                                                flops / tk / 1e6 / 419.4)
             if args.check:
+                ok = K.conv_forward_split(f, ws, nbr_t, n, cout, args.planes, row_order=order,
+                                          tile_prefix=pre).double()
                 r = ref64(f, w, nbr)
+                line += " | sk err %.2e" % ((ok - r).abs().max().item() / r.abs().max().item())
                 o32 = K.conv_forward(f, wp, nbr, n, cout, row_order=order).double()
                 osp = K.conv_forward_split(f, ws, nbr_t, n, cout, args.planes,
                                            row_order=order).double()
