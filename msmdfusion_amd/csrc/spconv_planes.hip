@@ -123,10 +123,38 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// Phase timing of one wave (build with `make PROF=1`; never in the shipped library)
+#ifdef MSMD_KERNEL_PROF
+__device__ unsigned long long g_wprof[16];
+#define WP_BEGIN() unsigned long long wp_t = __builtin_amdgcn_s_memtime()
+#define WP_MARK(i)                                                                     \
+  {                                                                                    \
+    const unsigned long long wp_n = __builtin_amdgcn_s_memtime();                      \
+    if (lane == 0 && (wave == 1 || wave == 5) && blockIdx.x < 64)                         \
+      atomicAdd(&g_wprof[i + (wave == 5 ? 8 : 0)], wp_n - wp_t);                         \
+    wp_t = wp_n;                                                                       \
+  }
+#else
+#define WP_BEGIN()
+#define WP_MARK(i)
+#endif
+
 // ------------------------------------------------------------------ wgrad --
+// One workgroup per CU, 8 waves, slab of 128 c_in x 128 c_out channels, roles split:
+//   waves 4-7  PRODUCERS: wave 4+g gathers the pairs [8g, 8g+8) of every stage, both sides
+//              (up to 12 LDS-DMA ops of 1 KiB per stage), and does nothing else;
+//   waves 0-3  CONSUMERS: 2 x 2 arrangement, up to 4 x 4 output tiles each (96 MFMAs per
+//              stage), operands by transposing LDS reads; they issue no memory operations
+//              besides the epilogue.
+// Each SIMD hosts one wave of each role: the producers' DMA issue (~90 cycles per op) and
+// index handling run beside the consumers' MFMAs instead of inside their instruction
+// stream -- with all 8 waves doing both (r02's first versions) the phases ran in
+// lockstep behind the stage barrier: 4100 cycles per stage around 770 cycles of MFMAs.
+// Ring of 3 stage buffers (144 KiB): the gathers of stages s+1, s+2 are in flight while s
+// is multiplied; ONE barrier per stage.
 constexpr int kSlab = 128;        // channels per workgroup slab, both sides (8 tiles of 16)
-constexpr int kWA = 4, kWB = 2;   // output tiles per wave at most (8 waves: 2 x 4 arrangement)
-constexpr int kBuffers = 3;       // stage ring: two stages of gathers in flight per workgroup
+constexpr int kWT = 4;            // output tiles per consumer wave and side, at most
+constexpr int kBuffers = 3;
 
 template <int NP>
 __global__ __launch_bounds__(512) void spconv_wgrad_planes_kernel(
@@ -137,7 +165,7 @@ __global__ __launch_bounds__(512) void spconv_wgrad_planes_kernel(
     int dbg /* experiments only: 2 no gathers, 4 no MFMAs, 8 rows folded onto 1024 */) {
   using P = Prod<NP>;
   // one stage buffer: per side [half 2][plane NP][group 4] KiB; A then B
-  constexpr int kSide = 2 * NP * 4 * 1024, kBuf = 2 * kSide;
+  constexpr int kSide = 2 * NP * 4096, kBuf = 2 * kSide;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
   const int slabs_b = (cout + kSlab - 1) / kSlab;
@@ -153,133 +181,178 @@ __global__ __launch_bounds__(512) void spconv_wgrad_planes_kernel(
   const int nB = remB >= kSlab ? 8 : (remB + 15) >> 4;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7
-  const int wa = wave >> 2, wb = wave & 3;
-  // this wave's output tiles: the valid A tiles split in 2, the valid B tiles in 4
-  const int hA = (nA + 1) >> 1;
-  const int ta0 = wa ? hA : 0, ta1 = wa ? nA : hA;
-  const int qB = nB >> 2, rB = nB & 3;
-  const int tb0 = wb * qB + (wb < rB ? wb : rB), tb1 = tb0 + qB + (wb < rB ? 1 : 0);
-  const bool has_tiles = ta1 > ta0 && tb1 > tb0;
+  const unsigned smem_base = (unsigned)(size_t)(lds_void*)smem;   // LDS byte address
+  WP_BEGIN();
 
-  // ---- gather side: waves 0-3 stage the A rows, waves 4-7 the B rows, wave (w & 3)
-  // the pairs [8 (w & 3), +8) of every stage ----
-  // One DMA op = 8 pairs x 64 channels of one plane = 1 KiB, lane-linear in LDS.  Lanes
-  // 8p .. 8p+7 fetch the 128 contiguous bytes of pair p's row (one full line per 8 lanes),
-  // but in a permuted piece order: position j of the LDS row holds piece j ^ x(p, g),
-  // x = 2 * ((p >> 1) & 1) + 4 * (g & 1) -- the XOR keeps a tile's two 16-byte pieces
-  // adjacent and spreads the 8 rows a transposing read touches together (rows 4q..4q+3 of
-  // two 16-lane groups) over all 64 banks.
-  const int g_side = wave >> 2, g_grp = wave & 3;
-  const int g_row = lane >> 3, g_pos = lane & 7;
-  const int g_piece = g_pos ^ (2 * ((g_row >> 1) & 1) + 4 * (g_grp & 1));
-  // Pair indices: every lane loads, ONCE and before the pipeline starts, the row indices
-  // its row group needs for stages s = 8 j + (lane & 7), j = 0..7 (a chunk has at most
-  // 2048 pairs per offset = 64 stages); stage s then takes its index from lane (s & 7) of
-  // the group (v_readlane).  No index load is in flight once the DMA ring runs, so the
-  // vector memory queue holds nothing but this wave's DMA ops and its counted waits are
-  // exact (scalar loads inside the loop had their ~1 us latency exposed at every stage).
-  const int32_t* plist = pairs + ((size_t)k * 2 + g_side) * ld + p_begin;
-  const int c_side = g_side ? cout : cin, n_side = g_side ? n_out : n_in;
-  const unsigned short* p_side = g_side ? pb : pa;
-  const int ch0 = (g_side ? b0 : a0) + 8 * g_piece;     // + 64 for the second half
-  const size_t row_elems = (size_t)NP * c_side;
-  const int halves = (g_side ? nB : nA) > 4 ? 2 : 1;
-  int rows_blk[8];
+  if (wave >= 4) {
+    // =============================== producer ===============================
+    // One DMA op = 8 pairs x 64 channels of one plane = 1 KiB, lane-linear in LDS.  Lanes
+    // 8p .. 8p+7 fetch the 128 contiguous bytes of pair p's row (one full line per 8
+    // lanes), in a permuted piece order: position j of the LDS row holds piece
+    // j ^ x(p, g), x = 2 * ((p >> 1) & 1) + 4 * (g & 1) -- the XOR keeps a tile's two
+    // 16-byte pieces adjacent and spreads the 8 rows a transposing read touches together
+    // (rows 4q..4q+3 of two 16-lane groups) over all 64 banks.
+    const int g_grp = wave & 3;
+    const int g_row = lane >> 3, g_pos = lane & 7;
+    const int g_piece = g_pos ^ (2 * ((g_row >> 1) & 1) + 4 * (g_grp & 1));
+    const int halvesA = nA > 4 ? 2 : 1, halvesB = nB > 4 ? 2 : 1;
+    const int32_t* pin = pairs + ((size_t)k * 2 + 0) * ld + p_begin;
+    const int32_t* pout = pairs + ((size_t)k * 2 + 1) * ld + p_begin;
+    const size_t rowA = (size_t)NP * cin, rowB = (size_t)NP * cout;
+    // The 8 row indices a wave needs per side and stage are read on the SCALAR unit (wave-
+    // uniform addresses, lgkmcnt) a stage ahead of their use, so the vector memory queue
+    // holds nothing but DMA ops and the counted waits below are exact.
+    // (the loads are issued at the top of an iteration and consumed at its end: ~1 us of
+    // scalar-cache miss latency otherwise sat in every stage)
+    struct Rows8 { int v[8]; };
+    auto load_rows = [&](const int32_t* list, int s) -> Rows8 {     // 8 uniform values
+      Rows8 r;
+      const int e0 = 32 * s + 8 * g_grp;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int e = 32 * (8 * j + g_pos) + 8 * g_grp + g_row;
-    int v = e < cnt ? plist[e] : n_side;          // "no pair" -> the zero row
-    rows_blk[j] = (dbg & 8) ? (v & 1023) : v;
+      for (int i = 0; i < 8; ++i) r.v[i] = list[e0 + i < cnt ? e0 + i : cnt - 1];   // s_load
+      return r;
+    };
+    auto pick_row = [&](const Rows8& r, int s, int none) -> int {   // this lane's row
+      const int e0 = 32 * s + 8 * g_grp;
+      int mine = none;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mine = (g_row == i && e0 + i < cnt) ? r.v[i] : mine;
+      return (dbg & 8) ? (mine & 1023) : mine;
+    };
+    auto rows_of = [&](const int32_t* list, int s, int none) -> int {
+      return pick_row(load_rows(list, s), s, none);
+    };
+    auto issue = [&](int s, int ra, int rb) {
+      if (dbg & 2) return;
+      char* buf = smem + (s % kBuffers) * kBuf;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h >= halvesA) break;
+        const int ch = a0 + 64 * h + 8 * g_piece;
+        const bool ok = ch < cin;     // channels past c_in: the zero row
+        const unsigned short* src = pa + (ok ? (size_t)ra * rowA + ch : (size_t)n_in * rowA);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          __builtin_amdgcn_global_load_lds((glb_void*)(src + (ok ? (size_t)p * cin : 0)),
+                                           (lds_void*)(buf + ((h * NP + p) * 4 + g_grp) * 1024),
+                                           16, 0, 0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h >= halvesB) break;
+        const int ch = b0 + 64 * h + 8 * g_piece;
+        const bool ok = ch < cout;
+        const unsigned short* src = pb + (ok ? (size_t)rb * rowB + ch : (size_t)n_out * rowB);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          __builtin_amdgcn_global_load_lds(
+              (glb_void*)(src + (ok ? (size_t)p * cout : 0)),
+              (lds_void*)(buf + kSide + ((h * NP + p) * 4 + g_grp) * 1024), 16, 0, 0);
+      }
+    };
+    const int ops = (halvesA + halvesB) * NP;     // DMA ops of this wave per stage
+    auto wait_all_but = [&](int stages_in_flight) {   // newest stages allowed to be in flight
+      const int n = (dbg & 2) ? 0 : stages_in_flight * ops;
+      switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2 * NP: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory"); break;
+        case 3 * NP: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory"); break;
+        case 4 * NP: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NP) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+    };
+    int ra = rows_of(pin, 0, n_in), rb = rows_of(pout, 0, n_out);
+    issue(0, ra, rb);
+    if (n_stages > 1) {
+      ra = rows_of(pin, 1, n_in);
+      rb = rows_of(pout, 1, n_out);
+      issue(1, ra, rb);
+    }
+    if (n_stages > 2) {
+      ra = rows_of(pin, 2, n_in);
+      rb = rows_of(pout, 2, n_out);
+    }
+    WP_MARK(0);
+    for (int s = 0; s < n_stages; ++s) {
+      Rows8 qa, qb;
+      const bool more = s + 3 < n_stages;
+      if (more) {                     // scalar loads for stage s+3: consumed at the end
+        qa = load_rows(pin, s + 3);
+        qb = load_rows(pout, s + 3);
+      }
+      // this wave's pieces of stage s have landed (stage s+1's may still be in flight)
+      wait_all_but(s + 1 < n_stages ? 1 : 0);
+      WP_MARK(1);
+      __builtin_amdgcn_s_barrier();   // stage s visible to the consumers; they are past s-1
+      WP_MARK(2);
+      if (s + 2 < n_stages) {
+        issue(s + 2, ra, rb);         // into the buffer stage s-1 was read from
+        WP_MARK(3);
+      }
+      if (more) {
+        ra = pick_row(qa, s + 3, n_in);
+        rb = pick_row(qb, s + 3, n_out);
+      }
+      WP_MARK(4);
+#ifdef MSMD_KERNEL_PROF
+      if (lane == 0 && wave == 5 && blockIdx.x < 64) atomicAdd(&g_wprof[7], 1ull);
+#endif
+    }
+    return;
   }
-  auto row_of = [&](int s) -> int {   // this lane's row of stage s (s < 64)
-    int cur = rows_blk[0];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) cur = (s >> 3) == j ? rows_blk[j] : cur;   // uniform select
-    // (gfx9 has no DPP8: 8 v_readlane + a select chain, VALU only)
-    int mine = 0;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int v = __builtin_amdgcn_readlane(cur, 8 * r + (s & 7));
-      mine = g_row == r ? v : mine;
-    }
-    return mine;
-  };
-  auto issue_stage = [&](int s, int row) {
-    if (dbg & 2) return;
-    char* buf = smem + (s % kBuffers) * kBuf + g_side * kSide;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (h >= halves) break;
-      const int ch = ch0 + 64 * h;
-      const bool ok = ch < c_side;     // channels past the side's width: the zero row
-      const unsigned short* src =
-          p_side + (ok ? (size_t)row * row_elems + ch : (size_t)n_side * row_elems);
-#pragma unroll
-      for (int p = 0; p < NP; ++p)
-        __builtin_amdgcn_global_load_lds((glb_void*)(src + (ok ? (size_t)p * c_side : 0)),
-                                         (lds_void*)(buf + ((h * NP + p) * 4 + g_grp) * 1024),
-                                         16, 0, 0);
-    }
-  };
-  // DMA ops still allowed in flight when stage s must have landed = those of stage s+1
-  auto wait_stage = [&](bool next_in_flight) {
-    if (!next_in_flight || (dbg & 2))
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (halves == 2)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-  };
 
-  // ---- multiply side: lane (i, g) reads rows 4q .. 4q+3 (q = 0, 1) of group g's op ----
-  // byte offset, inside one side of a stage buffer, of this lane's 8 bytes of tile t, plane 0:
+  // ================================= consumer =================================
+  const int wa = wave >> 1, wb = wave & 1;
+  const int hA = (nA + 1) >> 1, hB = (nB + 1) >> 1;
+  const int ta0 = wa ? hA : 0, ta1 = wa ? nA : hA;
+  const int tb0 = wb ? hB : 0, tb1 = wb ? nB : hB;
+  const bool has_tiles = ta1 > ta0 && tb1 > tb0;
+  // lane (i, g) reads rows 4q .. 4q+3 (q = 0, 1) of group g's op; byte offset, inside one
+  // side of a stage buffer, of this lane's 8 bytes of tile t, plane 0:
   //   (t >> 2) * NP * 4096 + g * 1024 + row * 128 + ((32 (t & 3)) ^ (16 x(row, g))) + 8 (i & 3)
   const int m_i = lane & 15, m_g = lane >> 4;
-  int offA[kWA][2], offB[kWB][2];   // loop-invariant, this wave's tiles
+  int offA[kWT][2], offB[kWT][2];   // loop-invariant, this wave's tiles
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int row = 4 * q + (m_i >> 2);
     const int x16 = 16 * (2 * ((row >> 1) & 1) + 4 * (m_g & 1));
     const int base = m_g * 1024 + row * 128 + 8 * (m_i & 3);
 #pragma unroll
-    for (int a = 0; a < kWA; ++a) {
+    for (int a = 0; a < kWT; ++a) {
       const int t = ta0 + a;
       offA[a][q] = (t >> 2) * (NP * 4096) + base + ((32 * (t & 3)) ^ x16);
     }
 #pragma unroll
-    for (int b = 0; b < kWB; ++b) {
+    for (int b = 0; b < kWT; ++b) {
       const int t = tb0 + b;
       offB[b][q] = kSide + (t >> 2) * (NP * 4096) + base + ((32 * (t & 3)) ^ x16);
     }
   }
-
-  f32x4 acc[kWA][kWB];
+  f32x4 acc[kWT][kWT];
 #pragma unroll
-  for (int a = 0; a < kWA; ++a)
+  for (int a = 0; a < kWT; ++a)
 #pragma unroll
-    for (int b = 0; b < kWB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < kWT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // The transposing reads are issued from inline asm: hipcc sees an LDS-DMA in flight
-  // (stages s+1, s+2) and would put `s_waitcnt vmcnt(0)` in front of the first LDS read it
-  // knows about -- every stage would wait for the gathers issued a moment earlier and
-  // nothing would overlap.  LDS returns in order: one lgkmcnt(0) after the last read, and
-  // empty asm statements tie the operand registers to it so no MFMA can move above.
+  // The transposing reads are issued from inline asm: hipcc sees LDS-DMA in the kernel and
+  // puts `s_waitcnt vmcnt(0)` in front of the first LDS read it knows about.  LDS returns
+  // in order: counted lgkmcnt waits (this wave has no scalar loads in flight), and empty asm
+  // statements tie the operand registers to the wait so no MFMA can move above it.
   auto read_half = [&](unsigned addr, int imm) -> u32x2 {   // imm: compile-time after unrolling
     u32x2 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(imm));
     return v;
   };
-  // one stage of this wave: NA x NB tiles (compile-time: straight-line code; a
-  // predicate per MFMA put every one of them into its own basic block)
-  auto multiply = [&](unsigned buf /* LDS byte address of the stage buffer */, auto na_c,
-                      auto nb_c) {
+  // one stage: NA x NB tiles.  The A operands and the first B tile are waited for first;
+  // the remaining B tiles land behind the MFMAs of the tiles before them.
+  auto multiply = [&](unsigned buf, auto na_c, auto nb_c) {
     constexpr int NA = decltype(na_c)::value, NB = decltype(nb_c)::value;
     u32x2 ra[NA][NP][2], rb[NB][NP][2];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const unsigned addr = (dbg & 16) ? buf + 8u * lane + 512u * q : buf + (unsigned)offA[a][q];
+        const unsigned addr = buf + (unsigned)offA[a][q];
         if constexpr (NP > 0) ra[a][0][q] = read_half(addr, 0);
         if constexpr (NP > 1) ra[a][1][q] = read_half(addr, 4096);
         if constexpr (NP > 2) ra[a][2][q] = read_half(addr, 8192);
@@ -288,75 +361,71 @@ __global__ __launch_bounds__(512) void spconv_wgrad_planes_kernel(
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const unsigned addr = (dbg & 16) ? buf + 8u * lane + 512u * q : buf + (unsigned)offB[b][q];
+        const unsigned addr = buf + (unsigned)offB[b][q];
         if constexpr (NP > 0) rb[b][0][q] = read_half(addr, 0);
         if constexpr (NP > 1) rb[b][1][q] = read_half(addr, 4096);
         if constexpr (NP > 2) rb[b][2][q] = read_half(addr, 8192);
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    u32x4 opa[NA][NP];
 #pragma unroll
-    for (int a = 0; a < NA; ++a)
+    for (int b = 0; b < NB; ++b) {
+      // reads still allowed in flight: those of the B tiles after b
+      constexpr int per_tile = 2 * NP;
+      switch ((NB - 1 - b) * per_tile) {
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+        case 1 * per_tile: asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(1 * per_tile) : "memory"); break;
+        case 2 * per_tile: asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * per_tile > 15 ? 15 : 2 * per_tile) : "memory"); break;
+        default: asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * per_tile > 15 ? 15 : 3 * per_tile) : "memory"); break;
+      }
+      if (b == 0) {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(ra[a][p][0]), "+v"(ra[a][p][1]));
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+          for (int p = 0; p < NP; ++p) {
+            asm volatile("" : "+v"(ra[a][p][0]), "+v"(ra[a][p][1]));
+            opa[a][p] = (u32x4){ra[a][p][0][0], ra[a][p][0][1], ra[a][p][1][0], ra[a][p][1][1]};
+          }
+      }
+      u32x4 opb[NP];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(rb[b][p][0]), "+v"(rb[b][p][1]));
-    u32x4 opa[NA][NP], opb[NB][NP];
+      for (int p = 0; p < NP; ++p) {
+        asm volatile("" : "+v"(rb[b][p][0]), "+v"(rb[b][p][1]));
+        opb[p] = (u32x4){rb[b][p][0][0], rb[b][p][0][1], rb[b][p][1][0], rb[b][p][1][1]};
+      }
 #pragma unroll
-    for (int a = 0; a < NA; ++a)
+      for (int t = 0; t < P::n; ++t)
 #pragma unroll
-      for (int p = 0; p < NP; ++p)
-        opa[a][p] = (u32x4){ra[a][p][0][0], ra[a][p][0][1], ra[a][p][1][0], ra[a][p][1][1]};
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int p = 0; p < NP; ++p)
-        opb[b][p] = (u32x4){rb[b][p][0][0], rb[b][p][0][1], rb[b][p][1][0], rb[b][p][1][1]};
-#pragma unroll
-    for (int t = 0; t < P::n; ++t)
-#pragma unroll
-      for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-          acc[a][b] = mfma_bf16(opa[a][P::a[t]], opb[b][P::b[t]], acc[a][b]);
-  };
-  const unsigned smem_base = (unsigned)(size_t)(lds_void*)smem;   // LDS byte address
-  const int my_na = ta1 - ta0, my_nb = tb1 - tb0;     // 0..4 x 0..2, wave-uniform
-  const int shape = has_tiles && !(dbg & 4) ? my_na * 4 + my_nb : 0;
-
-  // ring of kBuffers stage buffers: stages s+1 and s+2 are in flight while s is multiplied
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the index loads: none in flight below)
-  issue_stage(0, row_of(0));
-  if (n_stages > 1) issue_stage(1, row_of(1));
-  int row_next = n_stages > 2 ? row_of(2) : n_side;
-  for (int s = 0; s < n_stages; ++s) {
-    // this wave's pieces of stage s have landed; after the barrier everybody's have, and
-    // every wave is past its reads of stage s-1, whose buffer stage s+2 goes into
-    wait_stage(s + 1 < n_stages);
-    __builtin_amdgcn_s_barrier();
-    if (s + 2 < n_stages) {
-      issue_stage(s + 2, row_next);
-      if (s + 3 < n_stages) row_next = row_of(s + 3);
+        for (int a = 0; a < NA; ++a)
+          acc[a][b] = mfma_bf16(opa[a][P::a[t]], opb[P::b[t]], acc[a][b]);
     }
+  };
+  const int my_na = ta1 - ta0, my_nb = tb1 - tb0;     // 0..4 each, wave-uniform
+  const int shape = has_tiles && !(dbg & 4) ? my_na * 8 + my_nb : 0;
+  WP_MARK(0);
+  for (int s = 0; s < n_stages; ++s) {
+    __builtin_amdgcn_s_barrier();     // stage s has landed
+    WP_MARK(2);
     const unsigned buf = smem_base + (unsigned)((s % kBuffers) * kBuf);
 #define MSMD_SHAPE(A_, B_)                                                              \
-  case (A_) * 4 + (B_):                                                                  \
+  case (A_) * 8 + (B_):                                                                  \
     multiply(buf, std::integral_constant<int, A_>{}, std::integral_constant<int, B_>{}); \
     break;
     switch (shape) {
-      MSMD_SHAPE(4, 2) MSMD_SHAPE(4, 1) MSMD_SHAPE(3, 2) MSMD_SHAPE(3, 1) MSMD_SHAPE(2, 2)
-      MSMD_SHAPE(2, 1) MSMD_SHAPE(1, 2) MSMD_SHAPE(1, 1)
+      MSMD_SHAPE(4, 4) MSMD_SHAPE(4, 3) MSMD_SHAPE(4, 2) MSMD_SHAPE(4, 1)
+      MSMD_SHAPE(3, 4) MSMD_SHAPE(3, 3) MSMD_SHAPE(3, 2) MSMD_SHAPE(3, 1)
+      MSMD_SHAPE(2, 4) MSMD_SHAPE(2, 3) MSMD_SHAPE(2, 2) MSMD_SHAPE(2, 1)
+      MSMD_SHAPE(1, 4) MSMD_SHAPE(1, 3) MSMD_SHAPE(1, 2) MSMD_SHAPE(1, 1)
       default: break;
     }
 #undef MSMD_SHAPE
+    WP_MARK(5);
   }
   // ---- epilogue: D of tile (a, b): lane (n = i, g), reg r -> ci = 16a + 4g + r, co = 16b + n
   float* dst = partial + ((size_t)k * nchunks + chunk) * cin * cout;
 #pragma unroll
-  for (int a = 0; a < kWA; ++a)
+  for (int a = 0; a < kWT; ++a)
 #pragma unroll
-    for (int b = 0; b < kWB; ++b) {
+    for (int b = 0; b < kWT; ++b) {
       if (ta0 + a >= ta1 || tb0 + b >= tb1) continue;
       const int co = b0 + 16 * (tb0 + b) + m_i;
 #pragma unroll
@@ -432,17 +501,19 @@ template <int NP>
 int launch_wgrad_planes(const void* pa, int cin, int n_in, const void* pb, int cout, int n_out,
                         const int32_t* pairs, const int32_t* ranges, int ld, int nchunks, int kvol,
                         float* ws, hipStream_t st) {
-  constexpr size_t smem = (size_t)kBuffers * 2 * (2 * NP * 4 * 1024);
+  constexpr size_t smem = (size_t)kBuffers * 2 * (2 * NP * 4096);
   auto kern = spconv_wgrad_planes_kernel<NP>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
     attr_done = true;
   }
   const int slabs = ceil_div(cin, kSlab) * ceil_div(cout, kSlab);
+  static const int dbg = [] { const char* e = getenv("MSMD_DBG"); return e ? atoi(e) : 0; }();
   MSMD_LAUNCH(kern, dim3(wgrad_grid(nchunks, kvol, slabs)), dim3(512), smem, st,
               (const unsigned short*)pa, cin, n_in, (const unsigned short*)pb, cout, n_out, pairs,
-              ranges, ld, nchunks, kvol, ws, []{ const char* e = getenv("MSMD_DBG"); return e ? atoi(e) : 0; }());
+              ranges, ld, nchunks, kvol, ws, dbg);
   return launch_status();
 }
 
@@ -450,6 +521,18 @@ int launch_wgrad_planes(const void* pa, int cin, int n_in, const void* pb, int c
 }  // namespace msmd
 
 using namespace msmd;
+
+#ifdef MSMD_KERNEL_PROF
+// out[16] <- phase cycle sums of the wgrad plane kernel (then cleared): 0 prologue, 1 DMA
+// wait, 2 barrier, 3 DMA issue, 4 row indices, 5 LDS reads + MFMAs, 7 stages
+MSMD_EXPORT int msmd_debug_wprof(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wprof), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wprof), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 MSMD_EXPORT size_t msmd_planes_bytes(int n_rows, int channels, int planes) {
   return (size_t)(n_rows > 0 ? n_rows + 1 : 1) * (size_t)planes * (size_t)channels * 2;

@@ -189,6 +189,10 @@ __device__ __forceinline__ void wait_rows(u32x4 (&raw)[2][2]) {
                : "n"(N));
 }
 // 4 fp32 (one 16-byte piece) -> dwords [2h, 2h+1] of each bf16 plane.
+// Scalar arithmetic on purpose: beside MFMAs a v_pk_add_f32 costs ~13 cycles more than the
+// two v_sub_f32 it replaces (MI355X_MICROARCH.md, "price of one filler") -- with the
+// residuals as f32x2 vectors this conversion added ~780 cycles to a unit's 1536 MFMA
+// cycles (the file is built with -fno-slp-vectorize so the pairs are not re-packed).
 template <int NP>
 __device__ __forceinline__ void split_quarter(const u32x4& piece, int h, u32x4 (&planes)[NP]) {
 #pragma unroll
@@ -196,12 +200,16 @@ __device__ __forceinline__ void split_quarter(const u32x4& piece, int h, u32x4 (
     // (copy the elements out first: __builtin_bit_cast applied directly to a vector
     // element lvalue reads element 0 whatever the index -- clang 20)
     const unsigned e0 = piece[2 * t], e1 = piece[2 * t + 1];
-    f32x2 v = {__builtin_bit_cast(float, e0), __builtin_bit_cast(float, e1)};
+    float v0 = __builtin_bit_cast(float, e0), v1 = __builtin_bit_cast(float, e1);
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) {
-      const bf16x2 hi = __builtin_convertvector(v, bf16x2);
-      planes[pl][2 * h + t] = __builtin_bit_cast(unsigned int, hi);
-      if (pl + 1 < NP) v = v - __builtin_convertvector(hi, f32x2);   // exact
+      const f32x2 v = {v0, v1};
+      const unsigned hi = __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+      planes[pl][2 * h + t] = hi;
+      if (pl + 1 < NP) {   // exact residuals
+        v0 = v0 - __builtin_bit_cast(float, hi << 16);
+        v1 = v1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+      }
     }
   }
 }

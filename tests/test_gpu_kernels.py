@@ -271,7 +271,9 @@ def test_split_conv_subm(dev, cin, cout, planes):
         pre = K.tile_prefix(tab)
         out_k = K.conv_forward_split(fd, ws, tab, n, cout, planes, row_order=order,
                                      tile_prefix=pre)
-        assert (out_k - whole).abs().max().item() <= 2e-6 * scale
+        # (on this small input a segment is ~10 ranks: a tile is summed in 3-4 pieces;
+        # reassociating ~5000 products of a row costs a few 1e-6 of the largest output)
+        assert (out_k - whole).abs().max().item() <= 5e-6 * scale
         assert torch.equal(out_k, K.conv_forward_split(fd, ws, tab, n, cout, planes,
                                                        row_order=order, tile_prefix=pre))
     # KRSC weights pack to the same image

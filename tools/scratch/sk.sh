@@ -1,1 +1,3 @@
-for o in 0 2 8 16 48; do echo "== OVH=$o"; MSMD_SK_OVH=$o python tools/split_bench.py 2>&1 | grep fwd | sed 's/| fp32.*| split3/| split3/' | cut -c1-150; MSMD_SK_OVH=$o python tools/split_bench.py --lc 2>&1 | grep fwd| sed 's/| fp32.*| split3/| split3/' | cut -c1-150; done
+cd /root/repo
+python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "planes" 2>&1 | tail -3
+for D in 0 2 4; do echo "== DBG=$D"; MSMD_DBG=$D python tools/wgrad_planes_bench.py 2>&1 | grep "stage" | sed 's/+ split pass.*//' ; done
