@@ -233,6 +233,10 @@ int msmd_spconv_fwd_split(const float* in_feat /* [n_in,c_in] */, int n_in, int 
                                                         or NULL: dynamic tile scheduler */,
                           msmd_stream_t stream);
 
+/* Rows per tile the split kernel uses for a layer of c_out output channels (128 or 256):
+ * the rows_per_tile to compute its tile_prefix with. */
+int msmd_spconv_fwd_split_tile_rows(int c_out);
+
 /* Stream-K work table of a neighbour table (in the order the conv kernel tiles it):
  * prefix[t] = number of (row tile, active offset) work items before tile t, prefix[n_tiles]
  * = all of them (n_tiles = ceil(n_rows / rows_per_tile); an empty tile counts 1).  With it

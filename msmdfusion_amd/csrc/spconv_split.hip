@@ -287,8 +287,12 @@ constexpr int kSkMinRanks = 8;   // stream-K: smallest segment (ranks) worth a w
 // `nbr` must be in TILE order when `order` is given: column p of the table
 // belongs to output row order[p] (msmd_rulebook_permute_cols), so a tile's
 // slice is 512 contiguous bytes per offset.
-template <int NT, int UB, int NP>
-__global__ __launch_bounds__(256, 2) void spconv_fwd_split_kernel(
+// WV = waves per workgroup: 4 (128-row tiles, two workgroups per CU) or 8 (256-row tiles,
+// one workgroup per CU: the same 2 waves per SIMD, but ONE weight stream per CU instead of
+// two -- at ~17 B/clk the CU's memory pipeline could not feed two 24-KiB-per-item weight
+// streams plus the gathers at MFMA rate; stream-K removed the reason tiles had to be small).
+template <int NT, int UB, int NP, int WV>
+__global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_kernel(
     const float* __restrict__ in, int n_in, int cin, const u32x4* __restrict__ wp,
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
     const int32_t* __restrict__ order, int* __restrict__ tile_counter, float* __restrict__ out,
@@ -327,11 +331,11 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_split_kernel(
   // c0 into that.  Without it the segments of the light-mask tiles (few ranks each, many
   // tiles) took 4x as long as those of the dense ones on the 32-channel layers.  A range
   // that only touches a tile's overhead zone does not visit the tile.
-  constexpr int R = 2, kRows = 4 * R * 16;
+  constexpr int R = 2, kRows = WV * R * 16, kRowShift = WV == 4 ? 7 : 8;
   constexpr int kUnitU = NP * NT * 64;  // 16-byte units of one unit's weights (in LDS)
   constexpr int kWU = UB * kUnitU;
   constexpr int kGr = R * 2;            // gather loads per unit per lane
-  constexpr int kPw = (NP * NT + 3) / 4;  // weight DMA ops per unit per wave
+  constexpr int kPw = (NP * NT + WV - 1) / WV;  // weight DMA ops per unit per wave
   constexpr int kWp = UB * kPw;           // ... per item per wave
   constexpr int NS = NT / 2;            // fragment steps (pairs of 16-channel tiles) per unit
   static_assert(NT % 2 == 0, "pairs of output tiles");
@@ -361,8 +365,8 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_split_kernel(
   auto stage_table = [&](int T, int b) {
     int* dst = nbt + b * tstride;
     const int n_e = (kvol + (order ? 1 : 0)) * kRows;
-    for (int e0 = wave * 64; e0 < n_e; e0 += 256) {
-      const int e = e0 + lane, k = e >> 7;
+    for (int e0 = wave * 64; e0 < n_e; e0 += WV * 64) {
+      const int e = e0 + lane, k = e >> kRowShift;
       int p = T * kRows + (e & (kRows - 1));
       p = p < n_out ? p : n_out - 1;
       const int32_t* src = k < kvol ? nbr + (size_t)k * ld + p : order + p;
@@ -421,9 +425,11 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_split_kernel(
     const int* tab = nbt + tb * tstride;
     {  // offsets any row of this tile is connected through
       unsigned m = 0;
-      for (int k = wave; k < kvol; k += 4) {
-        const int v0 = tab[k * kRows + lane], v1 = tab[k * kRows + 64 + lane];
-        if (__any((v0 & v1) >= 0)) m |= 1u << k;   // v0 >= 0 || v1 >= 0
+      for (int k = wave; k < kvol; k += WV) {
+        int v = tab[k * kRows + lane];
+#pragma unroll
+        for (int c = 1; c < kRows / 64; ++c) v &= tab[k * kRows + 64 * c + lane];
+        if (__any(v >= 0)) m |= 1u << k;   // some row has a neighbour (-1 & x < 0 iff both < 0)
       }
       if (lane == 0 && m) atomicOr((unsigned*)&ctl[tb], m);
     }
@@ -493,8 +499,8 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_split_kernel(
         // piece 0: same bytes to the same place) so the queue counts are static
 #pragma unroll
         for (int pp = 0; pp < kPw; ++pp) {
-          int piece = wave + 4 * pp;
-          if ((NP * NT) % 4 != 0 && piece >= NP * NT) piece = 0;
+          int piece = wave + WV * pp;
+          if ((NP * NT) % WV != 0 && piece >= NP * NT) piece = 0;
           const int pl = piece / NT;
           int tile = mt0 + piece - pl * NT;          // tiles past the packed image repeat
           tile = tile < nt_total ? tile : nt_total - 1;   // the last one (never stored)
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_split_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- epilogue: lane (j,q) holds out[row j][16n + 4q .. +3] ----
     const int rt = tile;
-    constexpr int kSlotU = 4 * R * NT * 64;   // one tile's accumulators, f32x4 units
+    constexpr int kSlotU = WV * R * NT * 64;   // one tile's accumulators, f32x4 units
     // The exchange goes through agent-scope (sc1) accesses to the scratch lines and the
     // flag only: coherent across the XCDs' L2s on their own.  Fences would do it too,
     // but an agent-scope release writes back the whole L2 and an acquire invalidates it
@@ -698,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_split_kernel(
       // tile's first ranks, in ticket order
       if (sk && sk_lo > 0) {
         for (int c = sk_ts / sk_S; c < sk_seg; ++c) {
-          while (__hip_atomic_load(&flags[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4)
+          while (__hip_atomic_load(&flags[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < WV)
             __builtin_amdgcn_s_sleep(4);
           asm volatile("" ::: "memory");
           unsigned long long* sp = (unsigned long long*)(scratch + (size_t)c * kSlotU + lane);
@@ -712,10 +718,10 @@ __global__ __launch_bounds__(256, 2) void spconv_fwd_split_kernel(
               v[1] = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               acc[r][n] += __builtin_bit_cast(f32x4, v);
             }
-          if (lane == 0) {   // the last of the four reading waves re-arms the flag
+          if (lane == 0) {   // the last of the reading waves re-arms the flag
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (__hip_atomic_fetch_add(&flags[c], 1, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT) == 7)
+                                       __HIP_MEMORY_SCOPE_AGENT) == 2 * WV - 1)
               __hip_atomic_store(&flags[c], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
@@ -758,7 +764,7 @@ int split_slots_per_cu() {
   return v;
 }
 
-template <int NT, int UB, int NP>
+template <int NT, int UB, int NP, int WV>
 int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                      int ld, int n_out, int kvol, int flip, const int32_t* order,
                      int* tile_counter, float* out, int ldo, int cout, int nt_total, int mt0,
@@ -771,39 +777,58 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   const int ovh_units = ovh_env >= 0 ? ovh_env : 8;
   const int kbt = (cin + 31) / 32;
   const int sk_c0 = (ovh_units + kbt - 1) / kbt;
-  constexpr int kRows = 128;
+  constexpr int kRows = WV * 32;
   const size_t smem = sizeof(u32x4) * 2 * UB * NP * NT * 64 +
                       sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 8);
   const int n_tiles = ceil_div(n_out, kRows);
   int nblk = n_tiles;
-  const int slots = 256 * split_slots_per_cu();
+  const int slots = 256 * (WV == 4 ? split_slots_per_cu() : 1);
   if (nblk > slots) nblk = slots;
   if (tile_start) nblk = sk_grid;     // stream-K: one segment per workgroup
-  auto kern = spconv_fwd_split_kernel<NT, UB, NP>;
+  auto kern = spconv_fwd_split_kernel<NT, UB, NP, WV>;
   static size_t attr_smem = 0;  // per instantiation
   if (smem > attr_smem) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_smem = smem;
   }
-  MSMD_LAUNCH(kern, dim3(nblk), dim3(256), smem, st, in, n_in, cin, (const u32x4*)wp, nbr, ld,
+  MSMD_LAUNCH(kern, dim3(nblk), dim3(WV * 64), smem, st, in, n_in, cin, (const u32x4*)wp, nbr, ld,
               n_out, kvol, flip, order, tile_counter, out, ldo, cout, nt_total, mt0,
               (f32x4*)scratch, flags, tile_start, sk_c0, env_int2("MSMD_DBG", 0));
   return launch_status();
 }
 
+// Waves per workgroup / rows per tile of the split kernel (see the kernel): 4 x 128 rows,
+// two workgroups per CU.  MSMD_FWD_WAVES=8 selects the 8-wave / 256-row instantiations
+// (one workgroup per CU, one weight stream per CU, two units per weight buffer for the wide
+// layers): measured within +-5 % of the 4-wave ones on the 128-/192-channel layers (260 vs
+// 259-268 us on 128->128) and 25 % slower on the 80-channel ones -- the two waves of a SIMD
+// then belong to the same workgroup and stall at its barriers together.  Kept as an
+// experiment knob.
+int fwd_waves(int cout) {
+  (void)cout;
+  static const int force = env_int2("MSMD_FWD_WAVES", 0);
+  return force == 8 ? 8 : 4;
+}
 // stream-K: workgroups (= segments = exchange slots) of a launch over `row_tiles` tiles,
 // and the exchange buffer: one pass's accumulators of one tile per workgroup
-int sk_grid_size(int row_tiles, int kvol) {
+int sk_grid_size(int row_tiles, int kvol, int waves) {
   const long ranks_max = (long)row_tiles * kvol;
-  const long slots = 256L * split_slots_per_cu();
+  const long slots = 256L * (waves == 4 ? split_slots_per_cu() : 1);
   return (int)(ranks_max < slots ? ranks_max : slots);
 }
-size_t fwd_sk_ws_bytes(int row_tiles, int kvol, int cout) {
+size_t fwd_sk_ws_bytes(int n_out, int kvol, int cout) {
   const int nt_total = (cout + 15) / 16;
   const int n_pass = (nt_total + 7) / 8;
   int per = (nt_total + n_pass - 1) / n_pass;
   per = per > 6 ? 8 : per > 4 ? 6 : per > 2 ? 4 : 2;      // the instantiation's NT
-  return (size_t)sk_grid_size(row_tiles, kvol) * 128 * 16 * per * sizeof(float);
+  size_t need = 0;
+  for (int waves = 4; waves <= 8; waves += 4) {            // whichever the dispatch picks
+    const int rows = waves * 32;
+    const size_t b = (size_t)sk_grid_size(ceil_div(n_out > 0 ? n_out : 0, rows), kvol, waves) *
+                     rows * 16 * per * sizeof(float);
+    need = b > need ? b : need;
+  }
+  return need;
 }
 
 // c_out is covered in passes of at most 128 channels (8 tiles of 16; a pass's
@@ -816,14 +841,15 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
   const int nt_total = (cout + 15) / 16;
   const int n_pass = (nt_total + 7) / 8;
   const int per = (nt_total + n_pass - 1) / n_pass;   // tiles per pass
-  const int row_tiles = ceil_div(n_out, 128);
-  // Stream-K (see the kernel) whenever the caller passed the tile prefix and the exchange
-  // buffers cover one slot / one flag per workgroup; MSMD_STREAMK=0 falls back to the
-  // dynamic tile scheduler above (experiments).
+  const int waves = fwd_waves(cout);
+  const int row_tiles = ceil_div(n_out, waves * 32);
+  // Stream-K (see the kernel) whenever the caller passed the tile prefix (computed for this
+  // layer's tile size: msmd_spconv_fwd_split_tile_rows) and the exchange buffers cover one
+  // slot / one flag per workgroup; MSMD_STREAMK=0 falls back to the dynamic tile scheduler.
   static const int sk_on = env_int2("MSMD_STREAMK", 1);
-  const int sk_grid = sk_grid_size(row_tiles, kvol);
+  const int sk_grid = sk_grid_size(row_tiles, kvol, waves);
   const int32_t* tile_start = nullptr;
-  if (sk_on && tile_prefix && ws && ws_bytes >= fwd_sk_ws_bytes(row_tiles, kvol, cout) &&
+  if (sk_on && tile_prefix && ws && ws_bytes >= fwd_sk_ws_bytes(n_out, kvol, cout) &&
       sync_ints >= 1 + sk_grid) {
     tile_start = tile_prefix;
   }
@@ -834,14 +860,27 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
     const int width = (16 * (mt0 + tiles) <= cout ? 16 * tiles : cout - 16 * mt0);
     float* o = out + 16 * mt0;
     int rc;
-#define MSMD_GO(NT_, UB_)                                                                      \
-  rc = launch_fwd_split<NT_, UB_, NP>(in, n_in, cin, wp, nbr, ld, n_out, kvol, flip, order,   \
-                                      tile_counter, o, cout, width, nt_total, mt0, ws, flags,     \
-                                      tile_start, sk_grid, st)
-    if (tiles > 6) { MSMD_GO(8, 1); }
-    else if (tiles > 4) { MSMD_GO(6, 1); }
-    else if (tiles > 2) { MSMD_GO(4, 2); }
-    else { MSMD_GO(2, 4); }
+#define MSMD_GO(NT_, UB_, WV_)                                                                   \
+  rc = launch_fwd_split<NT_, UB_, NP, WV_>(in, n_in, cin, wp, nbr, ld, n_out, kvol, flip, order, \
+                                           tile_counter, o, cout, width, nt_total, mt0, ws,      \
+                                           flags, tile_start, sk_grid, st)
+    static const int ub8 = env_int2("MSMD_FWD_UB8", 2);   // units per item of the 8-wave kernels
+    if (waves == 8 && ub8 == 2 && tiles > 4) {
+      // two units per weight buffer: 2 x 48 KiB + 57 KiB of tables = 153 KiB, one barrier
+      // and one queue drain per 192 MFMAs of a wave instead of per 96
+      if (tiles > 6) { MSMD_GO(8, 2, 8); }
+      else { MSMD_GO(6, 2, 8); }
+    } else if (waves == 8) {
+      if (tiles > 6) { MSMD_GO(8, 1, 8); }
+      else if (tiles > 4) { MSMD_GO(6, 1, 8); }
+      else if (tiles > 2) { MSMD_GO(4, 2, 8); }
+      else { MSMD_GO(2, 4, 8); }
+    } else {
+      if (tiles > 6) { MSMD_GO(8, 1, 4); }
+      else if (tiles > 4) { MSMD_GO(6, 1, 4); }
+      else if (tiles > 2) { MSMD_GO(4, 2, 4); }
+      else { MSMD_GO(2, 4, 4); }
+    }
 #undef MSMD_GO
     if (rc != MSMD_OK) return rc;
   }
@@ -1106,8 +1145,10 @@ MSMD_EXPORT int msmd_spconv_fwd_split_supported(int cin, int cout, int kvol) {
          kvol <= kMaxK;
 }
 
+MSMD_EXPORT int msmd_spconv_fwd_split_tile_rows(int cout) { return 32 * fwd_waves(cout); }
+
 MSMD_EXPORT size_t msmd_spconv_fwd_split_workspace_bytes(int n_out, int cout) {
-  return fwd_sk_ws_bytes(ceil_div(n_out > 0 ? n_out : 0, 128), kMaxK, cout);
+  return fwd_sk_ws_bytes(n_out, kMaxK, cout);
 }
 
 MSMD_EXPORT int msmd_spconv_fwd_split(const float* planes, int n_in, int cin, const void* packed,

@@ -397,15 +397,21 @@ def permute_cols(nbr, order):
     return out
 
 
-def tile_prefix(nbr):
+def split_tile_rows(c_out):
+    """Rows per tile of the split kernel for a layer with c_out output channels."""
+    return int(lib.msmd_spconv_fwd_split_tile_rows(int(c_out)))
+
+
+def tile_prefix(nbr, rows=TILE_ROWS):
     """Stream-K work table of a neighbour table given in the order the conv kernel tiles
-    it (tile order when a row order is used): int32 [n_tiles + 1], see
+    it (tile order when a row order is used), for tiles of `rows` rows
+    (split_tile_rows(c_out) of the layer): int32 [n_tiles + 1], see
     msmd_rulebook_tile_prefix."""
     _need_cuda(nbr)
     kvol, n = nbr.shape
     t = nbr.contiguous()
-    out = torch.empty(((n + TILE_ROWS - 1) // TILE_ROWS + 1,), dtype=torch.int32, device=t.device)
-    check(lib.msmd_rulebook_tile_prefix(_p(t), kvol, n, n, TILE_ROWS, _p(out), _stream()),
+    out = torch.empty(((n + rows - 1) // rows + 1,), dtype=torch.int32, device=t.device)
+    check(lib.msmd_rulebook_tile_prefix(_p(t), kvol, n, n, int(rows), _p(out), _stream()),
           "msmd_rulebook_tile_prefix")
     return out
 
@@ -428,6 +434,11 @@ def conv_forward_split(feat, packed_weight, nbr, n_out, c_out, planes=3, weight_
     counter = _tile_counter(f.device)
     nbytes = lib.msmd_spconv_fwd_split_workspace_bytes(int(n_out), int(c_out))
     ws = _exchange_buffer(f.device, nbytes) if split_tiles else None
+    if tile_prefix is not None and split_tiles:
+        rows = split_tile_rows(c_out)
+        if tile_prefix.numel() != (int(n_out) + rows - 1) // rows + 1:
+            raise ValueError("tile_prefix was not computed for %d-row tiles (K.tile_prefix(nbr, "
+                             "K.split_tile_rows(c_out)))" % rows)
     ev = _prof_begin()
     check(lib.msmd_spconv_fwd_split(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld,
                                     int(n_out), kvol, int(bool(weight_flip)), _p(row_order),

@@ -35,8 +35,8 @@ class IndiceData:
         self._order_bwd = None
         self._tiled_fwd = None
         self._tiled_bwd = None
-        self._prefix_fwd = None
-        self._prefix_bwd = None
+        self._prefix_fwd = {}
+        self._prefix_bwd = {}
 
     @property
     def n_in(self):
@@ -63,12 +63,12 @@ class IndiceData:
             from .functional import _use_split, _wants_order
             kvol = self.nbr_fwd.shape[0]
             if _use_split(c_in, c_out, kvol, self.n_in):
-                self.prefix_fwd()
+                self.prefix_fwd(c_out)
             elif _wants_order(c_in, c_out):
                 self.order_fwd()
             if need_grad:       # dgrad: the same kernel over the mirrored problem
                 if _use_split(c_out, c_in, kvol, self.n_out):
-                    self.prefix_bwd()
+                    self.prefix_bwd(c_in)
                 elif _wants_order(c_out, c_in):
                     self.order_bwd()
         return self
@@ -103,19 +103,22 @@ class IndiceData:
             self._order_fwd, self._tiled_fwd = (order,), (table,)
         return self._tiled_fwd[0], self._order_fwd[0]
 
-    def prefix_fwd(self):
-        """Stream-K work table of the forward tiling (K.tile_prefix): with it every
-        workgroup of the split kernel takes the same share of the launch."""
-        if self._prefix_fwd is None:
-            self._prefix_fwd = K.tile_prefix(self.tiling_fwd()[0])
-        return self._prefix_fwd
+    def prefix_fwd(self, c_out):
+        """Stream-K work table of the forward tiling (K.tile_prefix) for a conv with
+        c_out output channels (the kernel's tile size depends on the width): with it
+        every workgroup of the split kernel takes the same share of the launch."""
+        rows = K.split_tile_rows(c_out)
+        if rows not in self._prefix_fwd:
+            self._prefix_fwd[rows] = K.tile_prefix(self.tiling_fwd()[0], rows)
+        return self._prefix_fwd[rows]
 
-    def prefix_bwd(self):
+    def prefix_bwd(self, c_in):
         if self.is_subm:
-            return self.prefix_fwd()
-        if self._prefix_bwd is None:
-            self._prefix_bwd = K.tile_prefix(self.tiling_bwd()[0])
-        return self._prefix_bwd
+            return self.prefix_fwd(c_in)
+        rows = K.split_tile_rows(c_in)
+        if rows not in self._prefix_bwd:
+            self._prefix_bwd[rows] = K.tile_prefix(self.tiling_bwd()[0], rows)
+        return self._prefix_bwd[rows]
 
     def tiling_bwd(self):
         if self.is_subm:      # forward table + flipped weights == backward table

@@ -157,7 +157,7 @@ class _SparseConvFunction(Function):
                 packed = K.pack_weight_split(weight, np_, krsc=krsc)
             table, order = rb.tiling_fwd()
             return K.conv_forward_split(features, packed, table, rb.n_out, c_out, np_,
-                                        row_order=order, tile_prefix=rb.prefix_fwd())
+                                        row_order=order, tile_prefix=rb.prefix_fwd(c_out))
         return _conv_f32(features, weight, krsc, False, rb.nbr_fwd, rb.n_out,
                          row_order=rb.order_fwd() if _wants_order(c_in, c_out) else None)
 
@@ -195,7 +195,7 @@ class _SparseConvFunction(Function):
             table, order = rb.tiling_bwd()
             d_feat = K.conv_forward_split(grad_out, packed_t, table, rb.n_in, c_in, np_,
                                           weight_flip=rb.is_subm, row_order=order,
-                                          tile_prefix=rb.prefix_bwd())
+                                          tile_prefix=rb.prefix_bwd(c_in))
         elif ctx.needs_input_grad[0]:
             order = rb.order_bwd() if _wants_order(c_out, c_in) else None
             # SubM: forward table + flipped weights == backward table

@@ -268,7 +268,7 @@ def test_split_conv_subm(dev, cin, cout, planes):
         assert torch.equal(out_s, K.conv_forward_split(fd, ws, tab, n, cout, planes,
                                                        row_order=order))
         # stream-K: tiles cut at segment boundaries are summed in pieces, in ticket order
-        pre = K.tile_prefix(tab)
+        pre = K.tile_prefix(tab, K.split_tile_rows(cout))
         out_k = K.conv_forward_split(fd, ws, tab, n, cout, planes, row_order=order,
                                      tile_prefix=pre)
         # (on this small input a segment is ~10 ranks: a tile is summed in 3-4 pieces;
@@ -495,7 +495,7 @@ def test_split_conv_under_cu_contention(dev):
     # the same under stream-K scheduling: an owner waits only for lower tickets, which are
     # resident by construction -- late workgroups cannot deadlock it, and the counter and
     # every exchange flag are back at 0 after each launch
-    pre = K.tile_prefix(nbr_t)
+    pre = K.tile_prefix(nbr_t, K.split_tile_rows(64))
     ref_k = K.conv_forward_split(f, ws, nbr_t, n, 64, 3, row_order=order, tile_prefix=pre)
     assert (ref_k - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
     torch.cuda.synchronize()
@@ -521,19 +521,21 @@ def test_tile_prefix(dev):
     order = K.row_mask_order(nbr)
     tab = K.permute_cols(nbr, order)
     tab[:, 256:384] = -1                   # one tile without any neighbour
-    got = K.tile_prefix(tab).cpu().numpy()
     tn = tab.cpu().numpy()
     n = tn.shape[1]
-    w = []
-    for t0 in range(0, n, 128):
-        m = (tn[:, t0:t0 + 128] >= 0).any(1).sum()
-        w.append(max(int(m), 1))
-    assert np.array_equal(got, np.concatenate([[0], np.cumsum(w)]))
-    assert w[2] == 1
+    for rows in (128, 256):
+        got = K.tile_prefix(tab, rows).cpu().numpy()
+        w = []
+        for t0 in range(0, n, rows):
+            m = (tn[:, t0:t0 + rows] >= 0).any(1).sum()
+            w.append(max(int(m), 1))
+        assert np.array_equal(got, np.concatenate([[0], np.cumsum(w)]))
+        if rows == 128:
+            assert w[2] == 1
     # such a tile's rows still come out as zeros under stream-K
     f = torch.randn(n, 32, device=dev)
     ws = K.pack_weight_split(torch.randn(27, 32, 32, device=dev) * 0.1, 3)
-    out = K.conv_forward_split(f, ws, tab, n, 32, 3, row_order=order, tile_prefix=K.tile_prefix(tab))
+    out = K.conv_forward_split(f, ws, tab, n, 32, 3, row_order=order, tile_prefix=K.tile_prefix(tab, K.split_tile_rows(32)))
     whole = K.conv_forward_split(f, ws, tab, n, 32, 3, row_order=order, split_tiles=False)
     assert (out - whole).abs().max().item() <= 2e-6 * whole.abs().max().item()
     assert not out[order[256:384].long()].abs().any()

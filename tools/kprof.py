@@ -19,7 +19,7 @@ for i, (pad, c) in enumerate([(1, 32), (1, 64), ([0, 1, 1], 128)]):
     idx, _, _, shape = K.rulebook_conv(idx, 4, shape, 3, 2, pad)
     nbr = K.rulebook_subm(idx, 4, shape, 3); n = idx.shape[0]
     f = torch.randn(n, c, device=dev); ws = K.pack_weight_split(torch.randn(27, c, c, device=dev) * 0.05, 3)
-    o, nt = K.rulebook_tiling(nbr); pre = K.tile_prefix(nt)
+    o, nt = K.rulebook_tiling(nbr); pre = K.tile_prefix(nt, K.split_tile_rows(c))
     for _ in range(3):
         K.conv_forward_split(f, ws, nt, n, c, 3, row_order=o, tile_prefix=pre)
     buf = (ctypes.c_ulonglong * 16)()

@@ -26,7 +26,7 @@ for i, (pad, c) in enumerate([(1, 32), (1, 64), ([0, 1, 1], 128)]):
     nbr = K.rulebook_subm(idx, 4, shape, 3); n = idx.shape[0]
     f = torch.randn(n, c, device=dev); ws = K.pack_weight_split(torch.randn(27, c, c, device=dev) * 0.05, 3)
     o, nt = K.rulebook_tiling(nbr)
-    pre = K.tile_prefix(nt) if sk else None
+    pre = K.tile_prefix(nt, K.split_tile_rows(c)) if sk else None
     for _ in range(3):
         K.conv_forward_split(f, ws, nt, n, c, 3, row_order=o, tile_prefix=pre)
     buf = np.zeros((16384, 8), dtype=np.uint64)

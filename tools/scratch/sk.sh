@@ -1,3 +1,3 @@
 cd /root/repo
-python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "planes" 2>&1 | tail -3
-for D in 0 2 4; do echo "== DBG=$D"; MSMD_DBG=$D python tools/wgrad_planes_bench.py 2>&1 | grep "stage" | sed 's/+ split pass.*//' ; done
+MSMD_FWD_WAVES=8 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "split_conv or tile_prefix" 2>&1 | tail -3
+for U in 2 1; do echo "== WAVES=8 UB8=$U"; MSMD_FWD_UB8=$U MSMD_FWD_WAVES=8 python tools/split_bench.py 2>&1 | grep fwd | sed 's/| fp32.*| split3/| split3/' | cut -c1-150; MSMD_FWD_UB8=$U MSMD_FWD_WAVES=8 python tools/split_bench.py --lc 2>&1 | grep fwd| sed 's/| fp32.*| split3/| split3/' | cut -c1-150; done

@@ -85,7 +85,7 @@ def main():
             ts = timed(lambda: K.conv_forward_split(f, ws, nbr_t, n, cout, args.planes,
                                                     row_order=order))
             line += " | split%d %.0f us %.1f TF" % (args.planes, ts, flops / ts / 1e6)
-            pre = K.tile_prefix(nbr_t)
+            pre = K.tile_prefix(nbr_t, K.split_tile_rows(cout))
             tk = timed(lambda: K.conv_forward_split(f, ws, nbr_t, n, cout, args.planes,
                                                     row_order=order, tile_prefix=pre))
             line += " | stream-K %.0f us %.1f TF (frac %.3f)" % (tk, flops / tk / 1e6,
