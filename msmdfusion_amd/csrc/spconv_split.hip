@@ -259,7 +259,19 @@ __device__ __forceinline__ int count_le(const int32_t* __restrict__ a, int n, in
   const int v = idx < hi ? a[idx] + c0 * idx : 0x7fffffff;
   return lo + __builtin_popcountll(__ballot(v <= x));
 }
-constexpr int kSkMinRanks = 8;   // stream-K: smallest segment (ranks) worth a workgroup
+constexpr int kSkMinRanks = 64;  // stream-K: smallest segment (cost units) worth a workgroup
+// Cost of one (tile, active offset) in stream-K's work sequence: sk_c1() + the number of the
+// tile's 32-row groups (= waves) with a row connected through the offset.  tools/ktrace.py
+// shows the workgroups of the dense tiles at 2.3 us per item and those of the light-mask
+// tiles at 1.5, but weighting by the busy waves does not pay: C1 = 0 / 1 / 3 / 6 / 12 gave
+// 298 / 278 / 268 / 261 / 263 us on the 128->128 layer -- the per-item time follows what
+// the whole chip is doing at that moment (everybody starts in dense tiles), not the tile.
+// 12 keeps the term as a tie-breaker.
+constexpr int kSkC1Default = 12;
+inline int sk_c1() {   // MSMD_SK_C1 overrides (experiments)
+  static const int v = [] { const char* e = getenv("MSMD_SK_C1"); return e ? atoi(e) : kSkC1Default; }();
+  return v;
+}
 
 // ------------------------------------------------------- forward / dgrad --
 // One workgroup = 4 waves x 32 output rows (two 16-row MFMA groups per wave) x
@@ -297,7 +309,8 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
     const int32_t* __restrict__ order, int* __restrict__ tile_counter, float* __restrict__ out,
     int ldo, int cout, int nt_total, int mt0, f32x4* __restrict__ scratch,
-    int* __restrict__ flags, const int32_t* __restrict__ tile_start, int sk_c0, int dbg) {
+    int* __restrict__ flags, const int32_t* __restrict__ tile_start, int sk_c0, int sk_c1v,
+    int dbg) {
   // Scheduling.  Without `tile_start`: persistent workgroups draw whole 128-row tiles from
   // a global counter (tiles arrive heaviest first: LPT list scheduling), every tile is one
   // unit and the result does not depend on the tiling order at all.  A tile whose rows are
@@ -423,29 +436,45 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
       sk_ts = t0s + sk_c0 * (tile + 1);        // where the tile's ranks start
     }
     const int* tab = nbt + tb * tstride;
-    {  // offsets any row of this tile is connected through
+    int* cst = ctl + 4 + tb * 32;     // stream-K cost of every offset of this tile (0: none)
+    {  // offsets any row of this tile is connected through, and how many waves each keeps busy
       unsigned m = 0;
       for (int k = wave; k < kvol; k += WV) {
-        int v = tab[k * kRows + lane];
+        int nact = 0;
 #pragma unroll
-        for (int c = 1; c < kRows / 64; ++c) v &= tab[k * kRows + 64 * c + lane];
-        if (__any(v >= 0)) m |= 1u << k;   // some row has a neighbour (-1 & x < 0 iff both < 0)
+        for (int c = 0; c < kRows / 64; ++c) {
+          const unsigned long long b = __ballot(tab[k * kRows + 64 * c + lane] >= 0);
+          nact += ((unsigned)b != 0u) + ((unsigned)(b >> 32) != 0u);
+        }
+        if (nact) m |= 1u << k;
+        if (lane == 0) cst[k] = nact ? sk_c1v + nact : 0;
       }
       if (lane == 0 && m) atomicOr((unsigned*)&ctl[tb], m);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the tile-id atomic too)
     __builtin_amdgcn_s_barrier();
     unsigned mask = __builtin_amdgcn_readfirstlane(ctl[tb]);
-    // stream-K: ranks [sk_lo, sk_hi) of the tile's sk_tw active offsets are this workgroup's
+    // stream-K: the offsets whose cost span STARTS in [sk_lo, sk_hi) of the tile's sk_tw
+    // units are this workgroup's; lane k (and k + 32) holds offset k's cost and start
     const int sk_lo = sk ? (sk_g0 > sk_ts ? sk_g0 - sk_ts : 0) : 0;
     const int sk_hi = sk ? (sk_g1 - sk_ts < sk_tw ? sk_g1 - sk_ts : sk_tw) : 0;
+    int sk_c = 0, sk_p = 0;
+    bool sk_owner = true;
     if (sk) {
-      unsigned sel = 0, rest = mask;
-      for (int c = 0; c < sk_hi && rest; ++c) {
-        if (c >= sk_lo) sel |= rest & -rest;
-        rest &= rest - 1;
+      for (int k = 0; k < kvol; ++k) {
+        const int c = cst[k];               // (uniform address: one broadcast read)
+        sk_p += k < (lane & 31) ? c : 0;
+        sk_c = k == (lane & 31) ? c : sk_c;
       }
-      mask = sel;
+      // the workgroup that takes the tile's last offset owns the tile (an empty tile: the
+      // one whose range holds its single unit)
+      if (mask) {
+        const int p_last = __builtin_amdgcn_readlane(sk_p, 31 - __builtin_clz(mask));
+        sk_owner = p_last >= sk_lo && p_last < sk_hi;
+      } else {
+        sk_owner = sk_lo == 0 && sk_hi > 0;
+      }
+      mask = (unsigned)__ballot(sk_c > 0 && sk_p >= sk_lo && sk_p < sk_hi);
     }
     const int kb0 = 0, kb1 = kbt;
     const int n_units = __builtin_popcount(mask) * (kb1 - kb0);
@@ -684,8 +713,10 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
     // flag only: coherent across the XCDs' L2s on their own.  Fences would do it too,
     // but an agent-scope release writes back the whole L2 and an acquire invalidates it
     // -- the weights and the table live there (measured: 62 -> 192 us on a 32-channel layer).
-    if (sk && sk_hi < sk_tw) {
+    if (sk && !sk_owner) {
       // a piece of a tile another workgroup owns: accumulators -> scratch[ticket], signal
+      // (nothing at all when the range took none of the tile's offsets)
+      if (mask != 0u) {
       unsigned long long* sp = (unsigned long long*)(scratch + (size_t)sk_seg * kSlotU + lane);
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -699,11 +730,15 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // written through before the signal
       if (lane == 0)
         __hip_atomic_fetch_add(&flags[sk_seg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     } else {
       // owner (or a whole tile): first add the pieces of the lower tickets that hold the
       // tile's first ranks, in ticket order
       if (sk && sk_lo > 0) {
         for (int c = sk_ts / sk_S; c < sk_seg; ++c) {
+          // (a lower ticket whose range took none of this tile's offsets left nothing)
+          const int rlo = c * sk_S - sk_ts;
+          if ((unsigned)__ballot(sk_c > 0 && sk_p >= rlo && sk_p < rlo + sk_S) == 0u) continue;
           while (__hip_atomic_load(&flags[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < WV)
             __builtin_amdgcn_s_sleep(4);
           asm volatile("" ::: "memory");
@@ -776,10 +811,10 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   // (swept 0..48 on the bench layers: 8 is within 2 % of the best for every width)
   const int ovh_units = ovh_env >= 0 ? ovh_env : 8;
   const int kbt = (cin + 31) / 32;
-  const int sk_c0 = (ovh_units + kbt - 1) / kbt;
+  const int sk_c0 = ((ovh_units + kbt - 1) / kbt) * (sk_c1() + 2);   // in cost units
   constexpr int kRows = WV * 32;
   const size_t smem = sizeof(u32x4) * 2 * UB * NP * NT * 64 +
-                      sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 8);
+                      sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 72);
   const int n_tiles = ceil_div(n_out, kRows);
   int nblk = n_tiles;
   const int slots = 256 * (WV == 4 ? split_slots_per_cu() : 1);
@@ -793,7 +828,7 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   }
   MSMD_LAUNCH(kern, dim3(nblk), dim3(WV * 64), smem, st, in, n_in, cin, (const u32x4*)wp, nbr, ld,
               n_out, kvol, flip, order, tile_counter, out, ldo, cout, nt_total, mt0,
-              (f32x4*)scratch, flags, tile_start, sk_c0, env_int2("MSMD_DBG", 0));
+              (f32x4*)scratch, flags, tile_start, sk_c0, sk_c1(), env_int2("MSMD_DBG", 0));
   return launch_status();
 }
 
@@ -898,26 +933,31 @@ __global__ __launch_bounds__(256) void permute_cols_kernel(const int32_t* __rest
   for (int k = 0; k < kvol; ++k) out[(size_t)k * n + p] = nbr[(size_t)k * ld + row];
 }
 
-// Stream-K work table: weight[t] = max(|union of the offset masks of tile t's rows|, 1),
-// tile t = columns [t * rows, (t+1) * rows) of the table; prefix[t] = sum of the weights
-// before t, prefix[n_tiles] = total.  One block per tile, then a one-block scan.
-__global__ __launch_bounds__(128) void tile_weight_kernel(const int32_t* __restrict__ nbr,
+// Stream-K work table: weight[t] = max(sum over the offsets of tile t's cost, 1), the cost of
+// an offset = sk_c1() + the number of 32-row groups of the tile with a row connected through it
+// (0 when none; exactly what the conv kernel computes from the tile's table slice, positions
+// past n clamped to the last row as there).  Tile t = columns [t * rows, (t+1) * rows);
+// prefix[t] = sum of the weights before t, prefix[n_tiles] = total.  One block of `rows`
+// threads per tile, then a one-block scan.
+__global__ __launch_bounds__(256) void tile_weight_kernel(const int32_t* __restrict__ nbr,
                                                           int kvol, int ld, int n, int rows,
-                                                          int32_t* __restrict__ weight) {
-  __shared__ unsigned m;
-  if (threadIdx.x == 0) m = 0;
+                                                          int c1, int32_t* __restrict__ weight) {
+  __shared__ int s_cnt[kMaxK];
+  __shared__ int s_total;
+  if (threadIdx.x < kMaxK) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_total = 0;
   __syncthreads();
-  unsigned v = 0;
-  for (int p = blockIdx.x * rows + threadIdx.x; p < (blockIdx.x + 1) * rows && p < n;
-       p += blockDim.x)
-    for (int k = 0; k < kvol; ++k)
-      if (nbr[(size_t)k * ld + p] >= 0) v |= 1u << k;
-  if (v) atomicOr(&m, v);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int pc = __builtin_popcount(m);
-    weight[blockIdx.x] = pc > 0 ? pc : 1;
+  int p = blockIdx.x * rows + threadIdx.x;
+  p = p < n ? p : n - 1;
+  for (int k = 0; k < kvol; ++k) {
+    const unsigned long long b = __ballot(nbr[(size_t)k * ld + p] >= 0);
+    const int groups = ((unsigned)b != 0u) + ((unsigned)(b >> 32) != 0u);
+    if ((threadIdx.x & 63) == 0 && groups) atomicAdd(&s_cnt[k], groups);
   }
+  __syncthreads();
+  if (threadIdx.x < kvol && s_cnt[threadIdx.x]) atomicAdd(&s_total, c1 + s_cnt[threadIdx.x]);
+  __syncthreads();
+  if (threadIdx.x == 0) weight[blockIdx.x] = s_total > 0 ? s_total : 1;
 }
 __global__ __launch_bounds__(1024) void tile_prefix_kernel(int32_t* __restrict__ a, int n) {
   // in place: a[0..n) weights -> a[0..n] exclusive prefix (a has n + 1 entries)
@@ -1176,7 +1216,8 @@ MSMD_EXPORT int msmd_rulebook_tile_prefix(const int32_t* nbr, int kvol, int ld, 
                                           int rows_per_tile, int32_t* prefix,
                                           msmd_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (kvol < 1 || kvol > kMaxK || n_rows < 0 || ld < n_rows || rows_per_tile < 1 || !prefix ||
+  if (kvol < 1 || kvol > kMaxK || n_rows < 0 || ld < n_rows || !prefix ||
+      (rows_per_tile != 128 && rows_per_tile != 256) ||
       (n_rows > 0 && !nbr))
     return MSMD_ERR_INVALID_ARG;
   const int n_tiles = ceil_div(n_rows, rows_per_tile);
@@ -1184,8 +1225,8 @@ MSMD_EXPORT int msmd_rulebook_tile_prefix(const int32_t* nbr, int kvol, int ld, 
     hipMemsetAsync(prefix, 0, sizeof(int32_t), st);
     return launch_status();
   }
-  MSMD_LAUNCH(tile_weight_kernel, dim3(n_tiles), dim3(128), 0, st, nbr, kvol, ld, n_rows,
-              rows_per_tile, prefix);
+  MSMD_LAUNCH(tile_weight_kernel, dim3(n_tiles), dim3(rows_per_tile), 0, st, nbr, kvol, ld, n_rows,
+              rows_per_tile, sk_c1(), prefix);
   MSMD_LAUNCH(tile_prefix_kernel, dim3(1), dim3(1024), 0, st, prefix, n_tiles);
   return launch_status();
 }

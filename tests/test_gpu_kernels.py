@@ -512,8 +512,9 @@ def test_split_conv_under_cu_contention(dev):
 
 
 def test_tile_prefix(dev):
-    """msmd_rulebook_tile_prefix == prefix sums of max(|union of the rows' offset masks|, 1)
-    per 128-row tile (numpy), including a partial last tile and an all-empty tile."""
+    """msmd_rulebook_tile_prefix == prefix sums of the tiles' stream-K cost (per active
+    offset 12 + the number of 32-row groups it keeps busy; at least 1 per tile), including a
+    partial last tile and an all-empty tile."""
     from msmdfusion_amd import kernels as K
     shape = [11, 64, 64]
     idx = S.random_voxel_indices(1500, 2, shape, seed=8)
@@ -527,8 +528,10 @@ def test_tile_prefix(dev):
         got = K.tile_prefix(tab, rows).cpu().numpy()
         w = []
         for t0 in range(0, n, rows):
-            m = (tn[:, t0:t0 + rows] >= 0).any(1).sum()
-            w.append(max(int(m), 1))
+            pos = np.minimum(np.arange(t0, t0 + rows), n - 1)       # past the end: the last row
+            act = (tn[:, pos] >= 0).reshape(tn.shape[0], rows // 32, 32).any(2)   # [K, groups]
+            groups = act.sum(1)
+            w.append(max(int((12 + groups[groups > 0]).sum()), 1))    # kSkC1Default = 12
         assert np.array_equal(got, np.concatenate([[0], np.cumsum(w)]))
         if rows == 128:
             assert w[2] == 1
