@@ -127,10 +127,15 @@ class SparseFusionPath(nn.Module):
                                          self.spatial_shapes[i], B, i, prev, need_grad)
         counts = torch.stack([p["counts"] for p in plans]).tolist()
         main = torch.cuda.current_stream()
-        side = self._side_stream(feats.device) if nn_side_stream else main
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            for i in range(4):
+        # one side stream PER STAGE: a stage's chain is FPS (2047 serial rounds, one
+        # workgroup per sample: 2 of 256 CUs busy for 6 ms at stage 0, 3 ms at stage 1) ->
+        # nearest voxel -> ball query -> assignment, and the four chains are independent.
+        # On one stream they took 11.7 ms back to back -- longer than the feature pass
+        # they hide under, i.e. the LC step time; side by side the longest one (7.5 ms) counts.
+        for i in range(4):
+            side = self._side_stream(feats.device, i) if nn_side_stream else main
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
                 mm.plan_stage_nn(plans[i], counts[i], B, self.fps_num_list[i],
                                  self.radius_list[i], self.max_cluster_samples_list[i],
                                  self.dist_thresh_list[i])
@@ -161,11 +166,11 @@ class SparseFusionPath(nn.Module):
         n, c, d, h, w = mm_dense.shape
         return x, mm_dense.view(n, c * d, h, w)
 
-    def _side_stream(self, device):
-        st = getattr(self, "_side", None)
-        if st is None or st.device != device:
+    def _side_stream(self, device, stage=0):
+        pool = getattr(self, "_side", None)
+        if pool is None or pool[0].device != device:
             # high priority: the FPS workgroups are 1024 threads x 128 registers -- a whole
             # CU each -- and must win the CU when one drains between the main stream's
             # chip-filling persistent kernels, or the search starts late
-            st = self._side = torch.cuda.Stream(device=device, priority=-1)
-        return st
+            pool = self._side = [torch.cuda.Stream(device=device, priority=-1) for _ in range(4)]
+        return pool[stage]

@@ -110,7 +110,8 @@ class SparseMultiModalEncoderPaint(nn.Module):
         """:208-225 -- a sample with no row gets one all-zero voxel at the
         origin so every per-sample mask downstream is non-empty."""
         if indices.shape[0]:
-            present = torch.bincount(indices[:, 0].long(), minlength=batch_size) > 0
+            ids = torch.arange(batch_size, device=indices.device, dtype=indices.dtype)
+            present = (indices[:, :1] == ids).any(0)     # (bincount would sync for its size)
         else:
             present = torch.zeros(batch_size, dtype=torch.bool, device=indices.device)
         missing = (~present).nonzero().flatten()
@@ -124,8 +125,9 @@ class SparseMultiModalEncoderPaint(nn.Module):
     @staticmethod
     def sample_counts(only_2d_bzyx, voxel_3d_bzyx, batch_size):
         """[2, B] device tensor: rows per sample of both voxel sets."""
-        return torch.stack([torch.bincount(only_2d_bzyx[:, 0].long(), minlength=batch_size),
-                            torch.bincount(voxel_3d_bzyx[:, 0].long(), minlength=batch_size)])
+        ids = torch.arange(batch_size, device=voxel_3d_bzyx.device, dtype=voxel_3d_bzyx.dtype)
+        # (two compare-and-sum passes: torch.bincount synchronises to size its output)
+        return torch.stack([(only_2d_bzyx[:, :1] == ids).sum(0), (voxel_3d_bzyx[:, :1] == ids).sum(0)])
 
     def nearest_3d_of_only_2d(self, only_2d_bzyx, voxel_3d_bzyx, batch_size, fps_num, radius,
                               max_cluster_samples, dist_thresh, counts=None):

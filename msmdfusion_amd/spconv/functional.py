@@ -138,6 +138,42 @@ class _SideLaunch:
         return self.value
 
 
+_FROZEN_PACKS = {}
+
+
+def _pack_split_cached(weight, np_, krsc):
+    """pack_weight_split of a weight that does not train (the LC recipe freezes the LiDAR
+    encoder, tools/train.py:185-219): packed once per (tensor, version), not once per
+    step -- 21 launches and their host time per step on the LC path."""
+    key = (weight.data_ptr(), weight._version, np_, krsc, tuple(weight.shape))
+    hit = _FROZEN_PACKS.get(id(weight))
+    if hit is None or hit[0] != key:
+        hit = _FROZEN_PACKS[id(weight)] = (key, K.pack_weight_split(weight, np_, krsc=krsc))
+        if len(_FROZEN_PACKS) > 512:
+            _FROZEN_PACKS.pop(next(iter(_FROZEN_PACKS)))
+    return hit[1]
+
+
+def _conv_forward(features, weight, rb, krsc, want_dgrad):
+    """-> (out, packed W^T for dgrad | None)."""
+    c_in, c_out = (weight.shape[-1], weight.shape[0]) if krsc else weight.shape[1:]
+    if _use_split(c_in, c_out, rb.nbr_fwd.shape[0], features.shape[0]):
+        np_ = conv_planes()
+        packed_t = None
+        if want_dgrad and _use_split(c_out, c_in, rb.nbr_fwd.shape[0], rb.n_out):
+            # dgrad will want W^T packed: both images in this launch
+            packed, packed_t = K.pack_weight_split_pair(weight, np_, krsc=krsc)
+        elif not weight.requires_grad:
+            packed = _pack_split_cached(weight, np_, krsc)
+        else:
+            packed = K.pack_weight_split(weight, np_, krsc=krsc)
+        table, order = rb.tiling_fwd()
+        return K.conv_forward_split(features, packed, table, rb.n_out, c_out, np_,
+                                    row_order=order, tile_prefix=rb.prefix_fwd(c_out)), packed_t
+    return _conv_f32(features, weight, krsc, False, rb.nbr_fwd, rb.n_out,
+                     row_order=rb.order_fwd() if _wants_order(c_in, c_out) else None), None
+
+
 class _SparseConvFunction(Function):
     """indice_conv / indice_subm_conv / implicit_gemm in one: forward and dgrad
     are the same implicit-GEMM kernel, wgrad contracts over the pair lists."""
@@ -146,20 +182,8 @@ class _SparseConvFunction(Function):
     def forward(ctx, features, weight, rb, krsc):
         ctx.rb, ctx.krsc = rb, krsc
         ctx.save_for_backward(features, weight)
-        c_in, c_out = (weight.shape[-1], weight.shape[0]) if krsc else weight.shape[1:]
-        ctx.packed_t = None
-        if _use_split(c_in, c_out, rb.nbr_fwd.shape[0], features.shape[0]):
-            np_ = conv_planes()
-            if ctx.needs_input_grad[0] and _use_split(c_out, c_in, rb.nbr_fwd.shape[0], rb.n_out):
-                # dgrad will want W^T packed: both images in this launch
-                packed, ctx.packed_t = K.pack_weight_split_pair(weight, np_, krsc=krsc)
-            else:
-                packed = K.pack_weight_split(weight, np_, krsc=krsc)
-            table, order = rb.tiling_fwd()
-            return K.conv_forward_split(features, packed, table, rb.n_out, c_out, np_,
-                                        row_order=order, tile_prefix=rb.prefix_fwd(c_out))
-        return _conv_f32(features, weight, krsc, False, rb.nbr_fwd, rb.n_out,
-                         row_order=rb.order_fwd() if _wants_order(c_in, c_out) else None)
+        out, ctx.packed_t = _conv_forward(features, weight, rb, krsc, ctx.needs_input_grad[0])
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -210,6 +234,8 @@ class _SparseConvFunction(Function):
 def sparse_conv(features, weight, rb, krsc=False):
     """weight: [K,Cin,Cout], or the KRSC module parameter with krsc=True (read
     and differentiated in place -- no permute/contiguous copies per step)."""
+    if not (torch.is_grad_enabled() and (features.requires_grad or weight.requires_grad)):
+        return _conv_forward(features, weight, rb, krsc, False)[0]   # nothing to record
     return _SparseConvFunction.apply(features, weight, rb, krsc)
 
 
@@ -258,6 +284,10 @@ def bn_act(x, bn, relu=False, residual=None):
     rv = bn.running_var if pass_running else None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
+    if not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad
+                                         or (residual is not None and residual.requires_grad))):
+        return K.bn_act_forward(x, residual, bn.weight, bn.bias, rm, rv, use_batch_stats,
+                                bn.momentum, bn.eps, relu)[0]
     return _BNActFunction.apply(x, residual, bn.weight, bn.bias, rm, rv, use_batch_stats,
                                 bn.momentum, bn.eps, relu)
 
