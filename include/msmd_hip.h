@@ -380,6 +380,74 @@ int msmd_dense_gather_f32(const float* dense /* [B,C,D,H,W] */,
                           msmd_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
+ * a12 -> f1  channels-last BEV hand-over
+ * replaces: stage_outs[-1].dense(); .view(N, C*D, H, W); torch.cat([x, x_mm], 1)
+ *           mmdet3d/models/detectors/MSMDFusion.py:436-440 (and
+ *           mmdet3d/models/middle_encoders/sparse_encoder.py:187-190 for x)
+ * bev is ONE [B,H,W,total_channels] buffer (the NHWC image of the reference's
+ * [B, total_channels, H, W] tensor) the caller has zero-filled; a tensor with c
+ * channels and depth D fills channels [channel_offset, channel_offset + c*D),
+ * channel index c_i*D + z as .view(N, C*D, H, W) orders them.  gather = backward.
+ * ------------------------------------------------------------------------ */
+int msmd_bev_scatter_nhwc_f32(const float* feat /* [n,c] */,
+                              const int32_t* indices /* [n,4] b,z,y,x */,
+                              int n, int c, int batch_size,
+                              const int* spatial_shape /* D,H,W */, float* bev,
+                              int total_channels, int channel_offset,
+                              msmd_stream_t stream);
+int msmd_bev_gather_nhwc_f32(const float* bev, const int32_t* indices, int n,
+                             int c, int batch_size, const int* spatial_shape,
+                             float* feat /* [n,c] */, int total_channels,
+                             int channel_offset, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * a13 (image half)  MSMDFusionDetector.get_foreground2D, gather part
+ * replaces: the per-(sample, camera) loop -- (fg_pxl * downscale).long(),
+ *           img_feat.permute(1,2,0)[coord_h, coord_w], the torch.cat calls
+ *           mmdet3d/models/detectors/MSMDFusion.py:195-224
+ * All cameras of all samples in one call.  img_feat is [planes, c, h, w] with
+ * arbitrary element strides (strides[4] = plane, channel, row, column), planes =
+ * B * cameras.  pixels is [n,3] (x, y, depth) in float32 or float64, the numpy
+ * dtype the loader produced: the product with `downscale` is taken in that
+ * dtype and truncated toward zero like .long().  Negative cells wrap like
+ * torch indexing; cells outside [-size, size) are COUNTED in *n_bad (the
+ * reference raises IndexError there; the Python mirror raises on n_bad != 0)
+ * and read as zeros.
+ *   fg_pcd   [n, pts_dim + c]  = [pts | feat]
+ *   score_in [n, c + 17]       = [feat | depth | lidar2img[plane] (16)]
+ *   cells    [n] (optional)    = linear (plane, h, w) cell per point, -1 = bad;
+ *                                input of msmd_fg_scatter_add_f32 (the backward)
+ * ------------------------------------------------------------------------ */
+int msmd_fg_gather_f32(const float* img_feat, const int64_t* strides,
+                       int planes, int c, int h, int w, const void* pixels,
+                       int pixel_is_f64, const int32_t* plane /* [n] */,
+                       double downscale, const float* pts /* [n,pts_dim] */,
+                       int pts_dim, const float* lidar2img /* [planes,16] */,
+                       int n, float* fg_pcd, float* score_in, int32_t* cells,
+                       int32_t* n_bad, msmd_stream_t stream);
+/* grad_img[plane, :, h, w] += grad[i, col0 : col0 + c]   (atomic fp32 adds: the
+ * order, hence the last bit, is not fixed -- as index_put(accumulate) on a GPU) */
+int msmd_fg_scatter_add_f32(const float* grad, int grad_stride, int col0,
+                            const int32_t* cells, int n, int planes, int c,
+                            int h, int w, const int64_t* strides,
+                            float* grad_img, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * f2  depth_aware_channel_compression, sparse depth canvas
+ * replaces: canvas[i,j].index_put_((y, x), depth) for B x 6 cameras
+ *           mmdet3d/models/detectors/MSMDFusion.py:336-356
+ * canvas is [planes, h, w], fully written.  Where several pixels land on one
+ * cell the row with the highest index wins (what a sequential index_put_
+ * leaves; the reference's CUDA index_put_ is unordered there).
+ * ------------------------------------------------------------------------ */
+size_t msmd_depth_canvas_workspace_bytes(int planes, int h, int w);
+int msmd_depth_canvas_f32(const void* pixels /* [n,3] x,y,depth */,
+                          int pixel_is_f64, const int32_t* plane, int n,
+                          int planes, int h, int w, float* canvas,
+                          int32_t* n_bad, void* workspace,
+                          size_t workspace_bytes, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
  * a17  spconv.pytorch.functional.sparse_add(a, b)
  * call site: mmdet3d/models/middle_encoders/sparse_multimodal_encoder_painting.py:455
  * Union of two coordinate sets on one grid, rows in ascending linear id,

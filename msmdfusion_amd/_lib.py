@@ -79,6 +79,13 @@ SIGNATURES = {
     "msmd_bn_act_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "msmd_dense_scatter_f32": (_i, [_vp, _vp, _i, _i, _i, _ip, _vp, _vp]),
     "msmd_dense_gather_f32": (_i, [_vp, _vp, _i, _i, _i, _ip, _vp, _vp]),
+    "msmd_bev_scatter_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _ip, _vp, _i, _i, _vp]),
+    "msmd_bev_gather_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _ip, _vp, _i, _i, _vp]),
+    "msmd_fg_gather_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, C.c_double, _vp, _i, _vp, _i,
+                                _vp, _vp, _vp, _vp, _vp]),
+    "msmd_fg_scatter_add_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "msmd_depth_canvas_workspace_bytes": (_sz, [_i, _i, _i]),
+    "msmd_depth_canvas_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "msmd_sparse_add_workspace_bytes": (_sz, [_i, _ip]),
     "msmd_sparse_add_count": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _sz, _vp]),
     "msmd_sparse_add_fill": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _ip, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -3,8 +3,8 @@
 Reference: configs/MSMDFusion_nusc_voxel_LC.py:141-190 and
 configs/transfusion_nusc_voxel_L.py:150-169 (values are facts; equality with the
 reference dicts is pinned by tests/golden/reference_configs.json).  Only the
-keys this path consumes are kept: the image branch, dense BEV backbone/neck and
-the detection head are out of scope.
+keys this path consumes are kept (plus the dense BEV backbone/neck of row f1);
+the image backbone and the detection head are not built here.
 
     from msmdfusion_amd.configs import MSMDFUSION_LC, build_hot_path
     vox, vfe, enc, mm = build_hot_path(MSMDFUSION_LC)
@@ -22,9 +22,18 @@ _PTS_MIDDLE_ENCODER = dict(
     encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
     block_type="basicblock")
 
+_BN2D = dict(type="BN", eps=0.001, momentum=0.01)
+_PTS_BACKBONE = dict(type="SECOND", in_channels=256, out_channels=[128, 256], layer_nums=[5, 5],
+                     layer_strides=[1, 2], norm_cfg=_BN2D,
+                     conv_cfg=dict(type="Conv2d", bias=False))
+_PTS_NECK = dict(type="SECONDFPN", in_channels=[128, 256], out_channels=[256, 256],
+                 upsample_strides=[1, 2], norm_cfg=_BN2D,
+                 upsample_cfg=dict(type="deconv", bias=False), use_conv_for_no_stride=True)
+
 TRANSFUSION_L = dict(
     model=dict(type="TransFusionDetector", pts_voxel_layer=_PTS_VOXEL_LAYER,
-               pts_voxel_encoder=_PTS_VOXEL_ENCODER, pts_middle_encoder=_PTS_MIDDLE_ENCODER),
+               pts_voxel_encoder=_PTS_VOXEL_ENCODER, pts_middle_encoder=_PTS_MIDDLE_ENCODER,
+               pts_backbone=_PTS_BACKBONE, pts_neck=_PTS_NECK),
     samples_per_gpu=4, point_cloud_range=POINT_CLOUD_RANGE, voxel_size=VOXEL_SIZE,
     optimizer=dict(type="AdamW", lr=0.0002, weight_decay=0.01),
     freeze_lidar_components=False)
@@ -45,7 +54,8 @@ MSMDFUSION_LC = dict(
             type="SparseMultiModalEncoderPaint", in_channels_3D=(16, 32, 64, 128),
             in_channels_2D=(64, 64, 64, 64), out_channels=(32, 64, 128, 128),
             padding=(1, 1, [0, 1, 1], 0), order=("conv", "norm", "act"),
-            norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01))),
+            norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01)),
+        pts_backbone=_PTS_BACKBONE, pts_neck=_PTS_NECK),
     samples_per_gpu=2, point_cloud_range=POINT_CLOUD_RANGE, voxel_size=VOXEL_SIZE,
     optimizer=dict(type="AdamW", lr=0.0001, betas=(0.9, 0.999), weight_decay=0.05,
                    paramwise_cfg=dict(custom_keys={
@@ -68,3 +78,13 @@ def build_hot_path(cfg):
     mm = build_middle_encoder(m["multimodal_middle_encoder"]) \
         if "multimodal_middle_encoder" in m else None
     return vox, vfe, enc, mm
+
+
+def build_bev_tail(cfg, compute_dtype=None):
+    """bev_fusion (SPPModule, built without a config: MSMDFusion.py:130) +
+    pts_backbone + pts_neck of one of the dicts above."""
+    from .bev import BevTail, SPPModule
+    from .registry import build_backbone, build_neck
+    m = cfg["model"]
+    return BevTail(SPPModule(), build_backbone(m["pts_backbone"]), build_neck(m["pts_neck"]),
+                   compute_dtype=compute_dtype)

@@ -2,7 +2,8 @@
 MSMDFusionDetector.voxelize (MSMDFusion.py:462-491), fetch_2D_voxels' voxel half
 (:371-393), voxel_modality_split (:251-325), extract_pts_feat's sparse part
 (:421-443).  The image branch, score_net and the dense BEV tail are outside the
-hot path; virtual points arrive here as ready [N,64] tensors.
+hot path proper; virtual points arrive here as ready [N,64] tensors
+(image_glue.get_foreground2D builds them; bev.BevTail consumes the result).
 """
 import torch
 from torch import nn
@@ -146,22 +147,27 @@ class SparseFusionPath(nn.Module):
         return dict(feats=feats, coors=coors, planned=planned, stages=stages, v2=v2,
                     idx3_5=idx3_5, s3=s3, s2=s2, plans=plans)
 
-    def forward(self, points, virtual_points_per_stage, prepared=None):
+    def forward(self, points, virtual_points_per_stage, prepared=None, joint_bev=False):
         """points: list of B [N,5] clouds; virtual_points_per_stage: 4 lists of
         B [Nv,64] tensors (what get_foreground2D yields per image scale).
 
         Order of work (results are those of MSMDFusion.py:421-443; only the
         schedule differs): the index-only part (prepare) first, then the two
-        feature passes.  `prepared` = a prepare() result computed ahead of time."""
+        feature passes.  `prepared` = a prepare() result computed ahead of time.
+        joint_bev=True returns cat([x, x_mm], 1) -- bev_fusion's input -- as one
+        channels-last [B,640,H,W] map both sparse tensors scatter into."""
         B = len(points)
         enc, mm = self.pts_middle_encoder, self.multimodal_middle_encoder
         p = prepared if prepared is not None else self.prepare(points, virtual_points_per_stage)
-        x, encode_features = enc(p["feats"], p["coors"], B, planned=p["planned"])
+        x, encode_features = enc(p["feats"], p["coors"], B, planned=p["planned"],
+                                 dense_out=not joint_bev)
         v3 = [spconv.SparseConvTensor(encode_features[i].features, p["idx3_5"][i],
                                       p["stages"][i][1], B) for i in range(4)]
         stage_outs = mm(v3, p["v2"], p["s3"], p["s2"], self.fps_num_list, self.radius_list,
                         self.max_cluster_samples_list, self.dist_thresh_list,
                         stage_plans=p["plans"])
+        if joint_bev:
+            return spconv.functional.bev_concat([x, stage_outs[-1]])
         mm_dense = stage_outs[-1].dense()
         n, c, d, h, w = mm_dense.shape
         return x, mm_dense.view(n, c * d, h, w)

@@ -599,6 +599,104 @@ def dense_gather(dense, indices, spatial_shape):
     return feat
 
 
+def bev_scatter_nhwc(feat, indices, batch_size, spatial_shape, bev, channel_offset):
+    """feat rows -> channels [channel_offset, +c*D) of the zero-filled NHWC buffer
+    bev [B,H,W,Ctot] (in place)."""
+    _need_bzyx(indices)
+    _need_cuda(feat, indices, bev)
+    f = feat.contiguous().float()
+    n, c = f.shape
+    d, h, w = [int(x) for x in spatial_shape]
+    if bev.dtype != torch.float32 or not bev.is_contiguous() or \
+            tuple(bev.shape[:3]) != (int(batch_size), h, w):
+        raise ValueError("bev must be a contiguous float32 [B,H,W,Ctot] buffer, got %s"
+                         % (tuple(bev.shape),))
+    check(lib.msmd_bev_scatter_nhwc_f32(_p(f), _p(indices.contiguous().int()), n, c,
+                                        int(batch_size), int3(spatial_shape), _p(bev),
+                                        int(bev.shape[3]), int(channel_offset), _stream()),
+          "msmd_bev_scatter_nhwc_f32")
+    return bev
+
+
+def bev_gather_nhwc(bev, indices, c, batch_size, spatial_shape, channel_offset):
+    _need_bzyx(indices)
+    _need_cuda(bev, indices)
+    if bev.dtype != torch.float32 or not bev.is_contiguous() or bev.dim() != 4:
+        raise ValueError("bev must be a contiguous float32 [B,H,W,Ctot] buffer")
+    n = indices.shape[0]
+    feat = torch.empty((n, int(c)), dtype=torch.float32, device=bev.device)
+    check(lib.msmd_bev_gather_nhwc_f32(_p(bev), _p(indices.contiguous().int()), n, int(c),
+                                       int(batch_size), int3(spatial_shape), _p(feat),
+                                       int(bev.shape[3]), int(channel_offset), _stream()),
+          "msmd_bev_gather_nhwc_f32")
+    return feat
+
+
+# ------------------------------------------------------------ image-side glue
+def _strides4(t):
+    return (C.c_int64 * 4)(*[int(s) for s in t.stride()])
+
+
+def _pixels(pixels):
+    if pixels.dim() != 2 or pixels.shape[1] != 3 or \
+            pixels.dtype not in (torch.float32, torch.float64):
+        raise ValueError("pixels must be [n,3] float32/float64 (x, y, depth)")
+    return pixels.contiguous(), int(pixels.dtype == torch.float64)
+
+
+def fg_gather(img_feat, pixels, plane, downscale, pts, lidar2img, want_cells=True):
+    """-> (fg_pcd [n, pts_dim+C], score_in [n, C+17], cells [n] | None, n_bad [1])"""
+    _need_cuda(img_feat, pixels, plane, pts, lidar2img)
+    if img_feat.dim() != 4 or img_feat.dtype != torch.float32:
+        raise ValueError("img_feat must be float32 [planes, C, H, W]")
+    px, is64 = _pixels(pixels)
+    n = px.shape[0]
+    planes, c, h, w = img_feat.shape
+    pts = pts.contiguous().float()
+    if pts.shape[0] != n or plane.shape[0] != n:
+        raise ValueError("pixels / points / plane ids disagree on the number of points")
+    l2i = lidar2img.contiguous().float().view(-1, 16)
+    if l2i.shape[0] != planes:
+        raise ValueError("need one 4x4 lidar2img per (sample, camera) plane")
+    dev = img_feat.device
+    fg = torch.empty((n, pts.shape[1] + c), dtype=torch.float32, device=dev)
+    sc = torch.empty((n, c + 17), dtype=torch.float32, device=dev)
+    cells = torch.empty((n,), dtype=torch.int32, device=dev) if want_cells else None
+    bad = torch.empty((1,), dtype=torch.int32, device=dev)
+    check(lib.msmd_fg_gather_f32(_p(img_feat), _strides4(img_feat), planes, c, h, w, _p(px), is64,
+                                 _p(plane.contiguous().int()), float(downscale), _p(pts),
+                                 int(pts.shape[1]), _p(l2i), n, _p(fg), _p(sc), _p(cells), _p(bad),
+                                 _stream()), "msmd_fg_gather_f32")
+    return fg, sc, cells, bad
+
+
+def fg_scatter_add(grad, col0, c, cells, like):
+    """Backward of fg_gather w.r.t. the feature map: zeros_like(like) + scatter."""
+    _need_cuda(grad, cells, like)
+    g = grad.contiguous().float()
+    out = torch.zeros_like(like)
+    planes, cc, h, w = like.shape
+    check(lib.msmd_fg_scatter_add_f32(_p(g), int(g.shape[1]), int(col0), _p(cells),
+                                      int(g.shape[0]), planes, int(c), h, w, _strides4(out),
+                                      _p(out), _stream()), "msmd_fg_scatter_add_f32")
+    return out
+
+
+def depth_canvas(pixels, plane, planes, h, w):
+    """-> (canvas [planes,h,w] float32, n_bad [1])"""
+    _need_cuda(pixels, plane)
+    px, is64 = _pixels(pixels)
+    dev = px.device
+    canvas = torch.empty((int(planes), int(h), int(w)), dtype=torch.float32, device=dev)
+    bad = torch.empty((1,), dtype=torch.int32, device=dev)
+    nbytes = lib.msmd_depth_canvas_workspace_bytes(int(planes), int(h), int(w))
+    ws = _ws(nbytes, dev)
+    check(lib.msmd_depth_canvas_f32(_p(px), is64, _p(plane.contiguous().int()), int(px.shape[0]),
+                                    int(planes), int(h), int(w), _p(canvas), _p(bad), _p(ws),
+                                    nbytes, _stream()), "msmd_depth_canvas_f32")
+    return canvas, bad
+
+
 def sparse_add(feat_a, idx_a, feat_b, idx_b, batch_size, spatial_shape):
     """-> (out_indices, out_feat, map_a, map_b)"""
     _need_bzyx(idx_a, idx_b)

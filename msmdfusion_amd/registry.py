@@ -53,6 +53,8 @@ CONV_LAYERS = Registry("conv layer")
 NORM_LAYERS = Registry("norm layer")
 MIDDLE_ENCODERS = Registry("middle_encoder")
 VOXEL_ENCODERS = Registry("voxel_encoder")
+BACKBONES = Registry("backbone")
+NECKS = Registry("neck")
 
 CONV_LAYERS.register_module("Conv1d", module=nn.Conv1d)
 CONV_LAYERS.register_module("Conv2d", module=nn.Conv2d)
@@ -89,7 +91,7 @@ def build_norm_layer(cfg, num_features, postfix=""):
 def _register_hot_path():
     """Import the modules whose decorators fill the registries (mmdet3d does
     this from its package __init__)."""
-    from . import multimodal_encoder, sparse_encoder, voxel_encoder  # noqa: F401
+    from . import bev, multimodal_encoder, sparse_encoder, voxel_encoder  # noqa: F401
     from .spconv import conv  # noqa: F401
 
 
@@ -101,3 +103,15 @@ def build_middle_encoder(cfg):
 def build_voxel_encoder(cfg):
     _register_hot_path()
     return VOXEL_ENCODERS.build(cfg)
+
+
+def build_backbone(cfg):
+    """mmdet3d.models.builder.build_backbone for the BEV tail (SECOND)."""
+    _register_hot_path()
+    return BACKBONES.build(cfg)
+
+
+def build_neck(cfg):
+    """mmdet3d.models.builder.build_neck for the BEV tail (SECONDFPN)."""
+    _register_hot_path()
+    return NECKS.build(cfg)

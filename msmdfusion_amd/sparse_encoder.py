@@ -74,8 +74,10 @@ class SparseEncoder(nn.Module):
         t.plan(convs(self.conv_out), need_grad)
         return planned, stages
 
-    def forward(self, voxel_features, coors, batch_size, planned=None):
-        """voxel_features [N,C] fp32, coors [N,4] (b,z,y,x) -> (BEV, stage outputs)."""
+    def forward(self, voxel_features, coors, batch_size, planned=None, dense_out=True):
+        """voxel_features [N,C] fp32, coors [N,4] (b,z,y,x) -> (BEV, stage outputs).
+        dense_out=False hands back conv_out's SparseConvTensor instead of the
+        [B, C*D, H, W] map (for spconv.functional.bev_concat)."""
         if planned is None:
             # all 21 rulebooks (4 SubM voxel sets + 4 strided) before any feature work
             planned, _ = self.plan(coors, batch_size)
@@ -86,6 +88,8 @@ class SparseEncoder(nn.Module):
             x = encoder_layer(x)
             encode_features.append(x)
         out = self.conv_out(encode_features[-1])
+        if not dense_out:
+            return out, encode_features
         spatial_features = out.dense()
         n, c, d, h, w = spatial_features.shape
         return spatial_features.view(n, c * d, h, w), encode_features

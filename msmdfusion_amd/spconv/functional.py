@@ -309,6 +309,48 @@ def dense(features, indices, batch_size, spatial_shape):
     return _DenseFunction.apply(features, indices, batch_size, spatial_shape)
 
 
+class _BevConcatFunction(Function):
+    """N sparse tensors -> one channels-last [B,H,W,sum(C_i*D_i)] buffer."""
+
+    @staticmethod
+    def forward(ctx, batch_size, metas, *features):
+        # metas: per tensor (indices, spatial_shape)
+        h, w = metas[0][1][1], metas[0][1][2]
+        widths = [f.shape[1] * m[1][0] for f, m in zip(features, metas)]
+        bev = torch.zeros((int(batch_size), h, w, sum(widths)), dtype=torch.float32,
+                          device=features[0].device)
+        off = 0
+        for f, (idx, shape), width in zip(features, metas, widths):
+            if shape[1] != h or shape[2] != w:
+                raise ValueError("bev_concat: BEV sizes differ: %s vs %s" % (shape, metas[0][1]))
+            K.bev_scatter_nhwc(f, idx, batch_size, shape, bev, off)
+            off += width
+        ctx.metas, ctx.batch_size = metas, int(batch_size)
+        ctx.channels = [f.shape[1] for f in features]
+        return bev.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad):
+        g = grad.permute(0, 2, 3, 1).contiguous().float()
+        out, off = [], 0
+        for i, ((idx, shape), c) in enumerate(zip(ctx.metas, ctx.channels)):
+            out.append(K.bev_gather_nhwc(g, idx, c, ctx.batch_size, shape, off)
+                       if ctx.needs_input_grad[2 + i] else None)
+            off += c * shape[0]
+        return (None, None, *out)
+
+
+def bev_concat(tensors):
+    """torch.cat([t.dense().view(N, C*D, H, W) for t in tensors], 1)
+    (MSMDFusion.py:436-440 with sparse_encoder.py:187-190) without the dense
+    intermediates: returns the [B, sum(C*D), H, W] map as a channels-last view."""
+    metas = []
+    for t in tensors:
+        assert t.indices.shape[1] == 4, "bev_concat needs (b,z,y,x) indices"
+        metas.append((t.indices, [int(v) for v in t.spatial_shape]))
+    return _BevConcatFunction.apply(tensors[0].batch_size, metas, *[t.features for t in tensors])
+
+
 class _SparseAddFunction(Function):
     @staticmethod
     def forward(ctx, fa, ia, fb, ib, batch_size, spatial_shape):

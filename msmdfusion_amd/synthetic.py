@@ -81,3 +81,27 @@ def random_voxel_indices(n, batch_size, spatial_shape, seed=0, clustered=True):
     _, first = np.unique(rows, axis=0, return_index=True)
     rows = rows[np.sort(first)][:n]
     return np.ascontiguousarray(rows, dtype=np.int32)
+
+
+def seeded_parameters(module, seed=0):
+    """Overwrite every parameter of a torch module with values that depend only
+    on (seed, parameter NAME, shape) -- numpy's frozen RandomState, not torch's
+    generator -- so two implementations with the same state-dict keys (the
+    reference's SPPModule and ours) get identical weights without shipping them.
+    Conv / linear weights ~ N(0, 1/fan_in); norm weights in [0.5, 1.5]; biases
+    in [-0.2, 0.5]."""
+    import zlib
+
+    import torch
+    with torch.no_grad():
+        for name, p in sorted(module.named_parameters()):
+            rng = np.random.RandomState((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31))
+            if p.dim() > 1:
+                fan_in = int(np.prod(p.shape[1:]))
+                v = rng.standard_normal(tuple(p.shape)) / math.sqrt(fan_in)
+            elif name.endswith("weight"):
+                v = 0.5 + rng.rand(*p.shape)
+            else:
+                v = -0.2 + 0.7 * rng.rand(*p.shape)
+            p.copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)))
+    return module

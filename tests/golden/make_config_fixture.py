@@ -12,7 +12,7 @@ import os
 REF = "/root/reference/configs"
 HOT_KEYS = ["type", "spatial_shapes", "downscale_factors", "fps_num_list", "radius_list",
             "max_cluster_samples_list", "dist_thresh_list", "pts_voxel_layer", "pts_voxel_encoder",
-            "pts_middle_encoder", "multimodal_middle_encoder"]
+            "pts_middle_encoder", "multimodal_middle_encoder", "pts_backbone", "pts_neck"]
 
 
 def load(name):
