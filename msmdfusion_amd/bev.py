@@ -5,17 +5,19 @@ attribute names, so its checkpoints load key for key
 (`bev_fusion.conv3x3.0.weight`, `pts_backbone.blocks.1.3.weight`,
 `pts_neck.deblocks.1.0.weight`, ...).
 
-These are plain dense 2-D convolutions over a 180x180 map -- library work
-(MIOpen), not something to hand-write.  What is done for MI355X here is the
-data movement around them:
+These are plain dense 2-D convolutions over a 180x180 map -- MIOpen's work in
+this round (25 convolutions, 0.87 TFLOP forward at B=2).  Measured on MI355X,
+B=2, forward+backward (tools/bev_tail_bench.py, profiles/r02_bev_tail.txt):
 
-  * the sparse side hands over ONE channels-last buffer [B,H,W,640] that both
-    sparse tensors scatter into (kernels.bev_scatter_nhwc): no dense() permute,
-    no view, no torch.cat -- and MIOpen's NHWC kernels read it as it lies;
-  * every module keeps channels_last end to end (`to_channels_last`), so no
-    layout change is inserted between the 25 convolutions;
-  * `BevTail(compute_dtype=torch.bfloat16)` runs the stack under autocast (the
-    reference wraps the neck in @auto_fp16 for the same reason); default fp32.
+    fp32  NCHW 30.1 ms   NHWC 34.7 ms      bf16 autocast  NCHW 13.3 ms   NHWC 13.4 ms
+
+so the default is NCHW fp32 (the reference's arithmetic); channels-last does not
+pay with this MIOpen build and is an option, not the default.  With
+channels_last=True the sparse side can hand over ONE [B,H,W,640] buffer that
+both sparse tensors scatter into (spconv.functional.bev_concat: 0.05 ms against
+0.24 ms for dense() + view + cat, 0.49 ms with the layout change).  13 ms at bf16
+is 8 % of the dense MFMA peak: a hand-written implicit-GEMM 3x3 kernel for the
+640->256 SPP branches is the obvious next step for this row.
 """
 import torch
 from torch import nn
@@ -141,7 +143,7 @@ class BevTail(nn.Module):
     (MSMDFusion.py:440-447).  Attribute names are the detector's."""
 
     def __init__(self, bev_fusion=None, pts_backbone=None, pts_neck=None, compute_dtype=None,
-                 channels_last=True):
+                 channels_last=False):
         super().__init__()
         self.bev_fusion = bev_fusion if bev_fusion is not None else SPPModule()
         self.pts_backbone = pts_backbone if pts_backbone is not None else SECOND(

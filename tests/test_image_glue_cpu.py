@@ -153,7 +153,8 @@ def test_bev_tail_forward_backward_equals_plain_torch():
     torch.manual_seed(0)
     tail = BevTail(SPPModule(in_channels=24, channels=16),
                    SECOND(16, [8, 16], [1, 2], [1, 2]),
-                   SECONDFPN([8, 16], [12, 12], [1, 2], use_conv_for_no_stride=True)).train()
+                   SECONDFPN([8, 16], [12, 12], [1, 2], use_conv_for_no_stride=True),
+                   channels_last=True).train()
     x = torch.randn(2, 10, 12, 12)
     xm = torch.randn(2, 14, 12, 12)
     xa, xb = x.clone().requires_grad_(True), xm.clone().requires_grad_(True)
