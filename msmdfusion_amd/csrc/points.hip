@@ -11,6 +11,10 @@
 #include "common.hpp"
 
 #include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
 
 namespace msmd {
 namespace {
@@ -194,6 +198,202 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
   }
 }
 
+// ---- exact pruned FPS ---------------------------------------------------------
+// The plain kernel above is VALU-bound on ONE CU: every round touches every point
+// (24 points x ~10 VALU per lane, 16 waves on 4 SIMDs = ~4800 clk = 2.9 us), and
+// the 2047 rounds are serial.  Most of that work changes nothing: after the first
+// few hundred samples a new sample only lowers the running distance of points
+// NEAR it.  Here the element's points are cut into buckets of 256 consecutive
+// points (64 lanes x 4 register slots of one wave); per bucket the owning wave
+// keeps, in the registers of lane g, the bucket's bounding box, its current
+// (max running distance, tie rank) and the coordinates of that point.  A round
+// updates bucket g only if  bound(sample, box_g) < maxdist_g , where bound is the
+// box distance evaluated with the SAME fp32 operation sequence as the point
+// distance: rounding is monotone, so bound <= d(sample, q) for every q in the
+// box, hence min(d, running) == running for all of them and skipping is exact
+// -- the selected indices are bit-identical to the unpruned kernel's (and the
+// reference's: same distances, same tie order).  Skipped buckets contribute
+// their cached (maxdist, rank).  One barrier per round: every wave publishes its
+// best point's coordinates with its candidate, so the winner's coordinates are
+// read back from LDS instead of being fetched by its owner in a second phase.
+// Buckets are index ranges: the pruning is as good as the input order is
+// spatially coherent (voxels in first-touch order of object-by-object virtual
+// points are); on a shuffled cloud every bucket spans the scene and the kernel
+// degrades to the plain one plus ~10 % bookkeeping.
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+constexpr int kFpsPrunedThreads = 512;
+constexpr int kFpsSlotsPerBucket = 4;
+
+template <int P>
+__global__ __launch_bounds__(kFpsPrunedThreads) void fps_pruned_kernel(
+    const float* __restrict__ xyz_all, const int* __restrict__ offsets, int n_fixed, int m,
+    int32_t* __restrict__ idx_all) {
+  constexpr int SB = kFpsSlotsPerBucket, G = P / SB, NW = kFpsPrunedThreads / 64;
+  static_assert(P % SB == 0 && G <= 16, "bucket state lives in lanes 0..15");
+  __shared__ float red_d[2][NW];
+  __shared__ uint32_t red_t[2][NW];
+  __shared__ float red_p[2][NW][3];
+  if (m <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: ranks split below
+  const long base = offsets ? offsets[blockIdx.x] : (long)blockIdx.x * n_fixed;
+  const int n = offsets ? offsets[blockIdx.x + 1] - offsets[blockIdx.x] : n_fixed;
+  const float* xyz = xyz_all + base * 3;
+  int32_t* idx = idx_all + (size_t)blockIdx.x * m;
+  if (n <= 0) {
+    for (int j = tid; j < m; j += kFpsPrunedThreads) idx[j] = 0;
+    return;
+  }
+  const int bs_shift = min(31 - __clz(n), 10);
+  const int bs_ref = 1 << bs_shift;
+  // slot s of this lane holds point k = U_s + lane, U_s = (wave*P + s)*64.
+  // tie rank of k (see fps_kernel) = (bitrev(k mod bs) << 21) | (k div bs); U_s is a
+  // multiple of 64 and lane < 64, so the two never share a bit and the rank splits
+  // into a per-lane constant OR a wave-uniform term (scalar ALU):
+  const int wp = wave * P;
+  const int rsh = 32 - bs_shift;
+  const uint32_t lane_rank =
+      ((bs_shift ? (__brev((uint32_t)lane) >> rsh) : 0u) << 21) |
+      (bs_shift < 6 ? (uint32_t)lane >> bs_shift : 0u);
+  auto rank_of = [&](uint32_t u) -> uint32_t {      // u: a multiple of 64
+    const uint32_t urev = bs_shift ? (__brev(u) >> rsh) : 0u;
+    return (urev << 21) | (u >> bs_shift);
+  };
+  // ... and U_s = U_g + 64*q (bucket g, slot q of SB=4; U_g a multiple of 256) splits
+  // once more: 4 per-lane constants (lane + slot) and one scalar per bucket
+  uint32_t lane_slot_rank[kFpsSlotsPerBucket];
+#pragma unroll
+  for (int q = 0; q < kFpsSlotsPerBucket; ++q) lane_slot_rank[q] = lane_rank | rank_of(64u * q);
+  float px[P], py[P], pz[P], pd[P];
+#pragma unroll
+  for (int s = 0; s < P; ++s) {
+    const int k = (wp + s) * 64 + lane;
+    const bool ok = k < n;
+    px[s] = ok ? xyz[(size_t)k * 3 + 0] : 0.f;
+    py[s] = ok ? xyz[(size_t)k * 3 + 1] : 0.f;
+    pz[s] = ok ? xyz[(size_t)k * 3 + 2] : 0.f;
+    pd[s] = ok ? 1e10f : -1.f;
+  }
+  // state of bucket g, held by lane g (lanes >= G: an empty bucket)
+  float bx0 = 0.f, bx1 = 0.f, by0 = 0.f, by1 = 0.f, bz0 = 0.f, bz1 = 0.f;
+  float mybd = -1.f, cx = 0.f, cy = 0.f, cz = 0.f;
+  uint32_t mybt = 0xFFFFFFFFu;
+  const float kInf = __int_as_float(0x7f800000);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+#pragma unroll
+    for (int q = 0; q < SB; ++q) {
+      const int s = g * SB + q;
+      const bool ok = pd[s] >= 0.f;
+      lo[0] = ok ? fminf(lo[0], px[s]) : lo[0];  hi[0] = ok ? fmaxf(hi[0], px[s]) : hi[0];
+      lo[1] = ok ? fminf(lo[1], py[s]) : lo[1];  hi[1] = ok ? fmaxf(hi[1], py[s]) : hi[1];
+      lo[2] = ok ? fminf(lo[2], pz[s]) : lo[2];  hi[2] = ok ? fmaxf(hi[2], pz[s]) : hi[2];
+    }
+    const float x0 = -fmax_wave(-lo[0]), x1 = fmax_wave(hi[0]);
+    const float y0 = -fmax_wave(-lo[1]), y1 = fmax_wave(hi[1]);
+    const float z0 = -fmax_wave(-lo[2]), z1 = fmax_wave(hi[2]);
+    if (lane == g) {
+      bx0 = x0; bx1 = x1; by0 = y0; by1 = y1; bz0 = z0; bz1 = z1;
+      mybd = x0 <= x1 ? kInf : -1.f;     // not empty: round 1 updates it (bound < inf)
+    }
+  }
+  // update of one bucket against the sample (sx, sy, sz) + refresh of its cached state
+  auto update = [&](auto gc, float sx, float sy, float sz) {
+    constexpr int g = decltype(gc)::value;
+    float ld = -1.f;
+#pragma unroll
+    for (int q = 0; q < SB; ++q) {
+      const int s = g * SB + q;
+      float dx = px[s] - sx, dy = py[s] - sy, dz = pz[s] - sz;
+      float d = dx * dx + dy * dy + dz * dz;
+      float d2 = fminf(d, pd[s]);          // padding: min(d, -1) = -1
+      pd[s] = d2;
+      ld = fmaxf(ld, d2);
+    }
+    const float wd = fmax_wave(ld);
+    uint32_t lt = 0xFFFFFFFFu;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (wd >= 0.f) {
+      uint32_t bucket_rank = rank_of((uint32_t)(wp + g * SB) * 64u);
+      // keep the OR below inside the loop: hoisted, its 48 results would live in VGPRs
+      asm volatile("" : "+s"(bucket_rank));
+#pragma unroll
+      for (int q = 0; q < SB; ++q) {
+        const int s = g * SB + q;
+        const uint32_t r = lane_slot_rank[q] | bucket_rank;
+        const bool better = pd[s] == wd && r < lt;
+        lt = better ? r : lt;
+        qx = better ? px[s] : qx;
+        qy = better ? py[s] : qy;
+        qz = better ? pz[s] : qz;
+      }
+    }
+    const uint32_t wt = umin_wave(lt);
+    const unsigned long long holders = __ballot(lt == wt);
+    const int owner = holders ? __ffsll((long long)holders) - 1 : 0;
+    const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), owner));
+    const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), owner));
+    const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), owner));
+    if (lane == g) {
+      mybd = wd; mybt = wt; cx = ox; cy = oy; cz = oz;
+    }
+  };
+  float sx = xyz[0], sy = xyz[1], sz = xyz[2];
+  if (tid == 0) idx[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    // which of this wave's buckets can the sample still reach?
+    const float ex = fmaxf(fmaxf(bx0 - sx, sx - bx1), 0.f);
+    const float ey = fmaxf(fmaxf(by0 - sy, sy - by1), 0.f);
+    const float ez = fmaxf(fmaxf(bz0 - sz, sz - bz1), 0.f);
+    const float bound = ex * ex + ey * ey + ez * ez;
+    const unsigned long long need = __ballot(lane < G && bound < mybd);
+    static_for<G>([&](auto gc) {
+      if ((need >> decltype(gc)::value) & 1ull) update(gc, sx, sy, sz);
+    });
+    // wave candidate: max distance over its buckets, then the smallest rank holding it
+    const float wd = __int_as_float(
+        __builtin_amdgcn_readfirstlane(__float_as_int(fmax_dpp16(mybd))));
+    const uint32_t ct = (lane < 16 && mybd == wd) ? mybt : 0xFFFFFFFFu;
+    const uint32_t wt = (uint32_t)__builtin_amdgcn_readfirstlane((int)umin_dpp16(ct));
+    const unsigned long long wh = __ballot(lane < 16 && ct == wt);
+    const int gw = wh ? __ffsll((long long)wh) - 1 : 0;
+    const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), gw));
+    const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), gw));
+    const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), gw));
+    const int buf = j & 1;
+    if (lane == 0) {
+      red_d[buf][wave] = wd;
+      red_t[buf][wave] = wt;
+      red_p[buf][wave][0] = wx;
+      red_p[buf][wave][1] = wy;
+      red_p[buf][wave][2] = wz;
+    }
+    __syncthreads();
+    const float cd = red_d[buf][lane & (NW - 1)];
+    const float bd = fmax_dpp16(cd);
+    const uint32_t tc = cd == bd ? red_t[buf][lane & (NW - 1)] : 0xFFFFFFFFu;
+    const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)umin_dpp16(tc));
+    const unsigned long long gh = __ballot(tc == tb);
+    const int ww = (gh ? __ffsll((long long)gh) - 1 : 0) & (NW - 1);
+    sx = red_p[buf][ww][0];
+    sy = red_p[buf][ww][1];
+    sz = red_p[buf][ww][2];
+    if (tid == 0) {
+      const uint32_t tid_ref = bs_shift ? (__brev(tb >> 21) >> (32 - bs_shift)) : 0u;
+      idx[j] = (int)((tb & 0x1FFFFFu) << bs_shift) | (int)tid_ref;
+    }
+  }
+}
+
 // One wave per centre; points visited 64 at a time in index order, hits
 // compacted with a ballot so the first `nsample` hits keep their order
 // (ball_query_cuda.cu:33-53).
@@ -304,8 +504,28 @@ int fps_block_size(int n) {  // opt_n_threads, furthest_point_sample_cuda.cu:11-
 using namespace msmd;
 
 namespace {
+bool fps_prune_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("MSMD_FPS_PRUNE");   // 0: the plain every-point kernel
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 int launch_fps(const float* xyz, const int* offsets, int b, int n_max, int n_fixed, int m,
                float* temp, int32_t* idx, hipStream_t st) {
+  // pruned kernel: elements of 2k..24k points (below, a round is ~100 instructions
+  // either way; above, the points do not fit one workgroup's registers)
+  const int ppl = ceil_div(n_max, kFpsPrunedThreads);
+  if (fps_prune_enabled() && n_max >= 2048 && ppl <= 48) {
+#define FPSP(P)                                                                              \
+  MSMD_LAUNCH(fps_pruned_kernel<P>, dim3(b), dim3(kFpsPrunedThreads), 0, st, xyz, offsets, \
+              n_fixed, m, idx)
+    if (ppl <= 16) FPSP(16);
+    else if (ppl <= 32) FPSP(32);
+    else FPSP(48);
+#undef FPSP
+    return launch_status();
+  }
   const int ppt = ceil_div(n_max, 1024);
 #define FPS(P) \
   MSMD_LAUNCH(fps_kernel<P>, dim3(b), dim3(1024), 0, st, xyz, offsets, n_fixed, m, temp, idx)

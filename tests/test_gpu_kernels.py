@@ -651,6 +651,37 @@ def test_fps(dev, n, m):
     assert np.array_equal(got.cpu().numpy(), exp)
 
 
+@pytest.mark.parametrize("order", ["first-touch", "shuffled"])
+def test_fps_pruned_lc_shape(dev, order):
+    """The bucket-pruned kernel at the LC stage-0 shape (2 x ~22k voxel coordinates,
+    2048 samples), on spatially coherent input (buckets get skipped) and on the
+    same points shuffled (nothing can be skipped): bit-identical to the oracle
+    both ways."""
+    from msmdfusion_amd import kernels as K
+    clouds = []
+    for seed in range(2):
+        p = S.virtual_points(seed, n=50000)[:, :3]
+        c = np.floor((p - np.array(S.POINT_CLOUD_RANGE[:3])) / np.array(S.VOXEL_SIZE))
+        c = c.astype(np.int64)[:, ::-1]
+        _, first = np.unique(c, axis=0, return_index=True)
+        clouds.append(np.ascontiguousarray(c[np.sort(first)], dtype=np.float32))
+    n = min(c.shape[0] for c in clouds)
+    assert 15000 < n <= 24576
+    xyz = np.stack([c[:n] for c in clouds])
+    if order == "shuffled":
+        rng = np.random.RandomState(0)
+        xyz = np.stack([x[rng.permutation(n)] for x in xyz])
+    exp = O.furthest_point_sample(xyz, 2048)
+    got = K.furthest_point_sample(t(xyz, dev), 2048)
+    assert np.array_equal(got.cpu().numpy(), exp)
+    # non-integer coordinates (no ties, rounding matters for the box bound)
+    rng = np.random.RandomState(1)
+    fxyz = (xyz * np.float32(0.075) + rng.rand(*xyz.shape).astype(np.float32) * 0.01)
+    exp = O.furthest_point_sample(fxyz, 512)
+    got = K.furthest_point_sample(t(fxyz, dev), 512)
+    assert np.array_equal(got.cpu().numpy(), exp)
+
+
 def test_fps_ragged_batch(dev):
     """One launch over elements of different sizes == per-element FPS."""
     from msmdfusion_amd import kernels as K
