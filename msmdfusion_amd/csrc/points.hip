@@ -25,37 +25,40 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 }
 
 // ---- DPP reductions (no LDS crossbar: ~12 VALU per 32-bit wave reduce instead
-// of 6 dependent ds_bpermute round trips) --------------------------------------
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ int dpp_mov(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
-}
+// of 6 dependent ds_bpermute round trips).  Written as assembly: through
+// __builtin_amdgcn_update_dpp the compiler emits v_mov_b32_dpp + a copy + the ALU
+// op per step (4 instructions and 2 waits); the ALU op takes the DPP operand
+// itself.  `s_nop 1` = the two wait states a DPP read needs after a VALU write of
+// the same register. -------------------------------------------------------------
+#define MSMD_DPP16(OP)                                                        \
+  "s_nop 1\n" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" \
+  "s_nop 1\n" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n" \
+  "s_nop 1\n" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"     \
+  "s_nop 1\n" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+#define MSMD_DPP64(OP)                                                        \
+  MSMD_DPP16(OP)                                                              \
+  "s_nop 1\n" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"       \
+  "s_nop 1\n" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
 __device__ __forceinline__ float fmax_dpp16(float v) {  // max over each 16-lane row, all lanes
-  v = fmaxf(v, __int_as_float(dpp_mov<0xB1>(__float_as_int(v))));   // quad_perm [1,0,3,2]
-  v = fmaxf(v, __int_as_float(dpp_mov<0x4E>(__float_as_int(v))));   // quad_perm [2,3,0,1]
-  v = fmaxf(v, __int_as_float(dpp_mov<0x141>(__float_as_int(v))));  // row_half_mirror
-  v = fmaxf(v, __int_as_float(dpp_mov<0x140>(__float_as_int(v))));  // row_mirror
+  asm(MSMD_DPP16("v_max_f32_dpp") : "+v"(v));
   return v;
 }
 __device__ __forceinline__ uint32_t umin_dpp16(uint32_t v) {
-  v = min(v, (uint32_t)dpp_mov<0xB1>((int)v));
-  v = min(v, (uint32_t)dpp_mov<0x4E>((int)v));
-  v = min(v, (uint32_t)dpp_mov<0x141>((int)v));
-  v = min(v, (uint32_t)dpp_mov<0x140>((int)v));
+  asm(MSMD_DPP16("v_min_u32_dpp") : "+v"(v));
   return v;
 }
 __device__ __forceinline__ float fmax_wave(float v) {  // wave-uniform result
-  v = fmax_dpp16(v);
-  v = fmaxf(v, __int_as_float(dpp_mov<0x142, 0xA>(__float_as_int(v))));  // row_bcast:15
-  v = fmaxf(v, __int_as_float(dpp_mov<0x143, 0xC>(__float_as_int(v))));  // row_bcast:31
+  asm(MSMD_DPP64("v_max_f32_dpp") : "+v"(v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ uint32_t umin_wave(uint32_t v) {
-  v = umin_dpp16(v);
-  v = min(v, (uint32_t)dpp_mov<0x142, 0xA>((int)v));
-  v = min(v, (uint32_t)dpp_mov<0x143, 0xC>((int)v));
+  asm(MSMD_DPP64("v_min_u32_dpp") : "+v"(v));
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+
+constexpr int kFpsPrunedThreads = 512;
+constexpr int kFpsSlotsPerBucket = 4;
+constexpr int kFpsProbe0 = 32, kFpsProbe1 = 96;   // see fps_pruned_kernel
 
 // Furthest point sampling, one 1024-thread workgroup per batch element; batch
 // elements may have different sizes (offsets[b+1], ragged) or all n (offsets
@@ -71,10 +74,11 @@ template <int PPT>
 __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz_all,
                                                    const int* __restrict__ offsets, int n_fixed,
                                                    int m, float* __restrict__ temp_all,
-                                                   int32_t* __restrict__ idx_all) {
+                                                   int32_t* __restrict__ idx_all, int resume) {
   __shared__ float red_d[2][16];
   __shared__ uint32_t red_t[2][16];
   __shared__ float s_xyz[3];
+  __shared__ float s_replay[kFpsProbe1][3];
   if (m <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long base = offsets ? offsets[blockIdx.x] : (long)blockIdx.x * n_fixed;
@@ -83,8 +87,18 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
   float* temp = temp_all + base;
   int32_t* idx = idx_all + (size_t)blockIdx.x * m;
   if (n <= 0) {
-    for (int j = tid; j < m; j += 1024) idx[j] = 0;
+    if (!resume)
+      for (int j = tid; j < m; j += 1024) idx[j] = 0;
     return;
+  }
+  // resume: second half of a hand-over from fps_pruned_kernel (idx[m-1] = -(next
+  // round j0)); an element it finished itself has idx[m-1] >= 0 and there is nothing
+  // to do.  The running distances after samples 0..j0-2 are rebuilt by replaying them.
+  int j0 = 1;
+  if (resume) {
+    const int mark = idx[m - 1];
+    if (mark >= 0) return;
+    j0 = -mark;
   }
   constexpr int P = PPT > 0 ? PPT : 1;
   // reference block size opt_n_threads(n): largest power of two <= n, max 1024
@@ -110,17 +124,36 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
       pz[s] = ok ? xyz[k * 3 + 2] : 0.f;
       pd[s] = ok ? 1e10f : -1.f;        // padding never wins (distances are >= 0)
     }
+    if (resume) {
+      for (int jj = tid; jj + 1 < j0 && jj < kFpsProbe1; jj += 1024) {
+        const int si = idx[jj];
+        s_replay[jj][0] = xyz[si * 3];
+        s_replay[jj][1] = xyz[si * 3 + 1];
+        s_replay[jj][2] = xyz[si * 3 + 2];
+      }
+      __syncthreads();
+      for (int jj = 0; jj + 1 < j0; ++jj) {
+        const float x1 = s_replay[jj][0], y1 = s_replay[jj][1], z1 = s_replay[jj][2];
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+          float dx = px[s] - x1, dy = py[s] - y1, dz = pz[s] - z1;
+          float d = dx * dx + dy * dy + dz * dz;
+          pd[s] = fminf(d, pd[s]);
+        }
+      }
+    }
   } else {
     for (int k = tid; k < n; k += 1024) temp[k] = 1e10f;
   }
   if (tid == 0) {
-    idx[0] = 0;
-    s_xyz[0] = xyz[0];
-    s_xyz[1] = xyz[1];
-    s_xyz[2] = xyz[2];
+    const int first = resume ? idx[j0 - 1] : 0;
+    if (!resume) idx[0] = 0;
+    s_xyz[0] = xyz[first * 3];
+    s_xyz[1] = xyz[first * 3 + 1];
+    s_xyz[2] = xyz[first * 3 + 2];
   }
   __syncthreads();
-  for (int j = 1; j < m; ++j) {
+  for (int j = j0; j < m; ++j) {
     const float x1 = s_xyz[0], y1 = s_xyz[1], z1 = s_xyz[2];
     float best_d = -1.f;
     uint32_t best_t = 0xFFFFFFFFu;
@@ -229,8 +262,6 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-constexpr int kFpsPrunedThreads = 512;
-constexpr int kFpsSlotsPerBucket = 4;
 
 template <int P>
 __global__ __launch_bounds__(kFpsPrunedThreads) void fps_pruned_kernel(
@@ -241,6 +272,7 @@ __global__ __launch_bounds__(kFpsPrunedThreads) void fps_pruned_kernel(
   __shared__ float red_d[2][NW];
   __shared__ uint32_t red_t[2][NW];
   __shared__ float red_p[2][NW][3];
+  __shared__ int red_n[NW];
   if (m <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: ranks split below
@@ -254,11 +286,13 @@ __global__ __launch_bounds__(kFpsPrunedThreads) void fps_pruned_kernel(
   }
   const int bs_shift = min(31 - __clz(n), 10);
   const int bs_ref = 1 << bs_shift;
-  // slot s of this lane holds point k = U_s + lane, U_s = (wave*P + s)*64.
+  // Buckets are dealt round-robin to the waves (bucket g*NW + wave belongs to wave
+  // `wave`): the few buckets a sample can reach are neighbours in index order, and this
+  // way they are refreshed by different waves in parallel instead of one after another.
+  // Slot s = g*SB + q of this lane holds point k = U_s + lane, U_s = ((g*NW + wave)*SB + q)*64.
   // tie rank of k (see fps_kernel) = (bitrev(k mod bs) << 21) | (k div bs); U_s is a
   // multiple of 64 and lane < 64, so the two never share a bit and the rank splits
   // into a per-lane constant OR a wave-uniform term (scalar ALU):
-  const int wp = wave * P;
   const int rsh = 32 - bs_shift;
   const uint32_t lane_rank =
       ((bs_shift ? (__brev((uint32_t)lane) >> rsh) : 0u) << 21) |
@@ -275,7 +309,7 @@ __global__ __launch_bounds__(kFpsPrunedThreads) void fps_pruned_kernel(
   float px[P], py[P], pz[P], pd[P];
 #pragma unroll
   for (int s = 0; s < P; ++s) {
-    const int k = (wp + s) * 64 + lane;
+    const int k = (((s / SB) * NW + wave) * SB + s % SB) * 64 + lane;
     const bool ok = k < n;
     px[s] = ok ? xyz[(size_t)k * 3 + 0] : 0.f;
     py[s] = ok ? xyz[(size_t)k * 3 + 1] : 0.f;
@@ -323,7 +357,7 @@ __global__ __launch_bounds__(kFpsPrunedThreads) void fps_pruned_kernel(
     uint32_t lt = 0xFFFFFFFFu;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (wd >= 0.f) {
-      uint32_t bucket_rank = rank_of((uint32_t)(wp + g * SB) * 64u);
+      uint32_t bucket_rank = rank_of((uint32_t)((g * NW + wave) * SB) * 64u);
       // keep the OR below inside the loop: hoisted, its 48 results would live in VGPRs
       asm volatile("" : "+s"(bucket_rank));
 #pragma unroll
@@ -349,13 +383,22 @@ __global__ __launch_bounds__(kFpsPrunedThreads) void fps_pruned_kernel(
   };
   float sx = xyz[0], sy = xyz[1], sz = xyz[2];
   if (tid == 0) idx[0] = 0;
-  for (int j = 1; j < m; ++j) {
+  // Is the pruning paying?  Refreshes are counted over rounds kFpsProbe0..kFpsProbe1; if
+  // more than half of the (non-empty) buckets were refreshed per round -- an input
+  // whose index order is not spatially coherent -- the element is handed to the plain
+  // kernel, which is twice as fast when every point has to be touched anyway:
+  // idx[m-1] = -(next round) marks the hand-over; the plain kernel rebuilds the running
+  // distances from the samples chosen so far (a min over them: order-free, exact).
+  const int nbuckets = (n + 64 * SB - 1) / (64 * SB);
+  int refreshed = 0;
+  auto one_round = [&](int j) {
     // which of this wave's buckets can the sample still reach?
     const float ex = fmaxf(fmaxf(bx0 - sx, sx - bx1), 0.f);
     const float ey = fmaxf(fmaxf(by0 - sy, sy - by1), 0.f);
     const float ez = fmaxf(fmaxf(bz0 - sz, sz - bz1), 0.f);
     const float bound = ex * ex + ey * ey + ez * ez;
     const unsigned long long need = __ballot(lane < G && bound < mybd);
+    refreshed = j == kFpsProbe0 ? 0 : refreshed + __popcll(need);
     static_for<G>([&](auto gc) {
       if ((need >> decltype(gc)::value) & 1ull) update(gc, sx, sy, sz);
     });
@@ -378,19 +421,39 @@ __global__ __launch_bounds__(kFpsPrunedThreads) void fps_pruned_kernel(
       red_p[buf][wave][2] = wz;
     }
     __syncthreads();
-    const float cd = red_d[buf][lane & (NW - 1)];
+    // every lane fetches candidate (lane mod NW) whole -- five independent LDS reads,
+    // one wait -- and the winner's coordinates come out of a lane, not a second trip
+    const int cw = lane & (NW - 1);
+    const float cd = red_d[buf][cw];
+    const uint32_t ctv = red_t[buf][cw];
+    const float cpx = red_p[buf][cw][0], cpy = red_p[buf][cw][1], cpz = red_p[buf][cw][2];
     const float bd = fmax_dpp16(cd);
-    const uint32_t tc = cd == bd ? red_t[buf][lane & (NW - 1)] : 0xFFFFFFFFu;
+    const uint32_t tc = cd == bd ? ctv : 0xFFFFFFFFu;
     const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)umin_dpp16(tc));
     const unsigned long long gh = __ballot(tc == tb);
-    const int ww = (gh ? __ffsll((long long)gh) - 1 : 0) & (NW - 1);
-    sx = red_p[buf][ww][0];
-    sy = red_p[buf][ww][1];
-    sz = red_p[buf][ww][2];
+    const int ww = gh ? __ffsll((long long)gh) - 1 : 0;
+    sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cpx), ww));
+    sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cpy), ww));
+    sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cpz), ww));
     if (tid == 0) {
       const uint32_t tid_ref = bs_shift ? (__brev(tb >> 21) >> (32 - bs_shift)) : 0u;
       idx[j] = (int)((tb & 0x1FFFFFu) << bs_shift) | (int)tid_ref;
     }
+  };
+  const bool probe = m > 2 * kFpsProbe1;
+  const int m1 = probe ? kFpsProbe1 : m;
+  for (int j = 1; j < m1; ++j) one_round(j);
+  if (probe) {
+    if (lane == 0) red_n[wave] = refreshed;
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) total += red_n[w];
+    if (2 * total > nbuckets * (kFpsProbe1 - kFpsProbe0)) {
+      if (tid == 0) idx[m - 1] = -m1;
+      return;
+    }
+    for (int j = m1; j < m; ++j) one_round(j);
   }
 }
 
@@ -511,24 +574,12 @@ bool fps_prune_enabled() {
   }();
   return on;
 }
-int launch_fps(const float* xyz, const int* offsets, int b, int n_max, int n_fixed, int m,
-               float* temp, int32_t* idx, hipStream_t st) {
-  // pruned kernel: elements of 2k..24k points (below, a round is ~100 instructions
-  // either way; above, the points do not fit one workgroup's registers)
-  const int ppl = ceil_div(n_max, kFpsPrunedThreads);
-  if (fps_prune_enabled() && n_max >= 2048 && ppl <= 48) {
-#define FPSP(P)                                                                              \
-  MSMD_LAUNCH(fps_pruned_kernel<P>, dim3(b), dim3(kFpsPrunedThreads), 0, st, xyz, offsets, \
-              n_fixed, m, idx)
-    if (ppl <= 16) FPSP(16);
-    else if (ppl <= 32) FPSP(32);
-    else FPSP(48);
-#undef FPSP
-    return launch_status();
-  }
+void launch_fps_plain(const float* xyz, const int* offsets, int b, int n_max, int n_fixed, int m,
+                      float* temp, int32_t* idx, int resume, hipStream_t st) {
   const int ppt = ceil_div(n_max, 1024);
-#define FPS(P) \
-  MSMD_LAUNCH(fps_kernel<P>, dim3(b), dim3(1024), 0, st, xyz, offsets, n_fixed, m, temp, idx)
+#define FPS(P)                                                                               \
+  MSMD_LAUNCH(fps_kernel<P>, dim3(b), dim3(1024), 0, st, xyz, offsets, n_fixed, m, temp, idx, \
+              resume)
   if (ppt <= 2) FPS(2);
   else if (ppt <= 4) FPS(4);
   else if (ppt <= 8) FPS(8);
@@ -538,6 +589,26 @@ int launch_fps(const float* xyz, const int* offsets, int b, int n_max, int n_fix
   else if (ppt <= 24) FPS(24);
   else FPS(0);
 #undef FPS
+}
+int launch_fps(const float* xyz, const int* offsets, int b, int n_max, int n_fixed, int m,
+               float* temp, int32_t* idx, hipStream_t st) {
+  // pruned kernel: elements of 6k..24k points sampled sparsely (below that a round is
+  // mostly fixed cost either way; above, the points do not fit one workgroup's
+  // registers).  It may hand an element over (see kFpsProbe1): the plain kernel runs
+  // right behind it in resume mode and returns at once for finished elements.
+  const int ppl = ceil_div(n_max, kFpsPrunedThreads);
+  if (fps_prune_enabled() && n_max >= 6144 && ppl <= 48 && m > 2 * kFpsProbe1) {
+#define FPSP(P)                                                                              \
+  MSMD_LAUNCH(fps_pruned_kernel<P>, dim3(b), dim3(kFpsPrunedThreads), 0, st, xyz, offsets, \
+              n_fixed, m, idx)
+    if (ppl <= 16) FPSP(16);
+    else if (ppl <= 32) FPSP(32);
+    else FPSP(48);
+#undef FPSP
+    launch_fps_plain(xyz, offsets, b, n_max, n_fixed, m, temp, idx, 1, st);
+    return launch_status();
+  }
+  launch_fps_plain(xyz, offsets, b, n_max, n_fixed, m, temp, idx, 0, st);
   return launch_status();
 }
 }  // namespace
