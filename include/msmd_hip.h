@@ -97,11 +97,6 @@ int msmd_voxel_mean(const float* voxels /* [M,max_points,C] */,
  * msmd_rulebook_pairs() converts it to the reference's indicePairs/indiceNum.
  * ------------------------------------------------------------------------ */
 size_t msmd_rulebook_subm_workspace_bytes(int n);
-/* Workspace of the faster path for large voxel sets (a per-grid-line index
- * instead of the hash table; chosen inside msmd_rulebook_subm3d when n is large
- * and the workspace is at least this big).  >= the n-only query. */
-size_t msmd_rulebook_subm_grid_workspace_bytes(int n, int batch_size,
-                                               const int* spatial_shape);
 
 int msmd_rulebook_subm3d(const int32_t* indices /* [n,4] */, int n,
                          int batch_size, const int* spatial_shape /* host[3] */,

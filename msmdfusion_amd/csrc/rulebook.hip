@@ -23,8 +23,6 @@
 #include "common.hpp"
 #include "scan.hpp"
 
-#include <stdlib.h>
-
 namespace msmd {
 namespace {
 
@@ -66,99 +64,6 @@ __global__ __launch_bounds__(256) void subm_lookup(const int32_t* __restrict__ i
   if (z >= 0 && z < g.shape[0] && y >= 0 && y < g.shape[1] && x >= 0 && x < g.shape[2])
     v = hash_find(table, bits, cell_id(r.x, z, y, x, g.shape));
   nbr[(size_t)k * n + o] = v;
-}
-
-// ---- SubM, large voxel sets: line buckets ------------------------------------
-// The hash table above destroys the locality the input has: voxel rows arrive in
-// scan order (consecutive rows are mostly neighbours in space), but their 27
-// probes land on 27 unrelated cache lines of a 2N-slot table -- measured 5x the
-// algorithmic bytes at 720k voxels (profiles/r01_rulebook_voxelize_roofline.jsonl).
-// Here the index is a CSR over grid LINES (fixed b,z,y; x runs along the line):
-// start[line] .. end[line] delimit the line's (x, row) entries.  A line of a
-// LiDAR grid holds a handful of voxels, so a lookup is "read two ints of a small,
-// L2-resident table, scan a few contiguous 8-byte entries" and gives the THREE
-// x-neighbours of one (dz,dy) at once: 9 lookups per row instead of 27 probes,
-// and rows that are neighbours in space read the same lines of both arrays.
-// Entries inside a line are unordered (placed by an atomic cursor); duplicate
-// coordinates resolve to the highest row, as the hash path does.
-struct LineEntry {
-  int32_t x, row;
-};
-__global__ __launch_bounds__(256) void line_count(const int32_t* __restrict__ idx, int n, Geom g,
-                                                  int* __restrict__ cnt) {
-  int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  int4 r = ((const int4*)idx)[j];
-  atomicAdd(&cnt[((size_t)r.x * g.shape[0] + r.y) * g.shape[1] + r.z], 1);
-}
-struct LineCount {
-  const int* cnt;
-  __device__ int operator()(int i) const { return cnt[i]; }
-};
-struct LineEmit {
-  int* start;
-  int* cursor;
-  __device__ void operator()(int i, int prefix, int) const {
-    start[i] = prefix;
-    cursor[i] = prefix;
-  }
-};
-__global__ __launch_bounds__(256) void line_fill(const int32_t* __restrict__ idx, int n, Geom g,
-                                                 int* __restrict__ cursor,
-                                                 LineEntry* __restrict__ entries) {
-  int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  int4 r = ((const int4*)idx)[j];
-  int pos = atomicAdd(&cursor[((size_t)r.x * g.shape[0] + r.y) * g.shape[1] + r.z], 1);
-  entries[pos] = LineEntry{r.w, j};
-}
-// thread (o, line neighbour): blockIdx.y = kz*ks[1] + ky; the ks[2] results go to
-// ks[2] consecutive planes of nbr, each store coalesced along o.  KX = ks[2] (<= 3
-// as a template so that the candidates stay in registers).
-template <int KX>
-__global__ __launch_bounds__(256) void line_lookup(const int32_t* __restrict__ idx, int n, Geom g,
-                                                   const int* __restrict__ start,
-                                                   const int* __restrict__ end,
-                                                   const LineEntry* __restrict__ entries,
-                                                   int32_t* __restrict__ nbr) {
-  int o = blockIdx.x * 256 + threadIdx.x;
-  if (o >= n) return;
-  const int kzy = blockIdx.y;
-  const int ky = kzy % g.ks[1], kz = kzy / g.ks[1];
-  int4 r = ((const int4*)idx)[o];
-  const int z = r.y - g.pd[0] + kz, y = r.z - g.pd[1] + ky, x0 = r.w - g.pd[2];
-  int v[KX];
-#pragma unroll
-  for (int i = 0; i < KX; ++i) v[i] = -1;
-  if (z >= 0 && z < g.shape[0] && y >= 0 && y < g.shape[1]) {
-    const size_t line = ((size_t)r.x * g.shape[0] + z) * g.shape[1] + y;
-    const int b = start[line], e = end[line];
-    for (int p = b; p < e; ++p) {
-      const LineEntry t = entries[p];
-      const int dx = t.x - x0;
-#pragma unroll
-      for (int i = 0; i < KX; ++i) v[i] = (dx == i && t.row > v[i]) ? t.row : v[i];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < KX; ++i) nbr[((size_t)kzy * KX + i) * n + o] = v[i];
-}
-
-constexpr int kSubmLineMinRows = 150000;   // below: the hash path's 3 launches win
-struct LineWs {
-  int *cnt, *start, *cursor, *tiles;
-  LineEntry* entries;
-  long lines;
-};
-template <typename A>
-void carve_lines(A& a, LineWs* w, int n, int batch, const int* shape) {
-  const long lines = (long)batch * shape[0] * shape[1];
-  int* cnt = a.template take<int>(lines);
-  int* start = a.template take<int>(lines);
-  int* cursor = a.template take<int>(lines);
-  int* tiles = a.template take<int>(scan_num_tiles(lines) + 1);
-  LineEntry* en = a.template take<LineEntry>(n > 0 ? n : 1);
-  if (w) *w = LineWs{cnt, start, cursor, tiles, en, lines};
 }
 
 // ------------------------------------------------------------- strided ----
@@ -284,20 +189,6 @@ MSMD_EXPORT size_t msmd_rulebook_subm_workspace_bytes(int n) {
   return align_up(sizeof(unsigned long long) << bits);
 }
 
-// Workspace of the path msmd_rulebook_subm3d takes for this (n, grid): the line-bucket
-// index for large voxel sets, the hash table otherwise.  A caller that only knows n
-// (msmd_rulebook_subm_workspace_bytes) gets the hash path.
-MSMD_EXPORT size_t msmd_rulebook_subm_grid_workspace_bytes(int n, int batch_size,
-                                                           const int* spatial_shape) {
-  size_t hash = msmd_rulebook_subm_workspace_bytes(n);
-  if (n < kSubmLineMinRows || batch_size < 1 || !spatial_shape) return hash;
-  const double lines = (double)batch_size * spatial_shape[0] * spatial_shape[1];
-  if (lines <= 0 || lines > 64.0 * n) return hash;      // an almost empty grid: hash it
-  ArenaSize a;
-  carve_lines(a, (LineWs*)nullptr, n, batch_size, spatial_shape);
-  return a.off > hash ? a.off : hash;
-}
-
 MSMD_EXPORT int msmd_rulebook_subm3d(const int32_t* indices, int n, int batch_size,
                                      const int* spatial_shape, const int* ksize, int32_t* nbr,
                                      void* workspace, size_t workspace_bytes,
@@ -307,44 +198,14 @@ MSMD_EXPORT int msmd_rulebook_subm3d(const int32_t* indices, int n, int batch_si
   if (rc) return rc;
   if (n < 0 || (n > 0 && (!indices || !nbr))) return MSMD_ERR_INVALID_ARG;
   if (n == 0) return MSMD_OK;
-  hipStream_t st = (hipStream_t)stream;
-  const int nb = ceil_div(n, 256);
-  if (((uintptr_t)workspace & 255)) return MSMD_ERR_WORKSPACE;
-  static const bool lines_on = [] {
-    const char* e = getenv("MSMD_SUBM_LINES");    // 0: always the hash path
-    return !(e && e[0] == '0');
-  }();
-  if (lines_on && n >= kSubmLineMinRows && g.ks[2] <= 3 &&
-      (double)batch_size * g.shape[0] * g.shape[1] <= 64.0 * n) {
-    Arena a(workspace, workspace_bytes);
-    LineWs w;
-    carve_lines(a, &w, n, batch_size, g.shape);
-    if (a.ok()) {
-      hipMemsetAsync(w.cnt, 0, sizeof(int) * w.lines, st);
-      MSMD_LAUNCH(line_count, dim3(nb), dim3(256), 0, st, indices, n, g, w.cnt);
-      device_scan(LineCount{w.cnt}, LineEmit{w.start, w.cursor}, (int)w.lines, w.tiles,
-                  (int*)nullptr, -1, st);
-      MSMD_LAUNCH(line_fill, dim3(nb), dim3(256), 0, st, indices, n, g, w.cursor, w.entries);
-      // after the fill cursor[line] is the END of the line
-      const dim3 grid(nb, g.ks[0] * g.ks[1]);
-      if (g.ks[2] == 3)
-        MSMD_LAUNCH(line_lookup<3>, grid, dim3(256), 0, st, indices, n, g, w.start, w.cursor,
-                    w.entries, nbr);
-      else if (g.ks[2] == 2)
-        MSMD_LAUNCH(line_lookup<2>, grid, dim3(256), 0, st, indices, n, g, w.start, w.cursor,
-                    w.entries, nbr);
-      else
-        MSMD_LAUNCH(line_lookup<1>, grid, dim3(256), 0, st, indices, n, g, w.start, w.cursor,
-                    w.entries, nbr);
-      return launch_status();
-    }
-    // workspace sized by the n-only query: fall through to the hash path
-  }
   int bits = next_pow2_bits(2L * n);
   if (bits < 6) bits = 6;
-  if (workspace_bytes < (sizeof(unsigned long long) << bits)) return MSMD_ERR_WORKSPACE;
+  if (workspace_bytes < (sizeof(unsigned long long) << bits) || ((uintptr_t)workspace & 255))
+    return MSMD_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
   auto* table = (unsigned long long*)workspace;
   hipMemsetAsync(table, 0xFF, sizeof(unsigned long long) << bits, st);
+  const int nb = ceil_div(n, 256);
   MSMD_LAUNCH(subm_insert, dim3(nb), dim3(256), 0, st, indices, n, g, table, bits);
   MSMD_LAUNCH(subm_lookup, dim3(nb, g.kvol), dim3(256), 0, st, indices, n, g, table, bits,
                      nbr);

@@ -154,7 +154,7 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize):
     n = idx.shape[0]
     ks = _expand3(ksize)
     nbr = torch.empty((kernel_volume(ks), n), dtype=torch.int32, device=idx.device)
-    nbytes = lib.msmd_rulebook_subm_grid_workspace_bytes(n, int(batch_size), int3(spatial_shape))
+    nbytes = lib.msmd_rulebook_subm_workspace_bytes(n)
     ws = _ws(nbytes, idx.device)
     check(lib.msmd_rulebook_subm3d(_p(idx), n, int(batch_size), int3(spatial_shape), int3(ks),
                                    _p(nbr), _p(ws), nbytes, _stream()), "msmd_rulebook_subm3d")

@@ -132,31 +132,6 @@ def test_rulebook_lidar_full_grid(dev, subm, ks, st, pd):
     _check_rulebook(dev, idx, 1, S.SPARSE_SHAPE, subm, ks, st, pd)
 
 
-@pytest.mark.parametrize("ks,pd", [([3, 3, 3], [1, 1, 1]), ([1, 3, 3], [0, 1, 1]),
-                                   ([3, 1, 1], [1, 0, 0])])
-def test_rulebook_subm_line_buckets(dev, ks, pd):
-    """Voxel sets of >= 150k rows take the per-grid-line index instead of the hash
-    table (rulebook.hip): same table as the oracle, batch 3, dense lines (the grid
-    is small, so some lines hold dozens of voxels), rows in random order."""
-    from msmdfusion_amd import kernels as K
-    shape = [9, 300, 300]
-    idx = S.random_voxel_indices(190000, 3, shape, seed=17, clustered=False)
-    assert idx.shape[0] >= 150000
-    oi, pr, nm, osz = O.get_indice_pairs(idx, 3, shape, ks, 1, pd, 1, True)
-    _, can, _ = O.canonical_rulebook(oi, pr, nm, osz, keep_rows=True)
-    nbr = K.rulebook_subm(t(idx, dev), 3, shape, ks)
-    assert np.array_equal(nbr.cpu().numpy(), O.nbr_table_from_pairs(can, idx.shape[0]))
-    # duplicate coordinates: the highest row wins, as on the hash path / the CPU
-    # reference's grid (geometry.h:277-282)
-    dup = np.concatenate([idx, idx[:5000]])
-    n = idx.shape[0]
-    nbr_d = K.rulebook_subm(t(dup, dev), 3, shape, ks).cpu().numpy()
-    centre = (ks[0] * ks[1] * ks[2]) // 2
-    assert np.array_equal(nbr_d[centre, :5000], np.arange(n, n + 5000))
-    assert np.array_equal(nbr_d[centre, n:], np.arange(n, n + 5000))
-    assert np.array_equal(nbr_d[centre, 5000:n], np.arange(5000, n))
-
-
 def test_rulebook_edges(dev):
     from msmdfusion_amd import kernels as K
     shape = [5, 8, 8]
