@@ -29,6 +29,10 @@ for w in $WHAT; do
          tail -1 $P/bench.log | cut -c1-160
          [ -n "$f" ] && python $R/tools/prof_summary.py $f $([ $wl = lc ] && echo 42 || echo 36) 40 > $P/summary.txt
        done) ;;
+    rb)   # integer kernels at nominal and stress size (profiles/rNN_rulebook_voxelize_roofline.jsonl)
+      timeout 300 python tools/rulebook_bench.py 2>/dev/null > $OUT/rulebook_voxelize_roofline.jsonl
+      cut -c1-200 $OUT/rulebook_voxelize_roofline.jsonl
+      timeout 120 python tools/fps_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/fps.txt; cat $OUT/fps.txt ;;
     pmc)
       bash tools/pmc_collect.sh lc $OUT/pmc_lc
       bash tools/pmc_collect.sh transfusion_l $OUT/pmc_transfusion_l ;;
