@@ -221,7 +221,8 @@ def run_workload(workload, args, dev, rank, world, profile):
         threaded = os.environ.get("MSMD_PREFETCH_THREAD", "1" if lc else "0") == "1"
         if threaded:    # two threads share the GIL: hand it over promptly (default 5 ms)
             sys.setswitchinterval(float(os.environ.get("MSMD_SWITCH_INTERVAL", "0.0005")))
-        prefetch = IndexPrefetcher(model.prepare, dev, threaded=threaded)
+        prefetch = IndexPrefetcher(model.prepare, dev, threaded=threaded,
+                                   depth=int(os.environ.get("MSMD_PREFETCH_DEPTH", "1")))
     # grad_clip max_norm=10 (config); the step structure is msmdfusion_amd.distributed.TrainStep
     step = D.TrainStep(net, params, opt, lambda bev: (bev * target).mean(), prefetch, 10.0)
     step.prime(batch)

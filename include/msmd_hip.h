@@ -501,6 +501,20 @@ int msmd_modality_split(const int32_t* idx_3d /* [n3,4] */, int n3,
                         int32_t* pair_2d /* [min(n3,n2)] */,
                         int32_t* n_mixed /* [1] */, void* workspace,
                         size_t workspace_bytes, msmd_stream_t stream);
+/* The same, plus per-sample row counts in the same pass (what the detector and
+ * the fusion stack otherwise obtain from boolean masks with a host round trip
+ * each: only_3D / only_2D selections MSMDFusion.py:251-325 callers,
+ * pad_missing_batch_id sparse_multimodal_encoder_painting.py:208-225, the
+ * per-sample split of fps_NN_fast :349-369).
+ * sample_stats[4*batch_size] = rows per sample of [3D unmatched | 3D matched |
+ * 2D unmatched | 2D matched]; rows of a sample need not be contiguous. */
+int msmd_modality_split_stats(const int32_t* idx_3d, int n3,
+                              const int32_t* idx_2d, int n2, int batch_size,
+                              const int* spatial_shape, int32_t* mix3d,
+                              int32_t* mix2d, int32_t* pair_3d, int32_t* pair_2d,
+                              int32_t* n_mixed, int32_t* sample_stats,
+                              void* workspace, size_t workspace_bytes,
+                              msmd_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * a15  GMA-Conv neighbour search helpers

@@ -92,6 +92,8 @@ SIGNATURES = {
     "msmd_sparse_add_rows": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "msmd_modality_split_workspace_bytes": (_sz, [_i, _ip]),
     "msmd_modality_split": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "msmd_modality_split_stats": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                       _vp]),
     "msmd_furthest_point_sample": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "msmd_furthest_point_sample_ragged": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "msmd_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp]),

@@ -115,19 +115,36 @@ __global__ __launch_bounds__(256) void and_words(uint32_t* a, const uint32_t* __
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < words) a[i] &= b[i];
 }
+// stats (optional, zeroed by the caller): rows per sample of this voxel set, split by the
+// mix flag -- stats[(base + (flag ? batch : 0)) + b].  One atomic per (wave, sample).
 __global__ __launch_bounds__(256) void split_rows(const int32_t* __restrict__ idx, int n,
                                                   Shape3 sh, const uint32_t* __restrict__ both,
                                                   const int* __restrict__ prefix, int cap,
                                                   int32_t* __restrict__ mix,
-                                                  int32_t* __restrict__ pair) {
+                                                  int32_t* __restrict__ pair,
+                                                  int32_t* __restrict__ stats, int batch,
+                                                  int mixed_offset) {
   int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  uint32_t cell = cell_of(((const int4*)idx)[i], sh.s);
-  int m = bitmap_test(both, cell);
-  mix[i] = m;
-  if (m) {
-    int r = bitmap_rank(both, prefix, cell);
-    if (r < cap) pair[r] = i;
+  int m = 0, b = -1;
+  if (i < n) {
+    const int4 r = ((const int4*)idx)[i];
+    uint32_t cell = cell_of(r, sh.s);
+    m = bitmap_test(both, cell);
+    b = r.x;
+    mix[i] = m;
+    if (m) {
+      int rk = bitmap_rank(both, prefix, cell);
+      if (rk < cap) pair[rk] = i;
+    }
+  }
+  if (stats) {
+    for (int s = 0; s < batch; ++s) {
+      const unsigned long long plain = __ballot(b == s && !m), mixed = __ballot(b == s && m);
+      if ((threadIdx.x & 63) == 0) {
+        if (plain) atomicAdd(&stats[s], __popcll(plain));
+        if (mixed) atomicAdd(&stats[mixed_offset + s], __popcll(mixed));
+      }
+    }
   }
 }
 
@@ -284,11 +301,11 @@ MSMD_EXPORT size_t msmd_modality_split_workspace_bytes(int batch_size, const int
   return a.off;
 }
 
-MSMD_EXPORT int msmd_modality_split(const int32_t* idx_3d, int n3, const int32_t* idx_2d, int n2,
-                                    int batch_size, const int* spatial_shape, int32_t* mix3d,
-                                    int32_t* mix2d, int32_t* pair_3d, int32_t* pair_2d,
-                                    int32_t* n_mixed, void* workspace, size_t workspace_bytes,
-                                    msmd_stream_t stream) {
+static int modality_split_impl(const int32_t* idx_3d, int n3, const int32_t* idx_2d, int n2,
+                               int batch_size, const int* spatial_shape, int32_t* mix3d,
+                               int32_t* mix2d, int32_t* pair_3d, int32_t* pair_2d,
+                               int32_t* n_mixed, int32_t* stats, void* workspace,
+                               size_t workspace_bytes, msmd_stream_t stream) {
   Shape3 sh;
   int rc = check_grid(batch_size, spatial_shape, &sh);
   if (rc) return rc;
@@ -300,6 +317,7 @@ MSMD_EXPORT int msmd_modality_split(const int32_t* idx_3d, int n3, const int32_t
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(w.bits, 0, sizeof(uint32_t) * w.words, st);
   hipMemsetAsync(w.bits2, 0, sizeof(uint32_t) * w.words, st);
+  if (stats) hipMemsetAsync(stats, 0, sizeof(int32_t) * 4 * batch_size, st);
   if (n3 > 0)
     MSMD_LAUNCH(mark_rows, dim3(ceil_div(n3, 256)), dim3(256), 0, st, idx_3d, n3, sh,
                        w.bits);
@@ -310,11 +328,35 @@ MSMD_EXPORT int msmd_modality_split(const int32_t* idx_3d, int n3, const int32_t
                      w.bits2, w.words);
   device_scan(PopcCount{w.bits}, StorePrefix{w.prefix}, (int)w.words, w.tiles, n_mixed, -1, st);
   const int cap = n3 < n2 ? n3 : n2;
+  // stats = [3D plain | 3D mixed | 2D plain | 2D mixed], batch_size entries each
   if (n3 > 0)
     MSMD_LAUNCH(split_rows, dim3(ceil_div(n3, 256)), dim3(256), 0, st, idx_3d, n3, sh,
-                       w.bits, w.prefix, cap, mix3d, pair_3d);
+                       w.bits, w.prefix, cap, mix3d, pair_3d, stats, batch_size, batch_size);
   if (n2 > 0)
     MSMD_LAUNCH(split_rows, dim3(ceil_div(n2, 256)), dim3(256), 0, st, idx_2d, n2, sh,
-                       w.bits, w.prefix, cap, mix2d, pair_2d);
+                       w.bits, w.prefix, cap, mix2d, pair_2d,
+                       stats ? stats + 2 * batch_size : nullptr, batch_size, batch_size);
   return launch_status();
+}
+
+MSMD_EXPORT int msmd_modality_split(const int32_t* idx_3d, int n3, const int32_t* idx_2d, int n2,
+                                    int batch_size, const int* spatial_shape, int32_t* mix3d,
+                                    int32_t* mix2d, int32_t* pair_3d, int32_t* pair_2d,
+                                    int32_t* n_mixed, void* workspace, size_t workspace_bytes,
+                                    msmd_stream_t stream) {
+  return modality_split_impl(idx_3d, n3, idx_2d, n2, batch_size, spatial_shape, mix3d, mix2d,
+                             pair_3d, pair_2d, n_mixed, nullptr, workspace, workspace_bytes,
+                             stream);
+}
+
+MSMD_EXPORT int msmd_modality_split_stats(const int32_t* idx_3d, int n3, const int32_t* idx_2d,
+                                          int n2, int batch_size, const int* spatial_shape,
+                                          int32_t* mix3d, int32_t* mix2d, int32_t* pair_3d,
+                                          int32_t* pair_2d, int32_t* n_mixed,
+                                          int32_t* sample_stats, void* workspace,
+                                          size_t workspace_bytes, msmd_stream_t stream) {
+  if (!sample_stats) return MSMD_ERR_INVALID_ARG;
+  return modality_split_impl(idx_3d, n3, idx_2d, n2, batch_size, spatial_shape, mix3d, mix2d,
+                             pair_3d, pair_2d, n_mixed, sample_stats, workspace, workspace_bytes,
+                             stream);
 }

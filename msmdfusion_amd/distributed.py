@@ -135,7 +135,7 @@ class TrainStep:
         pf = self.prefetcher
         ticket = None
         if pf is not None:
-            if not self._pending:
+            while len(self._pending) < getattr(pf, "depth", 1):     # keep `depth` in flight
                 self.prime(batch)
             self._pending.append(pf.submit(*(batch if next_batch is None else next_batch)))
             ticket = self._pending.pop(0)

@@ -20,9 +20,12 @@ def voxelize_batch(voxel_layer, points, downscale_factor=1.0, base_voxel_size=No
     base * downscale_factor, concatenated, batch id prepended to coors.
     Returns (voxels | mean, num_points, coors[M,4]) -- the reference's order."""
     base = list(base_voxel_size) if base_voxel_size is not None else [0.075, 0.075, 0.2]
-    voxel_layer.voxel_size = [v * downscale_factor for v in base]   # :475-478 mutates the layer
+    # the reference rescales the layer's attribute (:475-478); passed per call here, so
+    # that batches prepared concurrently (IndexPrefetcher depth > 1) cannot see each
+    # other's scale
+    size = [v * downscale_factor for v in base]
     feats, coors, nums = [], [], []
-    for f, c, n in voxel_layer.forward_batch(points, fused_mean=fused_mean):
+    for f, c, n in voxel_layer.forward_batch(points, fused_mean=fused_mean, voxel_size=size):
         feats.append(f)
         coors.append(c)
         nums.append(n)
@@ -93,6 +96,32 @@ class SparseFusionPath(nn.Module):
         self.dist_thresh_list = list(dist_thresh_list)
         self.base_voxel_size = list(base_voxel_size)
 
+    @torch.no_grad()
+    def _voxelize_all(self, points, virtual_points_per_stage, B):
+        """voxelize(pts) (MSMDFusion.py:425) and the four fetch_2D_voxels
+        voxelizations (:382, one per image scale) as ONE batch of 5*B clouds with
+        per-cloud voxel sizes.  -> (LiDAR mean features, LiDAR coors, [voxel_2D x4])."""
+        base = self.base_voxel_size
+        clouds, sizes = list(points), [list(base)] * B
+        for i in range(4):
+            for p in virtual_points_per_stage[i]:
+                clouds.append(p if p.shape[0] else p.new_zeros((100, p.shape[1])))   # :376-380
+                sizes.append([v * self.downscale_factors[i] for v in base])
+        res = self.pts_voxel_layer.forward_batch(clouds, fused_mean=True, voxel_size=sizes)
+
+        def joined(group):
+            coors = torch.cat([F.pad(c, (1, 0), mode="constant", value=b)
+                               for b, (_, c, _) in enumerate(group)], 0)
+            return torch.cat([f for f, _, _ in group], 0), coors
+        feats, coors = joined(res[:B])
+        norm = feats.new_tensor([13.5, 13.5, 2.0])
+        v2 = []
+        for i in range(4):
+            mean, c2 = joined(res[B * (i + 1):B * (i + 2)])
+            mean = torch.cat([mean[:, :3] / norm[None, :], mean[:, 3:]], 1)     # :388-389
+            v2.append(spconv.SparseConvTensor(mean, c2, self.spatial_shapes[i], B))
+        return feats, coors, v2
+
     def prepare(self, points, virtual_points_per_stage, nn_side_stream=True):
         """Everything of a step that depends on the INPUTS alone (no weights, no
         previous step): LiDAR voxelization, the encoder's rulebooks, the
@@ -105,19 +134,23 @@ class SparseFusionPath(nn.Module):
         (msmdfusion_amd/prefetch.py) passes False."""
         B = len(points)
         enc, mm = self.pts_middle_encoder, self.multimodal_middle_encoder
-        feats, _, coors = voxelize_batch(self.pts_voxel_layer, points, 1.0, self.base_voxel_size,
-                                         fused_mean=True)
+        # Host reads are what this function's latency is made of (each one waits for a
+        # short chain of small kernels that queue behind the feature pass's chip-filling
+        # ones): the five voxelizations share one read, the four modality splits share
+        # one -- which also brings the per-sample row counts every later selection needs.
+        feats, coors, v2 = self._voxelize_all(points, virtual_points_per_stage, B)
         planned, stages = enc.plan(coors, B)
-        v2, idx3_5, s3, s2, plans = [], [], [], [], []
+        jobs = []
         for i in range(4):
-            voxel_2D = virtual_points_to_voxels(self.pts_voxel_layer, virtual_points_per_stage[i],
-                                                self.spatial_shapes[i], self.downscale_factors[i],
-                                                B, self.base_voxel_size)
-            idx3, shape3 = stages[i]
-            shape = [max(a, b) for a, b in zip(shape3, voxel_2D.spatial_shape)]
-            i3, voxel_2D.indices, pa, pb = modality_split_indices(idx3, voxel_2D.indices, B, shape)
-            v2.append(voxel_2D); idx3_5.append(i3); s3.append(pa); s2.append(pb)
-            plans.append(mm.plan_stage_rows(i3, voxel_2D.indices, B))
+            shape = [max(a, b) for a, b in zip(stages[i][1], v2[i].spatial_shape)]
+            jobs.append((stages[i][0], v2[i].indices, shape))
+        idx3_5, s3, s2, plans = [], [], [], []
+        for i, (mix3, mix2, pa, pb, stats) in enumerate(K.modality_split_many(jobs, B)):
+            idx3, idx2 = jobs[i][0], jobs[i][1]
+            i3 = torch.cat([idx3[:, :1], mix3[:, None], idx3[:, 1:]], 1).contiguous()
+            v2[i].indices = torch.cat([idx2[:, :1], mix2[:, None], idx2[:, 1:]], 1).contiguous()
+            idx3_5.append(i3); s3.append(pa.long()); s2.append(pb.long())
+            plans.append(mm.plan_stage_rows(i3, v2[i].indices, B, stats))
         # the fusion stack's own voxel sets and rulebooks, stage by stage (each needs
         # the previous stage's output set).  Before the neighbour search is enqueued:
         # these calls read counts back, and must not wait behind 9 ms of FPS
@@ -126,7 +159,7 @@ class SparseFusionPath(nn.Module):
         for i in range(4):
             prev = mm.plan_stage_tensors(plans[i], idx3_5[i], v2[i].indices, s2[i], stages[i][1],
                                          self.spatial_shapes[i], B, i, prev, need_grad)
-        counts = torch.stack([p["counts"] for p in plans]).tolist()
+        counts = [p["counts_host"] for p in plans]
         main = torch.cuda.current_stream()
         # one side stream PER STAGE: a stage's chain is FPS (2047 serial rounds, one
         # workgroup per sample: 2 of 256 CUs busy for 6 ms at stage 0, 3 ms at stage 1) ->

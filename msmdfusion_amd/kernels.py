@@ -101,9 +101,14 @@ def hard_voxelize_batch(points_list, voxel_size, coors_range, max_points, max_vo
                         want_voxels=True, want_mean=False):
     """hard_voxelize for every sample of a batch with ONE host read: all
     launches are enqueued first, the B voxel counts come back together (the
-    reference syncs 4 times per sample, voxelization_cuda.cu:231-323)."""
+    reference syncs 4 times per sample, voxelization_cuda.cu:231-323).
+    voxel_size: one size for all clouds, or one size per cloud (the LiDAR sweep
+    and the four scales of virtual points of a step go out in a single call)."""
+    per_cloud = len(voxel_size) > 0 and isinstance(voxel_size[0], (list, tuple))
+    if per_cloud and len(voxel_size) != len(points_list):
+        raise ValueError("need one voxel size per cloud")
     pending = []
-    for points in points_list:
+    for ci, points in enumerate(points_list):
         _need_cuda(points)
         pts = points.contiguous().float()
         n, c = pts.shape
@@ -116,7 +121,8 @@ def hard_voxelize_batch(points_list, voxel_size, coors_range, max_points, max_vo
         count = torch.empty((1,), dtype=torch.int32, device=dev)
         nbytes = lib.msmd_voxelize_workspace_bytes(n, max_voxels, max_points)
         ws = _ws(nbytes, dev)
-        check(lib.msmd_hard_voxelize(_p(pts), n, c, float_arr(voxel_size),
+        check(lib.msmd_hard_voxelize(_p(pts), n, c,
+                                     float_arr(voxel_size[ci] if per_cloud else voxel_size),
                                      float_arr(coors_range), int(max_points), int(max_voxels),
                                      _p(voxels), _p(coors), _p(npv), _p(mean), _p(count), _p(ws),
                                      nbytes, _stream()), "msmd_hard_voxelize")
@@ -776,6 +782,64 @@ def modality_split(idx_3d, idx_2d, batch_size, spatial_shape):
                                   _stream()), "msmd_modality_split")
     m = int(count.item())
     return mix3, mix2, p3[:m], p2[:m]
+
+
+def modality_split_many(jobs, batch_size):
+    """Several independent modality splits (the four image scales of a step) with ONE
+    host read.  jobs: [(idx_3d, idx_2d, spatial_shape), ...] -> per job
+    (mix3d, mix2d, pair_3d, pair_2d, stats) with stats = dict of per-sample row
+    counts as python lists: c3_plain, c3_mixed, c2_plain, c2_mixed."""
+    pending = []
+    B = int(batch_size)
+    for idx_3d, idx_2d, spatial_shape in jobs:
+        _need_bzyx(idx_3d, idx_2d)
+        _need_cuda(idx_3d, idx_2d)
+        a, b = idx_3d.contiguous().int(), idx_2d.contiguous().int()
+        n3, n2 = a.shape[0], b.shape[0]
+        dev = a.device
+        cap = max(min(n3, n2), 1)
+        mix3 = torch.empty((n3,), dtype=torch.int32, device=dev)
+        mix2 = torch.empty((n2,), dtype=torch.int32, device=dev)
+        p3 = torch.empty((cap,), dtype=torch.int32, device=dev)
+        p2 = torch.empty((cap,), dtype=torch.int32, device=dev)
+        out = torch.empty((1 + 4 * B,), dtype=torch.int32, device=dev)   # count | stats
+        nbytes = lib.msmd_modality_split_workspace_bytes(B, int3(spatial_shape))
+        ws = _ws(nbytes, dev)
+        check(lib.msmd_modality_split_stats(_p(a), n3, _p(b), n2, B, int3(spatial_shape),
+                                            _p(mix3), _p(mix2), _p(p3), _p(p2), _p(out),
+                                            C.c_void_p(out.data_ptr() + 4), _p(ws), nbytes,
+                                            _stream()), "msmd_modality_split_stats")
+        pending.append((mix3, mix2, p3, p2, out, a, b, ws))
+    if not pending:
+        return []
+    host = torch.stack([p[4] for p in pending]).tolist()
+    res = []
+    for (mix3, mix2, p3, p2, _, _, _, _), h in zip(pending, host):
+        m = h[0]
+        stats = dict(c3_plain=h[1:1 + B], c3_mixed=h[1 + B:1 + 2 * B],
+                     c2_plain=h[1 + 2 * B:1 + 3 * B], c2_mixed=h[1 + 3 * B:1 + 4 * B])
+        res.append((mix3, mix2, p3[:m], p2[:m], stats))
+    return res
+
+
+def rows_where(mask, count):
+    """Row numbers where a 1-D bool tensor is set, ascending, when their number is
+    already known on the host: mask.nonzero() would wait for the device to size its
+    output."""
+    count = int(count)
+    if count == 0:
+        return torch.empty((0,), dtype=torch.long, device=mask.device)
+    global _NONZERO_STATIC
+    if _NONZERO_STATIC:
+        try:
+            return torch.nonzero_static(mask, size=count).flatten()
+        except (NotImplementedError, RuntimeError):
+            _NONZERO_STATIC = False
+    # stable sort of the inverted mask: the selected rows come first, in order
+    return torch.sort((~mask).to(torch.uint8), stable=True)[1][:count]
+
+
+_NONZERO_STATIC = hasattr(torch, "nonzero_static")
 
 
 # ------------------------------------------------------------------ GMA-Conv helpers

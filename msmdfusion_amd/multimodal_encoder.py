@@ -106,20 +106,23 @@ class SparseMultiModalEncoderPaint(nn.Module):
 
     # ---- helpers -----------------------------------------------------------------
     @staticmethod
-    def pad_missing_batch_id(indices, features, batch_size):
+    def pad_missing_batch_id(indices, features, batch_size, missing=None):
         """:208-225 -- a sample with no row gets one all-zero voxel at the
-        origin so every per-sample mask downstream is non-empty."""
-        if indices.shape[0]:
-            ids = torch.arange(batch_size, device=indices.device, dtype=indices.dtype)
-            present = (indices[:, :1] == ids).any(0)     # (bincount would sync for its size)
-        else:
-            present = torch.zeros(batch_size, dtype=torch.bool, device=indices.device)
-        missing = (~present).nonzero().flatten()
-        if missing.numel() == 0:
+        origin so every per-sample mask downstream is non-empty.
+        missing: the sample ids without a row, when the caller already knows them
+        on the host (no device read then)."""
+        if missing is None:
+            if indices.shape[0]:
+                ids = torch.arange(batch_size, device=indices.device, dtype=indices.dtype)
+                present = (indices[:, :1] == ids).any(0)     # (bincount would sync for its size)
+            else:
+                present = torch.zeros(batch_size, dtype=torch.bool, device=indices.device)
+            missing = (~present).nonzero().flatten().tolist()
+        if len(missing) == 0:
             return indices, features
-        pad_idx = indices.new_zeros((missing.numel(), indices.shape[1]))
-        pad_idx[:, 0] = missing.to(indices.dtype)
-        pad_feat = features.new_zeros((missing.numel(), features.shape[1]))
+        pad_idx = indices.new_zeros((len(missing), indices.shape[1]))
+        pad_idx[:, 0] = torch.tensor(missing, dtype=indices.dtype).to(indices.device)
+        pad_feat = features.new_zeros((len(missing), features.shape[1]))
         return torch.cat([indices, pad_idx], 0), torch.cat([features, pad_feat], 0)
 
     @staticmethod
@@ -175,14 +178,22 @@ class SparseMultiModalEncoderPaint(nn.Module):
         return out   # offsets are cumulative (reference: last sample's count only, B.4)
 
     # ---- index-only half of a GMA-Conv stage ------------------------------------
-    def plan_stage_rows(self, idx3_5, idx2_5, batch_size):
+    def plan_stage_rows(self, idx3_5, idx2_5, batch_size, stats=None):
         """Everything grouped_sparse_conv derives from the two 5-column index
         tensors alone, up to the neighbour search: row lists of the only-3D /
-        only-2D voxels, the padded only-2D indices, the per-sample counts (device
-        tensor -- the caller reads all stages' counts in one transfer)."""
+        only-2D voxels, the padded only-2D indices, the per-sample counts.
+        stats: the per-sample row counts kernels.modality_split_many read back
+        with the split itself; with them nothing here waits for the device
+        (without: three mask.nonzero() calls and a count transfer do)."""
         zyx = [0, 2, 3, 4]
-        only_3D_rows = (idx3_5[:, 1] == 0).nonzero().flatten()
-        only_2D_rows = (idx2_5[:, 1] == 0).nonzero().flatten()
+        if stats is None:
+            only_3D_rows = (idx3_5[:, 1] == 0).nonzero().flatten()
+            only_2D_rows = (idx2_5[:, 1] == 0).nonzero().flatten()
+            missing = None
+        else:
+            only_3D_rows = K.rows_where(idx3_5[:, 1] == 0, sum(stats["c3_plain"]))
+            only_2D_rows = K.rows_where(idx2_5[:, 1] == 0, sum(stats["c2_plain"]))
+            missing = [b for b in range(batch_size) if stats["c2_plain"][b] == 0]
         o2_idx = idx2_5.index_select(0, only_2D_rows)
         n_raw = o2_idx.shape[0]
         # the neighbour search runs on the real only-2D rows, which are grouped by
@@ -192,11 +203,17 @@ class SparseMultiModalEncoderPaint(nn.Module):
         # wrong whenever a sample other than the last one is the empty one
         o2_bzyx_raw = o2_idx[:, zyx].contiguous()
         o2_idx, _ = self.pad_missing_batch_id(o2_idx, o2_idx.new_zeros((n_raw, 0)).float(),
-                                              batch_size)
+                                              batch_size, missing)
         idx3 = idx3_5[:, zyx].contiguous()
-        return dict(only_3D_rows=only_3D_rows, only_2D_rows=only_2D_rows, o2_idx=o2_idx,
-                    o2_bzyx=o2_bzyx_raw, idx3=idx3, n_pad=o2_idx.shape[0] - n_raw,
-                    counts=self.sample_counts(o2_bzyx_raw, idx3, batch_size))
+        plan = dict(only_3D_rows=only_3D_rows, only_2D_rows=only_2D_rows, o2_idx=o2_idx,
+                    o2_bzyx=o2_bzyx_raw, idx3=idx3, n_pad=o2_idx.shape[0] - n_raw)
+        if stats is None:
+            plan["counts"] = self.sample_counts(o2_bzyx_raw, idx3, batch_size)
+        else:
+            plan["counts_host"] = [list(stats["c2_plain"]),
+                                   [a + b for a, b in zip(stats["c3_plain"], stats["c3_mixed"])]]
+            plan["mixed_missing"] = [b for b in range(batch_size) if stats["c2_mixed"][b] == 0]
+        return plan
 
     def plan_stage_nn(self, plan, counts, batch_size, fps_num, radius, max_cluster_samples,
                       dist_thresh):
@@ -238,7 +255,8 @@ class SparseMultiModalEncoderPaint(nn.Module):
         n_mix = syn_mix_2D.shape[0]
         mixed_idx, _ = self.pad_missing_batch_id(
             idx2_5.index_select(0, syn_mix_2D),
-            torch.empty((n_mix, 0), dtype=torch.float32, device=dev), batch_size)
+            torch.empty((n_mix, 0), dtype=torch.float32, device=dev), batch_size,
+            plan.get("mixed_missing"))
         unified = shell(torch.cat([o3_idx, plan["o2_idx"][:, zyx], mixed_idx[:, zyx]],
                                   0).contiguous(), shape2)
         unified.plan(convs(getattr(self.aggregation_blocks, stage)), need_grad)

@@ -21,7 +21,7 @@ import torch
 
 class IndexPrefetcher:
 
-    def __init__(self, prepare_fn, device, priority=-1, threaded=True):
+    def __init__(self, prepare_fn, device, priority=-1, threaded=True, depth=1):
         """threaded: run prepare_fn on a worker thread.  Its host reads (voxel and
         pair counts) wait for the side stream with the GIL released, so the calling
         thread keeps the main stream fed meanwhile -- without it those waits come
@@ -29,33 +29,46 @@ class IndexPrefetcher:
 
         On a CPU device (the gloo tests of the multi-rank step structure) there
         are no streams: prepare_fn runs inline or on the worker thread, and the
-        hand-over / retire events are no-ops."""
+        hand-over / retire events are no-ops.
+
+        depth: batches in flight.  prepare() is a chain of ~150 small dependent
+        launches and ~35 host reads; next to the feature pass (whose persistent
+        kernels fill every CU) its latency grows past the feature pass's own
+        duration and becomes the step time.  With depth 2 two batches are prepared
+        concurrently, each on its own worker thread and side stream, and the step
+        is bound by throughput again."""
         self.prepare_fn = prepare_fn
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
-        self.side = torch.cuda.Stream(device=self.device, priority=priority) if self.on_gpu \
-            else None
+        self.depth = max(int(depth), 1) if threaded else 1
+        self._sides = [torch.cuda.Stream(device=self.device, priority=priority)
+                       for _ in range(self.depth)] if self.on_gpu else [None]
+        self.side = self._sides[0]
+        self._next = 0
         self._retired = collections.deque()
         self.max_behind = 2      # steps the host may run ahead of the main stream
-        self._pool = ThreadPoolExecutor(1, thread_name_prefix="msmd-index") if threaded else None
+        self._pool = ThreadPoolExecutor(self.depth, thread_name_prefix="msmd-index") \
+            if threaded else None
 
-    def _run(self, grad, args, kw):
+    def _run(self, grad, side, args, kw):
         if not self.on_gpu:
             with torch.set_grad_enabled(grad):
                 return {"value": self.prepare_fn(*args, **kw), "ready": None}
         torch.cuda.set_device(self.device)          # current device / stream / grad mode
-        with torch.set_grad_enabled(grad), torch.cuda.stream(self.side):    # are per thread
+        with torch.set_grad_enabled(grad), torch.cuda.stream(side):    # are per thread
             value = self.prepare_fn(*args, **kw)
             ready = torch.cuda.Event()
-            ready.record(self.side)
+            ready.record(side)
         return {"value": value, "ready": ready}
 
     def submit(self, *args, **kw):
         self._collect()
         grad = torch.is_grad_enabled()
+        side = self._sides[self._next % len(self._sides)]
+        self._next += 1
         if self._pool is None:
-            return self._run(grad, args, kw)
-        return {"future": self._pool.submit(self._run, grad, args, kw)}
+            return self._run(grad, side, args, kw)
+        return {"future": self._pool.submit(self._run, grad, side, args, kw)}
 
     def take(self, ticket):
         if "future" in ticket:

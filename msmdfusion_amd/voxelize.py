@@ -58,11 +58,16 @@ class Voxelization(nn.Module):
                                  self.max_num_points, self._max_voxels())
 
     @torch.no_grad()
-    def forward_batch(self, points_list, fused_mean=False):
+    def forward_batch(self, points_list, fused_mean=False, voxel_size=None):
         """The per-sample loop of the detectors' voxelize()
         (MSMDFusion.py:479-483) with all launches enqueued before the single
-        host read of the voxel counts.  -> list of (voxels|mean, coors, num)."""
-        res = K.hard_voxelize_batch(points_list, self.voxel_size, self.point_cloud_range,
+        host read of the voxel counts.  -> list of (voxels|mean, coors, num).
+        voxel_size overrides the layer's for this call (the detector rescales it
+        per image scale; two batches prepared concurrently must not do that
+        through the shared attribute)."""
+        res = K.hard_voxelize_batch(points_list,
+                                    self.voxel_size if voxel_size is None else voxel_size,
+                                    self.point_cloud_range,
                                     self.max_num_points, self._max_voxels(),
                                     want_voxels=not fused_mean, want_mean=fused_mean)
         return [((mu if fused_mean else v), c, n) for v, c, n, mu in res]

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Host timeline of the pipelined LC step (bench.py's loop): per step, how long the
+training thread waits for the prepared batch, how long it spends enqueueing the
+feature pass, and how long each prepare() call takes on its worker thread.
+
+    python tools/lc_timeline.py            # depth from MSMD_PREFETCH_DEPTH (default 1)
+"""
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from msmdfusion_amd import distributed as D  # noqa: E402
+from msmdfusion_amd import synthetic as S  # noqa: E402
+from msmdfusion_amd.prefetch import IndexPrefetcher  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = bench.FusionBackbone().to(dev).train()
+params = [p for p in model.parameters() if p.requires_grad]
+opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+clouds = [torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in range(2)]
+batch = (clouds, [torch.from_numpy(S.virtual_points(i)).to(dev) for i in range(2)])
+target = torch.randn(2, 640, 180, 180, device=dev)
+depth = int(os.environ.get("MSMD_PREFETCH_DEPTH", "1"))
+sys.setswitchinterval(float(os.environ.get("MSMD_SWITCH_INTERVAL", "0.0005")))
+
+log = []
+orig = model.prepare
+
+
+def prepare(*a, **k):
+    t0 = time.perf_counter()
+    c0 = time.thread_time()
+    r = orig(*a, **k)
+    log.append(("prepare", threading.current_thread().name, t0, time.perf_counter(),
+                time.thread_time() - c0))
+    return r
+
+
+pf = IndexPrefetcher(prepare, dev, threaded=True, depth=depth)
+take0 = pf.take
+
+
+def take(ticket):
+    t0 = time.perf_counter()
+    r = take0(ticket)
+    log.append(("take", "main", t0, time.perf_counter(), 0.0))
+    return r
+
+
+pf.take = take
+step = D.TrainStep(model, params, opt, lambda bev: (bev * target).mean(), pf, 10.0)
+step.prime(batch)
+for _ in range(25):
+    step(batch)
+torch.cuda.synchronize()
+log.clear()
+N = 20
+t_start = time.perf_counter()
+marks = []
+for i in range(N):
+    a = time.perf_counter()
+    c = time.thread_time()
+    step(batch)
+    marks.append((a, time.perf_counter(), time.thread_time() - c))
+torch.cuda.synchronize()
+total = time.perf_counter() - t_start
+print("depth %d: %.2f ms/step (%.1f samples/s)" % (depth, total / N * 1e3, 2 * N / total))
+takes = [e for e in log if e[0] == "take"]
+preps = [e for e in log if e[0] == "prepare"]
+print("main thread per step: host %.2f ms wall (%.2f ms CPU), of which waiting for the prepared "
+      "batch %.2f ms" % (sum(b - a for a, b, _ in marks) / N * 1e3,
+                         sum(c for _, _, c in marks) / N * 1e3,
+                         sum(e[3] - e[2] for e in takes) / max(len(takes), 1) * 1e3))
+print("prepare() per call: %.2f ms wall, %.2f ms CPU  (%d calls)" % (
+    sum(e[3] - e[2] for e in preps) / max(len(preps), 1) * 1e3,
+    sum(e[4] for e in preps) / max(len(preps), 1) * 1e3, len(preps)))
+for e in sorted(log + [("step", "main", a, b, c) for a, b, c in marks], key=lambda e: e[2])[:24]:
+    print("  %-8s %-14s start %8.2f  dur %6.2f ms" % (e[0], e[1], (e[2] - t_start) * 1e3,
+                                                     (e[3] - e[2]) * 1e3))
