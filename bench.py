@@ -145,8 +145,9 @@ class FusionBackbone(torch.nn.Module):
         return self.path.prepare(points, [virtual] * 4, nn_side_stream=True)
 
     def forward(self, points, virtual, prepared=None):
-        x, x_mm = self.path(points, [virtual] * 4, prepared=prepared)
-        return torch.cat([x, x_mm], 1)
+        # cat([x, x_mm], 1) -- bev_fusion's input (MSMDFusion.py:440) -- as ONE
+        # channels-last map both sparse tensors scatter into (no dense()+view+cat)
+        return self.path(points, [virtual] * 4, prepared=prepared, joint_bev=True)
 
 
 def cpu_baseline(workload, seed=0, budget_s=14.0, max_samples=24):
@@ -213,6 +214,8 @@ def run_workload(workload, args, dev, rank, world, profile):
     if lc:
         batch = (clouds, [torch.from_numpy(S.virtual_points(i)).to(dev) for i in ids])
     target = torch.randn(spg, wl["bev_channels"], 180, 180, device=dev)
+    if lc:      # the LC path hands its BEV map over channels-last (see FusionBackbone.forward)
+        target = target.contiguous(memory_format=torch.channels_last)
 
     prefetch = None
     if os.environ.get("MSMD_PREFETCH", "1") == "1":

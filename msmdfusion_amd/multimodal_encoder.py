@@ -245,8 +245,7 @@ class SparseMultiModalEncoderPaint(nn.Module):
                 torch.empty((idx.shape[0], 0), dtype=torch.float32, device=dev), idx, shape,
                 batch_size)
 
-        def convs(block):
-            return [m for m in block.modules() if isinstance(m, spconv.SparseConvolution)]
+        convs = spconv.sparse_convs
 
         plan["dummy"] = self.dummy_embedding_fn(self.in_channels_3D[stage_id], dev)
         o3_idx = idx3_5.index_select(0, plan["only_3D_rows"])[:, zyx].contiguous()

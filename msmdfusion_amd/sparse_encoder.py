@@ -56,8 +56,7 @@ class SparseEncoder(nn.Module):
         planned = spconv.SparseConvTensor(
             torch.empty((coors.shape[0], 0), dtype=torch.float32, device=coors.device),
             coors.int(), self.sparse_shape, batch_size)
-        def convs(block):
-            return [m for m in block.modules() if isinstance(m, spconv.SparseConvolution)]
+        convs = spconv.sparse_convs
 
         # a frozen encoder over inputs that carry no gradient (the LC recipe) never runs
         # backward: no pair lists, no backward tilings

@@ -6,7 +6,8 @@ mmdet3d/models/detectors/MSMDFusion.py:15).  SURVEY Appendix C lists the surface
 from . import functional
 from .conv import ConvAlgo, SparseConv3d, SparseConvolution, SubMConv3d
 from .core import IndiceData, SparseConvTensor
-from .modules import SparseModule, SparseSequential, ToDense
+from .modules import SparseModule, SparseSequential, ToDense, sparse_convs
 
 __all__ = ["functional", "ConvAlgo", "SparseConv3d", "SparseConvolution", "SubMConv3d",
-           "IndiceData", "SparseConvTensor", "SparseModule", "SparseSequential", "ToDense"]
+           "IndiceData", "SparseConvTensor", "SparseModule", "SparseSequential", "ToDense",
+           "sparse_convs"]

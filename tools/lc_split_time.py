@@ -19,6 +19,8 @@ spg = 2 if lc else 4
 clouds = [torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in range(spg)]
 batch = (clouds, [torch.from_numpy(S.virtual_points(i)).to(dev) for i in range(spg)]) if lc else (clouds,)
 target = torch.randn(spg, 640 if lc else 256, 180, 180, device=dev)
+if lc:
+    target = target.contiguous(memory_format=torch.channels_last)
 
 
 def timed(fn, n=10, warm=6):
@@ -61,7 +63,7 @@ if lc:
     for _ in range(5):
         prep_side()
     torch.cuda.synchronize(); pr.disable()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(60)
     p = prep_side(); torch.cuda.synchronize()
     for _ in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter(); feature(p); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()

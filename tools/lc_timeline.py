@@ -26,12 +26,31 @@ params = [p for p in model.parameters() if p.requires_grad]
 opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
 clouds = [torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in range(2)]
 batch = (clouds, [torch.from_numpy(S.virtual_points(i)).to(dev) for i in range(2)])
-target = torch.randn(2, 640, 180, 180, device=dev)
+target = torch.randn(2, 640, 180, 180, device=dev).contiguous(memory_format=torch.channels_last)
 depth = int(os.environ.get("MSMD_PREFETCH_DEPTH", "1"))
 sys.setswitchinterval(float(os.environ.get("MSMD_SWITCH_INTERVAL", "0.0005")))
 
 log = []
 orig = model.prepare
+# wall time the prepare thread spends inside host reads (device round trips)
+waits = {"t": 0.0, "n": 0}
+_item, _tolist = torch.Tensor.item, torch.Tensor.tolist
+
+
+def _timed(fn):
+    def wrapper(self, *a, **k):
+        if threading.current_thread().name.startswith("msmd-index") and self.is_cuda:
+            t0 = time.perf_counter()
+            r = fn(self, *a, **k)
+            waits["t"] += time.perf_counter() - t0
+            waits["n"] += 1
+            return r
+        return fn(self, *a, **k)
+    return wrapper
+
+
+torch.Tensor.item = _timed(_item)
+torch.Tensor.tolist = _timed(_tolist)
 
 
 def prepare(*a, **k):
@@ -61,6 +80,7 @@ for _ in range(25):
     step(batch)
 torch.cuda.synchronize()
 log.clear()
+waits.update(t=0.0, n=0)
 N = 20
 t_start = time.perf_counter()
 marks = []
@@ -81,6 +101,8 @@ print("main thread per step: host %.2f ms wall (%.2f ms CPU), of which waiting f
 print("prepare() per call: %.2f ms wall, %.2f ms CPU  (%d calls)" % (
     sum(e[3] - e[2] for e in preps) / max(len(preps), 1) * 1e3,
     sum(e[4] for e in preps) / max(len(preps), 1) * 1e3, len(preps)))
+print("  of which inside host reads (.item/.tolist): %.2f ms per call, %.1f reads per call" % (
+    waits["t"] / max(len(preps), 1) * 1e3, waits["n"] / max(len(preps), 1)))
 for e in sorted(log + [("step", "main", a, b, c) for a, b, c in marks], key=lambda e: e[2])[:24]:
     print("  %-8s %-14s start %8.2f  dur %6.2f ms" % (e[0], e[1], (e[2] - t_start) * 1e3,
                                                      (e[3] - e[2]) * 1e3))
