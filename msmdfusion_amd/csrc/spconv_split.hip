@@ -1128,6 +1128,202 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_split_kernel(
   }
 }
 
+
+// The same kernel with a lean instruction stream (round 2).  The version above spends, per
+// 32-pair step and wave, 96 MFMAs against ~1000 other instructions: 58 branches and 440
+// register moves around its predicated 64-bit-address loads (zero rows for "no pair"),
+// 120 address operations, packed-fp32 residual subtractions.  Here the rows come through a
+// raw buffer descriptor with 32-bit byte offsets -- an absent pair or channel is an
+// out-of-range offset, which loads zeros without a branch, a move or any traffic -- and the
+// residuals are scalar subtractions (a v_pk_add_f32 beside MFMAs costs more than the two
+// v_sub_f32 it replaces, MI355X_MICROARCH.md).  Same operands, same products, same sums:
+// bit-identical partials.  Needs rows * channels * 4 < 4 GiB on both sides (32-bit offsets);
+// larger tensors take the pointer version.
+template <int NP, int GA>   // GA = 64-channel groups of c_in per slab (slab = 64*GA x 64)
+__global__ __launch_bounds__(256, GA == 1 ? 2 : 1) void spconv_wgrad_split_buf_kernel(
+    const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
+    const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
+    int kvol, float* __restrict__ partial /* [K][nchunks][cin][cout] */,
+    const int32_t* __restrict__ ranges /* [K][nchunks+1] or null: chunks of pair positions */,
+    int dbg /* ablations, wrong results: 1 rows folded onto 4096, 2 no loads, 4 no MFMAs;
+               8 = no priority raise around the MFMA burst (results unchanged) */) {
+  const bool prio = !(dbg & 8);
+  constexpr int CHUNK = kWgradSplitChunk, S = 4, TA = S * GA;
+  using P = Products<NP>;
+  __shared__ __attribute__((aligned(16))) char lds_raw[2 * TA * S * 64 * sizeof(f32x4)];
+  unsigned* s_in = (unsigned*)lds_raw;       // BYTE OFFSETS of the rows (or the OOB offset)
+  unsigned* s_out = s_in + CHUNK;
+  f32x4* red = (f32x4*)lds_raw;
+  static_assert(2 * CHUNK * sizeof(int) <= sizeof(lds_raw), "index arrays must fit");
+  const int NTs = (cout + 63) / 64;
+  int k, chunk, slab;
+  if (!wgrad_work(nchunks, kvol, ((cin + 64 * GA - 1) / (64 * GA)) * NTs, chunk, k, slab)) return;
+  int p_begin, cnt;
+  if (ranges) {     // the pairs of offset k whose OUTPUT row lies in chunk's row range
+    p_begin = ranges[(size_t)k * (nchunks + 1) + chunk];
+    cnt = ranges[(size_t)k * (nchunks + 1) + chunk + 1] - p_begin;   // <= CHUNK rows
+    if (cnt <= 0) return;                                            // (the reduction skips it)
+  } else {
+    const int Pk = num[k];
+    p_begin = chunk * CHUNK;
+    if (p_begin >= Pk) return;
+    cnt = (Pk - p_begin) < CHUNK ? (Pk - p_begin) : CHUNK;
+  }
+  const int sa = slab / NTs, sb = slab % NTs;
+  const int a0 = sa * 64 * GA, b0 = sb * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  {
+    const int32_t* pin = pairs + ((size_t)k * 2 + 0) * ld + p_begin;
+    const int32_t* pout = pairs + ((size_t)k * 2 + 1) * ld + p_begin;
+    const unsigned rowa = (unsigned)cin * 4u, rowb = (unsigned)cout * 4u;
+    for (int e = threadIdx.x; e < CHUNK; e += 256) {   // past the end: "no pair"
+      int ia = e < cnt ? pin[e] : -1, ib = e < cnt ? pout[e] : -1;
+      if (dbg & 1) { ia = ia < 0 ? ia : (ia & 4095); ib = ib < 0 ? ib : (ib & 4095); }
+      if (dbg & 2) { ia = -1; ib = -1; }
+      s_in[e] = ia >= 0 ? (unsigned)ia * rowa : kOobOffset;
+      s_out[e] = ib >= 0 ? (unsigned)ib * rowb : kOobOffset;
+    }
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rs_a =
+      __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)kOobOffset, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b =
+      __builtin_amdgcn_make_buffer_rsrc((void*)dout, 0, (int)kOobOffset, 0x00020000);
+  // this lane's channel offsets inside a row; lanes whose channels do not exist (partial
+  // slab) read out of range too (the sentinel is applied AFTER the add, so it cannot wrap
+  // back into range)
+  unsigned cola[GA];
+  bool in_a[GA];
+#pragma unroll
+  for (int ga = 0; ga < GA; ++ga) {
+    cola[ga] = (unsigned)(a0 + 64 * ga + 4 * i) * 4u;
+    in_a[ga] = a0 + 64 * ga + 4 * i < cin;
+  }
+  const unsigned colb = (unsigned)(b0 + 4 * i) * 4u;
+  const bool in_b = b0 + 4 * i < cout;
+
+  f32x4 acc[TA][S];
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < S; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[GA][8], rb[8];   // this lane's 8 pairs x 4 channels per group (fp32 bits)
+  auto fetch = [&](int step) {
+    const int e0 = 32 * step + 8 * g;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32x4 oa4 = *(const u32x4*)(s_in + e0 + 4 * h), ob4 = *(const u32x4*)(s_out + e0 + 4 * h);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+        for (int ga = 0; ga < GA; ++ga) {
+          const unsigned fa =
+              (oa4[s2] == kOobOffset || !in_a[ga]) ? kOobOffset : oa4[s2] + cola[ga];
+          ra[ga][4 * h + s2] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)fa, 0, 0);
+        }
+        const unsigned fb = (ob4[s2] == kOobOffset || !in_b) ? kOobOffset : ob4[s2] + colb;
+        rb[4 * h + s2] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)fb, 0, 0);
+      }
+    }
+  };
+  // raw [8 pairs][4 channels] -> op[tile = channel][plane] (8 slots each); the planes of
+  // (pair 2t, pair 2t+1) of one channel are dword t of that channel's operand
+  auto split_side = [&](const u32x4 (&r)[8], u32x4 (*op)[NP]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int a = 0; a < S; ++a) {
+        float v0 = __uint_as_float(r[2 * t][a]), v1 = __uint_as_float(r[2 * t + 1][a]);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+          unsigned hi;    // (asm: the builtin conversion first copies its inputs into a pair)
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+          op[a][pl][t] = hi;
+          if (pl + 1 < NP) {          // exact residuals; scalar on purpose (one v_pk_add_f32
+            v0 = v0 - __uint_as_float(hi << 16);          // measured slower than these two:
+            v1 = v1 - __uint_as_float(hi & 0xffff0000u);  // 404 against 370 us at 128x128)
+          }
+        }
+      }
+  };
+  const int n_steps = (cnt + 31) / 32;
+  if (wave < n_steps) fetch(wave);
+  for (int step = wave; step < n_steps; step += 4) {
+    u32x4 oa[TA][NP], ob[S][NP];
+#pragma unroll
+    for (int ga = 0; ga < GA; ++ga) split_side(ra[ga], oa + S * ga);
+    split_side(rb, ob);
+    if (step + 4 < n_steps) fetch(step + 4);   // in flight under the MFMAs below
+    if (dbg & 4) {   // keep the operands alive without multiplying
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) asm volatile("" ::"v"(oa[a][pl]));
+#pragma unroll
+      for (int b = 0; b < S; ++b)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) asm volatile("" ::"v"(ob[b][pl]));
+      continue;
+    }
+    // The conversion phase (VALU only) and this phase (MFMA only) of ONE wave cannot
+    // overlap, but the SIMD's other wave is free to convert while this one multiplies -- if
+    // the two are out of phase.  Raised priority for the MFMA burst makes that the stable
+    // state: the multiplying wave issues at full rate, the converting one takes the 12 of 16
+    // cycles each MFMA leaves the issue port idle.
+    if (prio) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+    for (int t = 0; t < P::n; ++t)
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < S; ++b)
+          acc[a][b] = mfma_bf16(oa[a][P::a[t]], ob[b][P::b[t]], acc[a][b]);
+    if (prio) __builtin_amdgcn_s_setprio(0);
+  }
+  // cross-wave sum, fixed tree order (w0+w2) + (w1+w3): deterministic
+  __syncthreads();   // everyone is done with the index arrays (red aliases them)
+  if (wave >= 2) {
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int b = 0; b < S; ++b) red[((wave - 2) * TA * S + a * S + b) * 64 + lane] = acc[a][b];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int b = 0; b < S; ++b) acc[a][b] += red[(wave * TA * S + a * S + b) * 64 + lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int b = 0; b < S; ++b) red[(a * S + b) * 64 + lane] = acc[a][b];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* dst = partial + ((size_t)k * nchunks + chunk) * cin * cout;
+    const int cb = b0 + 4 * i;
+#pragma unroll
+    for (int a = 0; a < TA; ++a) {
+      f32x4 v[S];
+#pragma unroll
+      for (int b = 0; b < S; ++b) v[b] = acc[a][b] + red[(a * S + b) * 64 + lane];
+      // tile a = 4*ga + ch: row 4g+r of the tile <-> channel a0 + 64*ga + 4*(4g+r) + ch
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = a0 + 64 * (a / S) + 4 * (4 * g + r) + (a % S);
+        if (ci < cin && cb < cout)
+          *(f32x4*)(dst + (size_t)ci * cout + cb) = (f32x4){v[0][r], v[1][r], v[2][r], v[3][r]};
+      }
+    }
+  }
+}
+
 }  // namespace
 }  // namespace msmd
 
@@ -1246,19 +1442,48 @@ MSMD_EXPORT int msmd_rulebook_permute_cols(const int32_t* nbr, int kvol, int ld,
 // caller finishes with that entry point's reduction (see msmd_spconv_wgrad_split
 // in spconv.hip).
 namespace msmd {
+static thread_local bool g_wgrad_ranges = false;
+bool wgrad_split_used_ranges() { return g_wgrad_ranges; }
 int wgrad_split_partials(const float* in_feat, int c_in, const float* d_out, int c_out,
                          const int32_t* pairs, const int32_t* num, int ld, int kvol, int np,
-                         int nchunks, float* ws, hipStream_t st) {
-  const dim3 grid(wgrad_grid(nchunks, kvol, ((c_in + 63) / 64) * ((c_out + 63) / 64)));
-  if (np == 3)
-    MSMD_LAUNCH(spconv_wgrad_split_kernel<3>, grid, dim3(256), 0, st, in_feat, c_in, d_out,
-                c_out, pairs, num, ld, nchunks, kvol, ws);
-  else if (np == 2)
-    MSMD_LAUNCH(spconv_wgrad_split_kernel<2>, grid, dim3(256), 0, st, in_feat, c_in, d_out,
-                c_out, pairs, num, ld, nchunks, kvol, ws);
-  else
-    MSMD_LAUNCH(spconv_wgrad_split_kernel<1>, grid, dim3(256), 0, st, in_feat, c_in, d_out,
-                c_out, pairs, num, ld, nchunks, kvol, ws);
+                         int nchunks, float* ws, int32_t* ranges, hipStream_t st) {
+  dim3 grid(wgrad_grid(nchunks, kvol, ((c_in + 63) / 64) * ((c_out + 63) / 64)));
+  // 32-bit row offsets (buffer loads) whenever both operands stay below 4 GiB
+  static const int buf_env = env_int2("MSMD_WGRAD_BUF", 1);
+  const bool buf = buf_env && (double)ld * 4.0 * (c_in > c_out ? c_in : c_out) < (double)kOobOffset;
+#define WG_LAUNCH(KERNEL, NPV)                                                                \
+  MSMD_LAUNCH(KERNEL<NPV>, grid, dim3(256), 0, st, in_feat, c_in, d_out, c_out, pairs, num, ld, \
+              nchunks, kvol, ws)
+  // 128 x 64 slabs (one wave per SIMD, accumulators in AGPRs) where c_in allows: the
+  // gathered bytes per MFMA drop by a quarter, and the gather rate is what bounds the kernel
+  static const int wide_env = env_int2("MSMD_WGRAD_WIDE", 0);   // measured slower, see DESIGN 8.2
+  static const int wdbg = env_int2("MSMD_WGRAD_DBG", 0);
+  const bool wide = buf && wide_env && c_in % 128 == 0;
+  if (wide) grid = dim3(wgrad_grid(nchunks, kvol, (c_in / 128) * ((c_out + 63) / 64)));
+#define WGB_LAUNCH(NPV)                                                                        \
+  do {                                                                                         \
+    if (wide)                                                                                  \
+      MSMD_LAUNCH((spconv_wgrad_split_buf_kernel<NPV, 2>), grid, dim3(256), 0, st, in_feat,    \
+                  c_in, d_out, c_out, pairs, num, ld, nchunks, kvol, ws, (const int32_t*)ranges, wdbg); \
+    else                                                                                       \
+      MSMD_LAUNCH((spconv_wgrad_split_buf_kernel<NPV, 1>), grid, dim3(256), 0, st, in_feat,    \
+                  c_in, d_out, c_out, pairs, num, ld, nchunks, kvol, ws, (const int32_t*)ranges, wdbg); \
+  } while (0)
+  g_wgrad_ranges = buf && ranges;
+  if (buf) {
+    if (ranges)
+      MSMD_LAUNCH(pair_ranges_kernel, dim3(ceil_div((long)kvol * (nchunks + 1), 256)), dim3(256),
+                  0, st, pairs, num, ld, kvol, kWgradSplitChunk, nchunks, ranges);
+    if (np == 3) WGB_LAUNCH(3);
+    else if (np == 2) WGB_LAUNCH(2);
+    else WGB_LAUNCH(1);
+  } else {
+    if (np == 3) WG_LAUNCH(spconv_wgrad_split_kernel, 3);
+    else if (np == 2) WG_LAUNCH(spconv_wgrad_split_kernel, 2);
+    else WG_LAUNCH(spconv_wgrad_split_kernel, 1);
+  }
+#undef WG_LAUNCH
+#undef WGB_LAUNCH
   return launch_status();
 }
 }  // namespace msmd

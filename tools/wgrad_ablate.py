@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Times the split wgrad kernel on LC-shaped layers (run under MSMD_WGRAD_DBG / MSMD_WGRAD_BUF
+/ MSMD_WGRAD_WIDE settings to ablate it; results are wrong by design with DBG != 0)."""
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from msmdfusion_amd import kernels as K  # noqa: E402
+from msmdfusion_amd import synthetic as S  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+clouds = [torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in range(4)]
+res = K.hard_voxelize_batch(clouds, S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 120000,
+                            want_voxels=False, want_mean=True)
+idx = torch.cat([F.pad(r[1], (1, 0), value=i) for i, r in enumerate(res)]).contiguous()
+shape = list(S.SPARSE_SHAPE)
+stages = []
+for pad in [1, 1, [0, 1, 1]]:
+    stages.append((idx, shape))
+    idx, _, _, shape = K.rulebook_conv(idx, 4, shape, 3, 2, pad)
+stages.append((idx, shape))
+out = []
+for si, cin, cout in [(2, 64, 64), (2, 128, 128), (3, 192, 192), (1, 96, 96)]:
+    idx, shape = stages[si]
+    n = idx.shape[0]
+    pairs, num = K.rulebook_pairs(K.rulebook_subm(idx, 4, shape, 3))
+    P = int(num.sum())
+    f, g = torch.randn(n, cin, device=dev), torch.randn(n, cout, device=dev)
+    t = timed(lambda: K.conv_wgrad_split(f, g, pairs, num, 3))
+    out.append("%d->%d %.0f us (%.0f TF)" % (cin, cout, t, 2.0 * P * cin * cout / t / 1e6))
+print("DBG=%s BUF=%s WIDE=%s | " % (os.environ.get("MSMD_WGRAD_DBG", "0"),
+                                   os.environ.get("MSMD_WGRAD_BUF", "1"),
+                                   os.environ.get("MSMD_WGRAD_WIDE", "0")) + " | ".join(out))
