@@ -1324,6 +1324,181 @@ __global__ __launch_bounds__(256, GA == 1 ? 2 : 1) void spconv_wgrad_split_buf_k
   }
 }
 
+
+// wgrad, 128 x 128 slabs with the operand conversion SHARED through LDS (round 2).
+// Ablating the lean kernel above (MSMD_WGRAD_DBG) shows its conversion phase alone is 52 %
+// of its time and adds to -- does not overlap with -- the MFMA phase: with 64 x 64 slabs
+// every wave converts 64 + 64 channels for 96 MFMAs, and each row of a 128-wide layer is
+// converted 2 x 27 times.  Here a workgroup owns a 128 x 128 slab and ALL four waves work on
+// the same 32-pair step: wave w gathers and converts ONE 64-channel unit (w = 0,1: the two
+// halves of c_in, w = 2,3: of c_out) and writes it to LDS in MFMA operand order (the lane's
+// own 16-byte operand pieces: lane-linear, conflict-free, no transposition); every wave
+// then reads the A unit and the B unit of its 64 x 64 quadrant.  Conversion work per MFMA
+// halves, and because it is independent of the current step's MFMAs it is interleaved with
+// them in program order (one MFMA, two conversion ops in its shadow): the conversion of step
+// s+1 and its LDS writes run under the MFMAs of step s.  Two barriers per step; two
+// workgroups per CU (64 KiB LDS each) fill each other's gaps.  Quadrants are disjoint: no
+// cross-wave reduction; partials and the final reduction as before.
+template <int NP>
+__global__ __launch_bounds__(256, 2) void spconv_wgrad_split_shared_kernel(
+    const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
+    const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
+    int kvol, float* __restrict__ partial /* [K][nchunks][cin][cout] */, int dbg) {
+  constexpr int CHUNK = kWgradSplitChunk, S = 4;
+  using P = Products<NP>;
+  __shared__ __attribute__((aligned(16))) char lds_raw[2 * CHUNK * sizeof(int) +
+                                                       4 * S * NP * 64 * sizeof(u32x4)];
+  unsigned* s_in = (unsigned*)lds_raw;       // BYTE OFFSETS of the rows (or the OOB offset)
+  unsigned* s_out = s_in + CHUNK;
+  u32x4* xch = (u32x4*)(lds_raw + 2 * CHUNK * sizeof(int));   // [unit][tile][plane][lane]
+  const int NB = (cout + 127) / 128;
+  int k, chunk, slab;
+  if (!wgrad_work(nchunks, kvol, ((cin + 127) / 128) * NB, chunk, k, slab)) return;
+  const int Pk = num[k];
+  const int p_begin = chunk * CHUNK;
+  if (p_begin >= Pk) return;
+  const int cnt = (Pk - p_begin) < CHUNK ? (Pk - p_begin) : CHUNK;
+  const int a0 = (slab / NB) * 128, b0 = (slab % NB) * 128;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  {
+    const int32_t* pin = pairs + ((size_t)k * 2 + 0) * ld + p_begin;
+    const int32_t* pout = pairs + ((size_t)k * 2 + 1) * ld + p_begin;
+    const unsigned rowa = (unsigned)cin * 4u, rowb = (unsigned)cout * 4u;
+    for (int e = threadIdx.x; e < CHUNK; e += 256) {   // past the end: "no pair"
+      int ia = e < cnt ? pin[e] : -1, ib = e < cnt ? pout[e] : -1;
+      if (dbg & 1) { ia = ia < 0 ? ia : (ia & 4095); ib = ib < 0 ? ib : (ib & 4095); }
+      if (dbg & 2) { ia = -1; ib = -1; }
+      s_in[e] = ia >= 0 ? (unsigned)ia * rowa : kOobOffset;
+      s_out[e] = ib >= 0 ? (unsigned)ib * rowb : kOobOffset;
+    }
+  }
+  __syncthreads();
+  // converter role: unit = wave (0,1: halves of c_in; 2,3: halves of c_out)
+  const int side = wave >> 1, half = wave & 1;
+  const unsigned* s_off = side ? s_out : s_in;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(side ? dout : in), 0, (int)kOobOffset, 0x00020000);
+  const int c0 = (side ? b0 : a0) + 64 * half + 4 * i;
+  const bool in_c = c0 < (side ? cout : cin);
+  const unsigned col = (unsigned)c0 * 4u;
+  u32x4* xw = xch + (size_t)wave * S * NP * 64 + lane;
+  // multiplier role: quadrant (qa, qb)
+  const int qa = wave & 1, qb = wave >> 1;
+  const u32x4* xa = xch + (size_t)qa * S * NP * 64 + lane;
+  const u32x4* xb = xch + (size_t)(2 + qb) * S * NP * 64 + lane;
+  // an all-padding quadrant (partial last slab) has nothing to multiply
+  const bool live = a0 + 64 * qa < cin && b0 + 64 * qb < cout;
+  const bool mul = live && !(dbg & 4);
+
+  f32x4 acc[S][S];
+#pragma unroll
+  for (int a = 0; a < S; ++a)
+#pragma unroll
+    for (int b = 0; b < S; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto fetch = [&](u32x4 (&r)[8], int step) {
+    const int e0 = 32 * step + 8 * g;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32x4 o4 = *(const u32x4*)(s_off + e0 + 4 * h);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const unsigned f = (o4[s2] == kOobOffset || !in_c) ? kOobOffset : o4[s2] + col;
+        r[4 * h + s2] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)f, 0, 0);
+      }
+    }
+  };
+  // raw [8 pairs][4 channels] -> the unit's operands, written to LDS as they are produced
+  // (channel a = tile a; (pair 2t, 2t+1) = dword t; 16 bytes per (tile, plane))
+  auto convert_write = [&](const u32x4 (&r)[8]) {
+#pragma unroll
+    for (int a = 0; a < S; ++a) {
+      u32x4 op[NP];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float v0 = __uint_as_float(r[2 * t][a]), v1 = __uint_as_float(r[2 * t + 1][a]);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+          unsigned hi;
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+          op[pl][t] = hi;
+          if (pl + 1 < NP) {          // exact residuals, scalar on purpose
+            v0 = v0 - __uint_as_float(hi << 16);
+            v1 = v1 - __uint_as_float(hi & 0xffff0000u);
+          }
+        }
+      }
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) xw[(a * NP + pl) * 64] = op[pl];
+    }
+  };
+  u32x4 oa[S][NP], ob[S][NP];
+  auto read_ops = [&]() {
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+        oa[a][pl] = xa[(a * NP + pl) * 64];
+        ob[a][pl] = xb[(a * NP + pl) * 64];
+      }
+  };
+  const int n_steps = (cnt + 31) / 32;
+  u32x4 raw0[8], raw1[8];
+  // prologue: step 0 converted and published; steps 1 and 2 in flight
+  fetch(raw0, 0);
+  if (1 < n_steps) fetch(raw1, 1);
+  convert_write(raw0);
+  if (2 < n_steps) fetch(raw0, 2);
+  __syncthreads();
+  read_ops();
+  // one step: MFMAs of step s from (oa, ob), under them the conversion of step s+1 (from
+  // `cur`) into LDS; then the load of step s+3 into the buffer just consumed
+  auto step_body = [&](int s, u32x4 (&cur)[8]) {
+    __syncthreads();              // everyone holds step s in registers: LDS may be rewritten
+    const bool more = s + 1 < n_steps;
+    auto multiply = [&]() {
+#pragma unroll
+      for (int t = 0; t < P::n; ++t)
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+#pragma unroll
+          for (int b = 0; b < S; ++b)
+            acc[a][b] = mfma_bf16(oa[a][P::a[t]], ob[b][P::b[t]], acc[a][b]);
+    };
+    // (Interleaving the two in program order -- one MFMA, two conversion ops, via
+    // sched_group_barrier in a common basic block -- was tried: the forced order
+    // stretches the live ranges to 464 spilled registers.  Left to the hardware: the other
+    // workgroup's wave on this SIMD converts while this one multiplies.)
+    if (more) convert_write(cur);
+    if (mul) multiply();
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 3 < n_steps) fetch(cur, s + 3);
+    __syncthreads();              // step s+1 is published
+    if (more) read_ops();
+  };
+  for (int s = 0; s < n_steps; s += 2) {
+    step_body(s, raw1);
+    if (s + 1 < n_steps) step_body(s + 1, raw0);
+  }
+  if (live) {
+    float* dst = partial + ((size_t)k * nchunks + chunk) * cin * cout;
+    const int cb = b0 + 64 * qb + 4 * i;
+#pragma unroll
+    for (int a = 0; a < S; ++a) {
+      // D of tile (a,b): lane (col n = i, g) reg r -> ci = 4(4g+r) + a, co = 4n + b
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = a0 + 64 * qa + 4 * (4 * g + r) + a;
+        if (ci < cin && cb < cout)
+          *(f32x4*)(dst + (size_t)ci * cout + cb) =
+              (f32x4){acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+      }
+    }
+  }
+}
+
 }  // namespace
 }  // namespace msmd
 
@@ -1469,6 +1644,22 @@ int wgrad_split_partials(const float* in_feat, int c_in, const float* d_out, int
       MSMD_LAUNCH((spconv_wgrad_split_buf_kernel<NPV, 1>), grid, dim3(256), 0, st, in_feat,    \
                   c_in, d_out, c_out, pairs, num, ld, nchunks, kvol, ws, (const int32_t*)ranges, wdbg); \
   } while (0)
+  // 128 x 128 slabs with the conversion shared through LDS: both widths multiples of 128
+  static const int shared_env = env_int2("MSMD_WGRAD_SHARED", 0);   // 359 vs 369 us: not worth it
+  if (buf && shared_env && c_in % 128 == 0 && c_out % 128 == 0) {
+    g_wgrad_ranges = false;
+    const dim3 gs(wgrad_grid(nchunks, kvol, (c_in / 128) * (c_out / 128)));
+    if (np == 3)
+      MSMD_LAUNCH(spconv_wgrad_split_shared_kernel<3>, gs, dim3(256), 0, st, in_feat, c_in,
+                  d_out, c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
+    else if (np == 2)
+      MSMD_LAUNCH(spconv_wgrad_split_shared_kernel<2>, gs, dim3(256), 0, st, in_feat, c_in,
+                  d_out, c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
+    else
+      MSMD_LAUNCH(spconv_wgrad_split_shared_kernel<1>, gs, dim3(256), 0, st, in_feat, c_in,
+                  d_out, c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
+    return launch_status();
+  }
   g_wgrad_ranges = buf && ranges;
   if (buf) {
     if (ranges)
