@@ -150,6 +150,22 @@ class FusionBackbone(torch.nn.Module):
         return self.path(points, [virtual] * 4, prepared=prepared, joint_bev=True)
 
 
+def lc_worker_init(sample_ids, seed):
+    """Runs in the index worker process (msmdfusion_amd/prefetch_proc.py): the synthetic
+    data source and the index half of the LC step.  Weights play no part in prepare();
+    the model is built for its structure (conv lists, channel counts) only."""
+    from msmdfusion_amd import synthetic as S
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(seed)
+    model = FusionBackbone().to(dev).train()
+    clouds = [torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in sample_ids]
+    virt = [torch.from_numpy(S.virtual_points(i)).to(dev) for i in sample_ids]
+
+    def produce():
+        return model.prepare(clouds, virt)
+    return produce
+
+
 def cpu_baseline(workload, seed=0, budget_s=14.0, max_samples=24):
     """The host baseline on a bounded sample: whole synthetic samples through the
     oracle port (oracle/baseline.py), one after the other, until ~budget_s of CPU
@@ -224,8 +240,13 @@ def run_workload(workload, args, dev, rank, world, profile):
         threaded = os.environ.get("MSMD_PREFETCH_THREAD", "1" if lc else "0") == "1"
         if threaded:    # two threads share the GIL: hand it over promptly (default 5 ms)
             sys.setswitchinterval(float(os.environ.get("MSMD_SWITCH_INTERVAL", "0.0005")))
-        prefetch = IndexPrefetcher(model.prepare, dev, threaded=threaded,
-                                   depth=int(os.environ.get("MSMD_PREFETCH_DEPTH", "1")))
+        if lc and os.environ.get("MSMD_PREFETCH_PROC", "0") == "1":
+            # index work in a worker process: no interpreter lock shared with this loop
+            from msmdfusion_amd.prefetch_proc import ProcessPrefetcher
+            prefetch = ProcessPrefetcher(lc_worker_init, (list(ids), 0), dev)
+        else:
+            prefetch = IndexPrefetcher(model.prepare, dev, threaded=threaded,
+                                       depth=int(os.environ.get("MSMD_PREFETCH_DEPTH", "1")))
     # grad_clip max_norm=10 (config); the step structure is msmdfusion_amd.distributed.TrainStep
     step = D.TrainStep(net, params, opt, lambda bev: (bev * target).mean(), prefetch, 10.0)
     step.prime(batch)
@@ -283,6 +304,8 @@ def run_workload(workload, args, dev, rank, world, profile):
                       "parallelism": "dp%d" % world, "index_prefetch": prefetch is not None,
                       "trainable_params": sum(p.numel() for p in params)}}
     res["roofline"] = roofline(prof, workload) if prof else None
+    if hasattr(prefetch, "close"):
+        prefetch.close()
     del step, net, model, opt, prefetch
     torch.cuda.empty_cache()
     return res

@@ -320,3 +320,33 @@ def test_prefetched_step_through_ddp(dev):
             assert torch.equal(p.grad, w)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_process_prefetch_matches_inline_lc(dev):
+    """prepare() in a worker PROCESS (flat IPC buffers + pickled skeleton,
+    msmdfusion_amd/prefetch_proc.py) feeds the same feature pass as prepare() inline:
+    identical BEV map, gradients flow, several batches in a row."""
+    import proc_prefetch_helper as H
+    from msmdfusion_amd.prefetch_proc import ProcessPrefetcher
+    model = H.build_model(dev)
+    clouds, virt = H.make_batch(dev)
+    with torch.no_grad():
+        want = model(clouds, virt, prepared=model.prepare(clouds, virt))
+    pf = ProcessPrefetcher(H.init, (), dev)
+    try:
+        for it in range(3):
+            ticket = pf.submit()
+            prepared = pf.take(ticket)
+            if it < 2:
+                with torch.no_grad():
+                    got = model(clouds, virt, prepared=prepared)
+                assert torch.equal(got, want), it
+            else:
+                out = model(clouds, virt, prepared=prepared)
+                out.mean().backward()
+                assert any(p.grad is not None and p.grad.abs().sum() > 0
+                           for n, p in model.named_parameters() if "gate_control" in n)
+            pf.retire(ticket)
+    finally:
+        pf.close()
