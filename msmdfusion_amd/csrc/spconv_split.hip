@@ -347,6 +347,10 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
   constexpr int R = 2, kRows = WV * R * 16, kRowShift = WV == 4 ? 7 : 8;
   constexpr int kUnitU = NP * NT * 64;  // 16-byte units of one unit's weights (in LDS)
   constexpr int kWU = UB * kUnitU;
+#ifndef MSMD_FWD_EMBED
+#define MSMD_FWD_EMBED 0   // measured: 256 vs 258 us on 128->128 -- no gain, see MSMD_ITEM1
+#endif
+  constexpr bool kEmbedIssue = MSMD_FWD_EMBED != 0;   // see MSMD_ITEM1
   constexpr int kGr = R * 2;            // gather loads per unit per lane
   constexpr int kPw = (NP * NT + WV - 1) / WV;  // weight DMA ops per unit per wave
   constexpr int kWp = UB * kPw;           // ... per item per wave
@@ -548,9 +552,13 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
     // Multiply unit (it, u) from its converted rows `b`; meanwhile convert the
     // next unit's rows raw_n -> b_n, a quarter (4 channels of one row group) per
     // fragment step, interleaved with the MFMAs.
+    // `during(st)`: memory-op issue work the caller wants done UNDER this unit's MFMAs
+    // (called once per fragment step, between two MFMA groups; see MSMD_ITEM1)
     auto compute = [&](int it, int u, const u32x4 (&b)[R][NP], int valid,
-                       const u32x4 (&raw_n)[R][2], u32x4 (&b_n)[R][NP]) {
+                       const u32x4 (&raw_n)[R][2], u32x4 (&b_n)[R][NP], auto&& during) {
       if (!__any(valid >= 0) || (dbg & 4)) {
+#pragma unroll
+        for (int st = 0; st < NS; ++st) during(st);
         split_all(raw_n, b_n);
         return;
       }
@@ -583,6 +591,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
             for (int p = 0; p < NP; ++p)
               a[(st + 1) & 1][nn][p] = wb[(p * NT + 2 * (st + 1) + nn) * 64];
         }
+        during(st);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int qi = st * 4 / NS; qi < (st + 1) * 4 / NS; ++qi)
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
     else                                                                \
       wait_rows<kGr>(RAW_N);                                            \
     KP_MARK(4);                                                         \
-    compute((IT), (U), CV_C, v_cur, RAW_N, CV_N);                       \
+    compute((IT), (U), CV_C, v_cur, RAW_N, CV_N, [](int) {});           \
     KP_MARK(5);                                                         \
   }
 #define MSMD_SLOT_UNIT(IT, U, S)                                        \
@@ -673,13 +682,65 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
     if (UB > 2) { MSMD_SLOT_UNIT(IT, 2, (PH)*UB + 2) }                                 \
     if (UB > 3) { MSMD_SLOT_UNIT(IT, 3, (PH)*UB + 3) }                                 \
   }
+    // UB == 1 (one unit per item: the 96-128-channel layers).  Measured per item there
+    // (PROF build): top wait 785, barrier 206, weight-DMA issue 496, gather issue + index
+    // fetch 534, wait for rows 242, MFMAs + conversion 2047, glue 291 cycles -- the two
+    // issue phases are a quarter of the item and run BEFORE the MFMAs.  Nothing forces
+    // that: the weight buffer written is the OTHER one, the raw slot gathered into was
+    // vacated a unit ago, and the rows this unit converts were drained at the item top.  So
+    // here they are issued between the MFMA groups of the unit (fragment steps 0 and 1..),
+    // and the only wait left is the drain at the top (which covers what `wait_rows` waited
+    // for).  RESULT: correct (all split-conv tests), and no faster -- 256 against 258 us on the
+    // 128->128 layer in the same call: the issue cycles moved under the MFMAs stretch the
+    // MFMA stream by as much.  Compiled out by default (make EXTRA=-DMSMD_FWD_EMBED=1).
+#define MSMD_UNIT1(IT, RAW_C, V_C, CV_C, RAW_N, V_N, CV_N)                                  \
+  {                                                                                          \
+    const int v_cur = V_C;                                                                   \
+    wait_rows<0>(RAW_N);   /* (drained at the top; this ties the registers to that wait) */  \
+    compute((IT), 0, CV_C, v_cur, RAW_N, CV_N, [&](int st) {                                 \
+      if (st == 0) {                                                                         \
+        issue_g(RAW_C, V_C);                                                                 \
+        load_src();                                                                          \
+      } else if (st == 1) {                                                                  \
+        issue_w((IT) + 1);                                                                   \
+      }                                                                                      \
+    });                                                                                      \
+    KP_MARK(5);                                                                              \
+  }
+#define MSMD_ITEM1(IT, PH)                                                                  \
+  {                                                                                          \
+    if ((IT) == 1 && tid == 0) {                                                             \
+      ctl[2] = nxt_v;                                                                        \
+      ctl[tb ^ 1] = 0;                                                                       \
+      if (!sk && nxt_v == last_ticket) *tile_counter = 0;                                    \
+    }                                                                                        \
+    KP_MARK(6);                                                                              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
+    KP_MARK(0);                                                                              \
+    __builtin_amdgcn_s_barrier();                                                            \
+    KP_MARK(1);                                                                              \
+    if ((IT) == 1) {                                                                         \
+      nxt = __builtin_amdgcn_readfirstlane(ctl[2]);                                          \
+      if (nxt < tile_lim) stage_table(nxt, tb ^ 1);                                          \
+      staged = true;                                                                         \
+    }                                                                                        \
+    if ((PH) == 0) MSMD_UNIT1(IT, raw0, vr0, cv0, raw1, vr1, cv1)                            \
+    else MSMD_UNIT1(IT, raw1, vr1, cv1, raw0, vr0, cv0)                                      \
+  }
     KP_BEGIN();
 #ifdef MSMD_KERNEL_PROF
     const unsigned long long kt0 = wall_clock64();
 #endif
-    for (int it = 0; it < n_items; it += 2) {
-      MSMD_ITEM(it, 0);
-      if (it + 1 < n_items) MSMD_ITEM(it + 1, 1);
+    if constexpr (UB == 1 && NS >= 2 && kEmbedIssue) {
+      for (int it = 0; it < n_items; it += 2) {
+        MSMD_ITEM1(it, 0);
+        if (it + 1 < n_items) MSMD_ITEM1(it + 1, 1);
+      }
+    } else {
+      for (int it = 0; it < n_items; it += 2) {
+        MSMD_ITEM(it, 0);
+        if (it + 1 < n_items) MSMD_ITEM(it + 1, 1);
+      }
     }
 #ifdef MSMD_KERNEL_PROF
     if (lane == 0 && wave == 1 && blockIdx.x < 8) atomicAdd(&g_kprof[7], (unsigned long long)n_items);
