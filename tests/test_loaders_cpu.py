@@ -1,0 +1,101 @@
+"""Row f4: the virtual-point on-disk format and its loaders against outputs of the
+reference's own loader classes (tests/golden/loader_vectors.npz, made by
+tests/golden/make_loader_golden.py from the same synthetic files)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+import foreground_files as FF
+from msmdfusion_amd import loaders as L
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loader_vectors.npz")
+
+
+@pytest.fixture()
+def tree(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    return FF.make_tree("data", seed=5)
+
+
+def test_format_roundtrip(tmp_path):
+    rng = np.random.RandomState(0)
+    payload = FF._sweep_payload(rng)
+    path = str(tmp_path / "a" / L.FOREGROUND_DIR / "x.pcd.bin.pkl.npy")
+    L.save_foreground(path, *payload)
+    back = L.load_foreground(path)
+    assert sorted(back) == ["real_pixel_indices", "real_points", "virtual_pixel_indices",
+                            "virtual_points"]
+    for got, want in zip(back["virtual_pixel_indices"], payload[0]):
+        np.testing.assert_array_equal(got, want)
+    assert L.foreground_path("data/nuscenes/samples/LIDAR_TOP/f.pcd.bin") == \
+        "data/nuscenes/samples/%s/f.pcd.bin.pkl.npy" % L.FOREGROUND_DIR
+    assert L.foreground_path("/abs/sweeps/LIDAR_TOP/f.bin").startswith("/abs/sweeps/")
+
+
+def test_load_foreground2d_matches_the_reference(tree):
+    gold = np.load(GOLD)
+    res = L.LoadForeground2D()(copy.deepcopy(tree))
+    info = res["foreground2D_info"]
+    assert sorted(info) == ["fg_pixels", "fg_points", "fg_real_pixels", "fg_real_points"]
+    for key in info:
+        assert len(info[key]) == FF.CAMS
+        for cam, a in enumerate(info[key]):
+            want = gold["single_%s_%d" % (key, cam)]
+            assert a.shape == want.shape and a.dtype == want.dtype, (key, cam)
+            np.testing.assert_array_equal(a, want)
+    assert info["fg_points"][0].shape[1] == 15 and info["fg_pixels"][0].shape[1] == 3
+    # the camera without virtual points still carries its real ones
+    assert info["fg_pixels"][4].shape[0] == info["fg_real_pixels"][4].shape[0] > 0
+
+
+def test_multi_sweep_loader_matches_the_reference(tree):
+    gold = np.load(GOLD)
+    res = L.LoadForeground2D()(copy.deepcopy(tree))
+    res = L.LoadForeground2DFromMultiSweeps(sweeps_num=10)(res)
+    info = res["foreground2D_info"]
+    for key in ("fg_pixels", "fg_real_pixels", "fg_real_points"):
+        for cam, a in enumerate(info[key]):
+            np.testing.assert_array_equal(a, gold["multi_%s_%d" % (key, cam)])
+    for cam, p in enumerate(info["fg_points"]):
+        np.testing.assert_array_equal(p.tensor.numpy(), gold["multi_fg_points_%d" % cam])
+        assert p.points_dim == 15
+    # sweep 1 has no foreground file and is skipped; sweeps 0 and 2 are merged
+    single = L.LoadForeground2D()(copy.deepcopy(tree))["foreground2D_info"]
+    assert info["fg_pixels"][0].shape[0] > single["fg_pixels"][0].shape[0]
+    dts = np.unique(info["fg_points"][0].tensor.numpy()[:, -1])
+    assert dts.size == 3 and dts[0] == 0.0            # key frame + two sweeps
+    # test_mode / sweeps_num < available: the first sweeps_num sweeps, deterministically
+    res2 = L.LoadForeground2DFromMultiSweeps(sweeps_num=1, test_mode=True)(
+        L.LoadForeground2D()(copy.deepcopy(tree)))
+    n1 = res2["foreground2D_info"]["fg_pixels"][0].shape[0]
+    assert single["fg_pixels"][0].shape[0] < n1 < info["fg_pixels"][0].shape[0]
+
+
+def test_loader_output_feeds_pack_foreground(tree):
+    """The loaders' results are what image_glue.pack_foreground takes (here on CPU)."""
+    from msmdfusion_amd.image_glue import pack_foreground
+    res = L.LoadForeground2DFromMultiSweeps()(L.LoadForeground2D()(copy.deepcopy(tree)))
+    meta = dict(foreground2D_info=res["foreground2D_info"],
+                lidar2img=[np.eye(4, dtype=np.float32)] * FF.CAMS)
+    pack = pack_foreground([meta, meta], "cpu")
+    n = sum(p.shape[0] for p in res["foreground2D_info"]["fg_pixels"])
+    assert pack.pixels.shape == (2 * n, 3) and pack.points.shape == (2 * n, 15)
+    assert pack.sample_counts == [n, n] and pack.real_pixels.shape[1] == 3
+
+
+def test_kitti_branch_and_unknown_dataset(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.RandomState(1)
+    os.makedirs("kitti/training/virtual_1NN")
+    payload = dict(virtual_pixel_indices=rng.rand(7, 2), real_pixel_indices=rng.rand(4, 2),
+                   virtual_points=rng.rand(7, 6), real_points=rng.rand(4, 6))
+    with open("kitti/training/virtual_1NN/000012.npy", "wb") as f:
+        np.save(f, np.array(payload, dtype=object), allow_pickle=True)
+    res = L.LoadForeground2D("KittiDataset")(dict(pts_filename="kitti/training/velodyne/000012.bin"))
+    info = res["foreground2D_info"]
+    assert info["fg_pixels"][0].shape == (11, 2) and tuple(info["fg_points"][0].tensor.shape) == (11, 6)
+    np.testing.assert_array_equal(info["fg_pixels"][0][:7], payload["virtual_pixel_indices"])
+    with pytest.raises(NotImplementedError):
+        L.LoadForeground2D("WaymoDataset")(dict(pts_filename="a/b/c.bin"))
