@@ -1,0 +1,91 @@
+"""Dense 2-D convolutions on the sparse-conv kernels (msmdfusion_amd/grid_conv.py) against
+plain PyTorch fp32 convolutions, and SPPModuleRows against the reference's own SPPModule
+output (tests/golden/image_glue_vectors.npz)."""
+import numpy as np
+import pytest
+import torch
+from torch.nn import functional as F
+
+from msmdfusion_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+GEOMS = [  # cin, cout, k, stride, pad, dil, H, W
+    (64, 64, 3, 1, 1, 1, 20, 24),
+    (64, 96, 3, 1, 6, 6, 20, 24),        # dilated, 'same'
+    (128, 64, 1, 1, 0, 1, 12, 12),
+    (64, 128, 3, 2, 1, 1, 20, 24),       # strided: separate backward table
+    (32, 32, 5, 1, 2, 1, 9, 11),
+    (64, 64, 3, 1, 0, 1, 10, 10),        # 'valid': output smaller than input
+    (640, 256, 3, 1, 12, 12, 36, 36),    # an SPP branch
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,H,W", GEOMS)
+def test_grid_conv2d_matches_torch(dev, cin, cout, k, stride, pad, dil, H, W):
+    from msmdfusion_amd.grid_conv import grid_conv2d, map_of, rows_of
+    rng = np.random.RandomState(cin + k + dil)
+    B = 2
+    x = torch.from_numpy(rng.randn(B, cin, H, W).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rng.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)).to(dev)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    want = F.conv2d(xr, wr, None, stride, pad, dil)
+    g = torch.randn_like(want)
+    (want * g).sum().backward()
+
+    xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    rows, grid = rows_of(xa.contiguous(memory_format=torch.channels_last))
+    y, ogrid = grid_conv2d(rows, grid, wa, stride, pad, dil)
+    got = map_of(y, ogrid)
+    assert tuple(got.shape) == tuple(want.shape)
+    (got * g).sum().backward()
+
+    def close(a, b, tol):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= tol * scale + 1e-7, \
+            (float((a - b).abs().max()), scale)
+    close(got, want, 1e-5)            # fp32-equivalent (three bf16 planes)
+    close(xa.grad, xr.grad, 1e-5)
+    close(wa.grad, wr.grad, 2e-5)
+
+
+def test_spp_module_rows_is_the_reference_spp(dev):
+    from image_glue_fixture import Fixture
+    from msmdfusion_amd.bev import SPPModule
+    from msmdfusion_amd.grid_conv import SPPModuleRows
+    fx = Fixture()
+    spp = S.seeded_parameters(SPPModuleRows(), seed=13).to(dev).train()
+    assert sorted(spp.state_dict()) == sorted(SPPModule().state_dict())
+    x = torch.from_numpy(np.random.RandomState(14).standard_normal((2, 640, 12, 12))
+                         .astype(np.float32)).to(dev)
+    with torch.no_grad():
+        y = spp(x)
+    np.testing.assert_allclose(y.cpu().numpy(), fx.g["spp_y"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(spp.fuse[1].running_mean.cpu().numpy(),
+                               fx.g["spp_running_mean_fuse"], rtol=1e-4, atol=1e-6)
+
+
+def test_spp_module_rows_gradients(dev):
+    """Same parameters through MIOpen (bev.SPPModule) and through the row kernels:
+    outputs and gradients agree, on a channels-last input as bev_concat hands it over."""
+    import copy
+    from msmdfusion_amd.bev import SPPModule
+    from msmdfusion_amd.grid_conv import SPPModuleRows
+    rows_mod = S.seeded_parameters(SPPModuleRows(), seed=3).to(dev).train()
+    ref_mod = SPPModule().to(dev).train()
+    ref_mod.load_state_dict(copy.deepcopy(rows_mod.state_dict()))
+    x = torch.randn(2, 640, 30, 28, device=dev)
+    xa = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    ya, yb = rows_mod(xa), ref_mod(xb)
+    g = torch.randn_like(yb)
+    (ya * g).sum().backward()
+    (yb * g).sum().backward()
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+    assert rel(ya, yb) <= 1e-4
+    assert rel(xa.grad, xb.grad) <= 2e-3
+    for (na, pa), (nb, pb) in zip(rows_mod.named_parameters(), ref_mod.named_parameters()):
+        assert na == nb
+        assert rel(pa.grad, pb.grad) <= 5e-3, na

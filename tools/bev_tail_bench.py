@@ -64,6 +64,34 @@ def main():
                   % ("nhwc" if cl else "nchw", "bf16" if dt else "fp32", ms, timed(fwd, a.iters),
                      first), flush=True)
             del tail
+    # SPP alone: MIOpen fp32 / bf16 against the sparse-conv row kernels (fp32-equivalent)
+    from msmdfusion_amd.bev import SPPModule
+    from msmdfusion_amd.grid_conv import SPPModuleRows
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    for name, mod, xin, dt in [("MIOpen fp32 nchw", SPPModule(), x, None),
+                               ("MIOpen bf16 nchw", SPPModule(), x, torch.bfloat16),
+                               ("row kernels (3 bf16 planes)", SPPModuleRows(), xcl, None)]:
+        mod = mod.to(dev).train()
+
+        def step():
+            xi = xin.detach().requires_grad_(True)
+            if dt is None:
+                out = mod(xi)
+            else:
+                with torch.autocast("cuda", dtype=dt):
+                    out = mod(xi)
+            out.float().mean().backward()
+
+        def fwd():
+            with torch.no_grad():
+                if dt is None:
+                    mod(xin)
+                else:
+                    with torch.autocast("cuda", dtype=dt):
+                        mod(xin)
+        print("SPP alone  %-28s fwd+bwd %.2f ms  fwd %.2f ms" % (name, timed(step, a.iters),
+                                                                  timed(fwd, a.iters)), flush=True)
+        del mod
     # hand-over
     shape = [2, 180, 180]
     sp = []
