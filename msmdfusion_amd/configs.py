@@ -80,11 +80,21 @@ def build_hot_path(cfg):
     return vox, vfe, enc, mm
 
 
-def build_bev_tail(cfg, compute_dtype=None):
+def build_bev_tail(cfg, compute_dtype=None, rows=True):
     """bev_fusion (SPPModule, built without a config: MSMDFusion.py:130) +
-    pts_backbone + pts_neck of one of the dicts above."""
+    pts_backbone + pts_neck of one of the dicts above.  rows=True (default): the same
+    modules, same parameters and checkpoint keys, computed on channels-last pixel rows by
+    the sparse-conv kernels (grid_conv.py: fp32-equivalent, 1.7x MIOpen's fp32 on the SPP
+    block); rows=False: MIOpen, optionally under bf16 autocast (compute_dtype)."""
     from .bev import BevTail, SPPModule
     from .registry import build_backbone, build_neck
     m = cfg["model"]
-    return BevTail(SPPModule(), build_backbone(m["pts_backbone"]), build_neck(m["pts_neck"]),
-                   compute_dtype=compute_dtype)
+    if not rows:
+        return BevTail(SPPModule(), build_backbone(m["pts_backbone"]),
+                       build_neck(m["pts_neck"]), compute_dtype=compute_dtype)
+    from .grid_conv import SECONDFPNRows, SECONDRows, SPPModuleRows
+
+    def args(d):
+        return {k: v for k, v in d.items() if k != "type"}
+    return BevTail(SPPModuleRows(), SECONDRows(**args(m["pts_backbone"])),
+                   SECONDFPNRows(**args(m["pts_neck"])), compute_dtype=None)

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import kernels as K
-from .bev import SPPModule
+from .bev import SECOND, SECONDFPN, SPPModule
 from .spconv import functional as Fsp
 from .spconv.core import IndiceData
 
@@ -126,3 +126,85 @@ class SPPModuleRows(SPPModule):
                 for name, _, _, _ in self.BRANCHES]
         y, grid = conv_bn_relu_rows(self.fuse, torch.cat(outs, 1), grid)
         return map_of(y, grid)
+
+
+def deconv_rulebook(batch, height, width, stride, device="cuda"):
+    """ConvTranspose2d with kernel == stride (no overlap: second_fpn.py:46-52): output
+    pixel (Y, X) has exactly one contribution, input (Y // s, X // s) through kernel tap
+    (Y % s, X % s).  -> (rulebook, out_height, out_width), cached."""
+    s = int(stride)
+    device = torch.device(device)
+    key = (device, "deconv", batch, height, width, s)
+    hit = _TABLES.get(key)
+    if hit is not None:
+        return hit
+    ho, wo = height * s, width * s
+    b = torch.arange(batch, device=device).view(1, batch, 1, 1)
+    ky = torch.arange(s, device=device).repeat_interleave(s).view(-1, 1, 1, 1)
+    kx = torch.arange(s, device=device).repeat(s).view(-1, 1, 1, 1)
+    yo = torch.arange(ho, device=device).view(1, 1, ho, 1)
+    xo = torch.arange(wo, device=device).view(1, 1, 1, wo)
+    ok = (yo % s == ky) & (xo % s == kx)
+    fwd = torch.where(ok, (b * height + yo // s) * width + xo // s, -1)
+    yi = torch.arange(height, device=device).view(1, 1, height, 1)
+    xi = torch.arange(width, device=device).view(1, 1, 1, width)
+    bwd = (b * ho + yi * s + ky) * wo + xi * s + kx
+    n_in, n_out = batch * height * width, batch * ho * wo
+    rb = IndiceData(torch.empty((n_out, 0), dtype=torch.int32, device=device),
+                    torch.empty((n_in, 0), dtype=torch.int32, device=device),
+                    fwd.reshape(s * s, n_out).int().contiguous(),
+                    bwd.reshape(s * s, n_in).int().contiguous(), False,
+                    [1, height, width], [1, ho, wo], [1, s, s], [1, s, s], [0, 0, 0], [1, 1, 1])
+    _TABLES[key] = (rb, ho, wo)
+    return _TABLES[key]
+
+
+def grid_deconv2d(rows, grid, weight, stride):
+    """nn.ConvTranspose2d(kernel_size=stride, stride=stride, bias=False) on pixel rows;
+    weight is the torch parameter [Cin, Cout, s, s]."""
+    b, h, w = grid
+    s = int(stride[0] if isinstance(stride, (tuple, list)) else stride)
+    if tuple(weight.shape[2:]) != (s, s):
+        raise NotImplementedError("grid deconv: kernel_size == stride only")
+    rb, ho, wo = deconv_rulebook(b, h, w, s, rows.device)
+    c_in, c_out = weight.shape[0], weight.shape[1]
+    rb.prepare(torch.is_grad_enabled() and (weight.requires_grad or rows.requires_grad),
+               c_in, c_out)
+    kio = weight.permute(2, 3, 0, 1).reshape(s * s, c_in, c_out)      # [K, Cin, Cout]
+    return Fsp.sparse_conv(rows.contiguous(), kio.contiguous(), rb, krsc=False), (b, ho, wo)
+
+
+class SECONDRows(SECOND):
+    """bev.SECOND (backbones/second.py:9-88), same parameters and keys, on pixel rows."""
+
+    def forward(self, x):
+        rows, grid = rows_of(x)
+        rows = rows.contiguous()
+        outs = []
+        for block in self.blocks:
+            for j in range(0, len(block), 3):          # (conv, BN, ReLU) triples
+                rows, grid = conv_bn_relu_rows(block[j:j + 3], rows, grid)
+            outs.append(map_of(rows, grid))
+        return tuple(outs)
+
+
+class SECONDFPNRows(SECONDFPN):
+    """bev.SECONDFPN (necks/second_fpn.py:10-93) on pixel rows: 1x1 / strided convs through
+    grid_conv2d, kernel == stride transposed convs through grid_deconv2d."""
+
+    def forward(self, x):
+        if len(x) != len(self.in_channels):
+            raise ValueError("SECONDFPN got %d maps for %d levels" % (len(x), len(self.in_channels)))
+        ups = []
+        for xi, deblock in zip(x, self.deblocks):
+            rows, grid = rows_of(xi)
+            up, bn = deblock[0], deblock[1]
+            if isinstance(up, nn.ConvTranspose2d):
+                y, grid = grid_deconv2d(rows, grid, up.weight, up.stride)
+            else:
+                y, grid = grid_conv2d(rows, grid, up.weight, up.stride, up.padding, up.dilation)
+            ups.append((Fsp.bn_act(y, bn, relu=True), grid))
+        if any(g != ups[0][1] for _, g in ups):
+            raise ValueError("SECONDFPN levels end on different grids: %s" % [g for _, g in ups])
+        rows = torch.cat([u for u, _ in ups], 1) if len(ups) > 1 else ups[0][0]
+        return [map_of(rows, ups[0][1])]

@@ -121,8 +121,10 @@ def test_bev_tail_checkpoint_keys_and_shapes():
     Sequential(up, BN, ReLU); MSMDFusion.py:51-78 for SPPModule), built from the LC
     config's own dicts."""
     from msmdfusion_amd import configs as C
-    tail = C.build_bev_tail(C.MSMDFUSION_LC)
+    tail = C.build_bev_tail(C.MSMDFUSION_LC, rows=False)
     sd = tail.state_dict()
+    # the row-kernel variants are the same modules with another forward: same keys
+    assert sorted(C.build_bev_tail(C.MSMDFUSION_LC).state_dict()) == sorted(sd)
     want = []
     for br in ("conv1x1", "conv3x3", "dilated_conv3x3_rate6", "dilated_conv3x3_rate12", "fuse"):
         want += [f"bev_fusion.{br}.0.weight"] + _bn_keys(f"bev_fusion.{br}.1.")

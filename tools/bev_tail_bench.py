@@ -40,7 +40,7 @@ def main():
     x = torch.randn(B, 640, 180, 180, device=dev)
     for cl in (False, True):
         for dt in (None, torch.bfloat16):
-            tail = C.build_bev_tail(C.MSMDFUSION_LC, compute_dtype=dt)
+            tail = C.build_bev_tail(C.MSMDFUSION_LC, compute_dtype=dt, rows=False)
             tail.channels_last = cl
             if not cl:
                 tail = tail.to(memory_format=torch.contiguous_format)
@@ -64,6 +64,20 @@ def main():
                   % ("nhwc" if cl else "nchw", "bf16" if dt else "fp32", ms, timed(fwd, a.iters),
                      first), flush=True)
             del tail
+    # the whole tail on pixel rows (sparse-conv kernels, fp32-equivalent)
+    tail = C.build_bev_tail(C.MSMDFUSION_LC).to(dev).train()
+    xcl0 = x.contiguous(memory_format=torch.channels_last)
+
+    def step_rows():
+        xi = xcl0.detach().requires_grad_(True)
+        tail(xi)[0].mean().backward()
+
+    def fwd_rows():
+        with torch.no_grad():
+            tail(xcl0)
+    print("bev tail  on rows (sparse-conv kernels, 3 bf16 planes)  fwd+bwd %.2f ms  fwd %.2f ms"
+          % (timed(step_rows, a.iters), timed(fwd_rows, a.iters)), flush=True)
+    del tail
     # SPP alone: MIOpen fp32 / bf16 against the sparse-conv row kernels (fp32-equivalent)
     from msmdfusion_amd.bev import SPPModule
     from msmdfusion_amd.grid_conv import SPPModuleRows
