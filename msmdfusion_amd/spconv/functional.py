@@ -163,7 +163,10 @@ def _conv_forward(features, weight, rb, krsc, want_dgrad):
         if want_dgrad and _use_split(c_out, c_in, rb.nbr_fwd.shape[0], rb.n_out):
             # dgrad will want W^T packed: both images in this launch
             packed, packed_t = K.pack_weight_split_pair(weight, np_, krsc=krsc)
-        elif not weight.requires_grad:
+        elif not weight.requires_grad and isinstance(weight, torch.nn.Parameter):
+            # (module parameters only: the cache is keyed on the tensor object, and a
+            # temporary -- grid_conv's KRSC copy of a Conv2d weight -- is freed and its
+            # address and id reused by the next layer's copy of the same shape)
             packed = _pack_split_cached(weight, np_, krsc)
         else:
             packed = K.pack_weight_split(weight, np_, krsc=krsc)

@@ -131,4 +131,9 @@ def test_bev_tail_rows_end_to_end(dev):
     with torch.no_grad():
         ya, yb = rows(x)[0], ref(x)[0]
     assert tuple(ya.shape) == (2, 512, 36, 36)
-    assert float((ya - yb).norm() / yb.norm()) <= 2e-4
+    assert float((ya - yb).norm() / yb.norm()) <= 1e-3      # 25 layers, train-mode BN
+    # (no-grad forwards take the conv's bypass, where weights that do not require grad may
+    # come from the frozen-weight pack cache: it must never serve one layer's temporary
+    # KRSC copy to the next layer)
+    with torch.no_grad():
+        assert torch.equal(rows(x)[0], ya)
