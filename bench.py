@@ -52,6 +52,14 @@ WORKLOADS = {
              "virtual-point voxels + modality split + GMA-Conv + sparse_add + downscale -> BEV "
              "640ch), fwd+bwd+AdamW, 2 x (28.7k LiDAR + 50k virtual pts)/GPU, 0.075 m voxels, fp32",
         spg=MSMDFUSION_LC["samples_per_gpu"], bev_channels=640, settle=16),
+    "lc_tail": dict(
+        metric="samples/sec MSMDFusion fwd+bwd nuScenes 0.075m voxel (MSMDFusion-LC sparse "
+               "fusion path + dense BEV tail)",
+        name="configs[2] + row f1: the MSMDFusion-LC sparse path followed by bev_fusion "
+             "(SPPModule) + SECOND + SECONDFPN -> [B,512,180,180], the dense tail computed on "
+             "channels-last pixel rows by the sparse-conv kernels (fp32-equivalent), "
+             "fwd+bwd+AdamW, 2 x (28.7k LiDAR + 50k virtual pts)/GPU, fp32",
+        spg=MSMDFUSION_LC["samples_per_gpu"], bev_channels=512, settle=16),
     "transfusion_l": dict(
         metric="samples/sec TransFusion-L voxel backbone fwd+bwd (nuScenes 0.075m voxel)",
         name="configs[1]: TransFusion-L voxel backbone (voxelize+VFE+SparseEncoder->BEV), "
@@ -150,6 +158,19 @@ class FusionBackbone(torch.nn.Module):
         return self.path(points, [virtual] * 4, prepared=prepared, joint_bev=True)
 
 
+class FusionTailBackbone(FusionBackbone):
+    """FusionBackbone + the dense BEV tail (extract_pts_feat to its end,
+    MSMDFusion.py:440-447): bev_fusion, pts_backbone, pts_neck, trained."""
+
+    def __init__(self):
+        super().__init__()
+        from msmdfusion_amd.configs import build_bev_tail
+        self.tail = build_bev_tail(MSMDFUSION_LC)
+
+    def forward(self, points, virtual, prepared=None):
+        return self.tail(super().forward(points, virtual, prepared=prepared))[0]
+
+
 def lc_worker_init(sample_ids, seed):
     """Runs in the index worker process (msmdfusion_amd/prefetch_proc.py): the synthetic
     data source and the index half of the LC step.  Weights play no part in prepare();
@@ -213,10 +234,11 @@ def run_workload(workload, args, dev, rank, world, profile):
     from msmdfusion_amd.prefetch import IndexPrefetcher
 
     wl = WORKLOADS[workload]
-    lc = workload == "lc"
+    lc = workload in ("lc", "lc_tail")
     spg = wl["spg"]
     torch.manual_seed(0)
-    model = (FusionBackbone() if lc else Backbone()).to(dev).train()
+    model = (FusionTailBackbone() if workload == "lc_tail" else FusionBackbone() if lc
+             else Backbone()).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     net = D.wrap_data_parallel(model, device_ids=[dev.index])
     # AdamW lr=1e-4, wd=0.01: the configs' optimizer
@@ -347,6 +369,10 @@ def main():
         if not args.no_cpu_baseline:
             also["cpu_baseline"] = cpu_baseline("transfusion_l", budget_s=8.0)
         out["also"] = {"configs[1]": also}
+        if os.environ.get("MSMD_BENCH_TAIL", "1") == "1":
+            tail = run_workload("lc_tail", args, dev, rank, world, False)
+            tail["metric"] = WORKLOADS["lc_tail"]["metric"]
+            out["also"]["configs[2]+f1"] = tail
     if rank == 0:
         print(json.dumps(out))
     D.shutdown()
