@@ -5,19 +5,21 @@ attribute names, so its checkpoints load key for key
 (`bev_fusion.conv3x3.0.weight`, `pts_backbone.blocks.1.3.weight`,
 `pts_neck.deblocks.1.0.weight`, ...).
 
-These are plain dense 2-D convolutions over a 180x180 map -- MIOpen's work in
-this round (25 convolutions, 0.87 TFLOP forward at B=2).  Measured on MI355X,
-B=2, forward+backward (tools/bev_tail_bench.py, profiles/r02_bev_tail.txt):
+The classes here are the torch / MIOpen form of the three modules.  Measured on MI355X,
+B=2, [2,640,180,180] input, forward+backward (tools/bev_tail_bench.py,
+profiles/r02_bev_tail.txt; 0.87 TFLOP forward):
 
-    fp32  NCHW 30.1 ms   NHWC 34.7 ms      bf16 autocast  NCHW 13.3 ms   NHWC 13.4 ms
+    MIOpen fp32  NCHW 30.0 ms  NHWC 34.7 ms     MIOpen bf16 autocast  13.3 / 13.5 ms
+    msmdfusion_amd.grid_conv (same modules on pixel rows, sparse-conv kernels,
+    fp32-equivalent)                            19.7 ms   (SPP block alone: 12.2 against 21.5)
 
-so the default is NCHW fp32 (the reference's arithmetic); channels-last does not
-pay with this MIOpen build and is an option, not the default.  With
-channels_last=True the sparse side can hand over ONE [B,H,W,640] buffer that
-both sparse tensors scatter into (spconv.functional.bev_concat: 0.05 ms against
-0.24 ms for dense() + view + cat, 0.49 ms with the layout change).  13 ms at bf16
-is 8 % of the dense MFMA peak: a hand-written implicit-GEMM 3x3 kernel for the
-640->256 SPP branches is the obvious next step for this row.
+Channels-last does not pay with this MIOpen build; what does is running these dense
+convolutions on the sparse-conv kernels (grid_conv.py: a dense channels-last map is a sparse
+tensor with every cell active, its neighbour table is arithmetic on the pixel index), which
+`configs.build_bev_tail` therefore builds by default -- `SPPModuleRows`, `SECONDRows`,
+`SECONDFPNRows` subclass the modules below and share their parameters and checkpoint keys.
+The sparse side hands them ONE [B,H,W,640] buffer that both sparse tensors scatter into
+(spconv.functional.bev_concat: 0.05 ms against 0.24 ms for dense() + view + cat).
 """
 import torch
 from torch import nn
