@@ -397,10 +397,13 @@ def pmc_traffic(kernel_name, workload):
     if "NT=" in kernel_name:    # "spconv_fwd_split_kernel<NT=8>" -> "spconv_fwd_split_kernel<8, ..."
         nt = kernel_name.split("NT=")[1].rstrip(">")
         prefix = kernel_name.split("<")[0] + "<" + nt + ","
-    else:                       # wgrad: the widest instantiation present
-        prefix = kernel_name + "<"
-    cands = sorted(k for k in kernels if k.startswith(prefix))
-    key = cands[-1] if cands else None
+        cands = sorted(k for k in kernels if k.startswith(prefix))
+        key = cands[-1] if cands else None
+    else:   # wgrad: whichever instantiation of the split kernel ran most (the lean
+        #     buffer-load variant is spconv_wgrad_split_buf_kernel<planes, groups>)
+        stem = kernel_name.replace("_kernel", "")
+        cands = [k for k in kernels if k.startswith(stem)]
+        key = max(cands, key=lambda k: kernels[k].get("launches_sampled", 0)) if cands else None
     e = kernels.get(key, {})
     return e.get("hbm_bytes_per_launch"), e.get("mfma_pipe_busy_frac"), os.path.relpath(path, ROOT)
 
