@@ -52,6 +52,12 @@ WORKLOADS = {
              "virtual-point voxels + modality split + GMA-Conv + sparse_add + downscale -> BEV "
              "640ch), fwd+bwd+AdamW, 2 x (28.7k LiDAR + 50k virtual pts)/GPU, 0.075 m voxels, fp32",
         spg=MSMDFUSION_LC["samples_per_gpu"], bev_channels=640, settle=16),
+    "lc_b4": dict(
+        metric="samples/sec MSMDFusion fwd+bwd nuScenes 0.075m voxel (MSMDFusion-LC sparse "
+               "fusion path, 4 samples per GPU)",
+        name="configs[2] at configs[3]'s per-GPU batch (batch_size=4/GPU): MSMDFusion-LC sparse "
+             "path, fwd+bwd+AdamW, 4 x (28.7k LiDAR + 50k virtual pts)/GPU, 0.075 m voxels, fp32",
+        spg=4, bev_channels=640, settle=16),
     "lc_tail": dict(
         metric="samples/sec MSMDFusion fwd+bwd nuScenes 0.075m voxel (MSMDFusion-LC sparse "
                "fusion path + dense BEV tail)",
@@ -197,7 +203,7 @@ def cpu_baseline(workload, seed=0, budget_s=14.0, max_samples=24):
     # memory-bound gather/scatter loops stop scaling well before the socket is
     # full (256 hardware threads were slower than 8 here): cap at 32
     cores = O.set_threads(min(os.cpu_count() or 1, 32))
-    one = B.lc_sample if workload == "lc" else B.transfusion_l_sample
+    one = B.lc_sample if workload.startswith("lc") else B.transfusion_l_sample
     runs = []
     t_all = time.perf_counter()
     while len(runs) < max_samples and (time.perf_counter() - t_all < budget_s or len(runs) < 2):
@@ -234,7 +240,7 @@ def run_workload(workload, args, dev, rank, world, profile):
     from msmdfusion_amd.prefetch import IndexPrefetcher
 
     wl = WORKLOADS[workload]
-    lc = workload in ("lc", "lc_tail")
+    lc = workload in ("lc", "lc_tail", "lc_b4")
     spg = wl["spg"]
     torch.manual_seed(0)
     model = (FusionTailBackbone() if workload == "lc_tail" else FusionBackbone() if lc
@@ -373,6 +379,9 @@ def main():
             tail = run_workload("lc_tail", args, dev, rank, world, False)
             tail["metric"] = WORKLOADS["lc_tail"]["metric"]
             out["also"]["configs[2]+f1"] = tail
+            b4 = run_workload("lc_b4", args, dev, rank, world, False)
+            b4["metric"] = WORKLOADS["lc_b4"]["metric"]
+            out["also"]["configs[2] @ 4/GPU"] = b4
     if rank == 0:
         print(json.dumps(out))
     D.shutdown()
