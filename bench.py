@@ -211,7 +211,7 @@ def cpu_baseline(workload, seed=0, budget_s=14.0, max_samples=24):
     timed = runs[1:] if len(runs) > 1 else runs
     secs = sum(r["seconds"] for r in timed)
     r = timed[-1]
-    if workload == "lc":
+    if workload.startswith("lc"):
         what = ("LiDAR voxelize + rulebooks + 21 encoder convs fwd (frozen), 4-scale virtual-point "
                 "voxelize + mean VFE, modality split, FPS/ball-query neighbour search, gates, 16 "
                 "fusion-stack convs fwd+dgrad+wgrad + sparse_add; %.1f GMAC fwd (%.1f in the "
