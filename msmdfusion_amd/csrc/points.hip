@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
 }
 
 // nearest key: grid (query blocks, key chunks); packed (dist bits, key) min.
-constexpr int kNnChunk = 4096;
+constexpr int kNnChunk = 1024;   // keys per block: one LDS tile; 4096 left most CUs idle (80 blocks)
 __global__ __launch_bounds__(256) void nn_partial(const int32_t* __restrict__ q, int nq,
                                                   const int32_t* __restrict__ key, int nk,
                                                   unsigned long long* best) {
