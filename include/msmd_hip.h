@@ -315,6 +315,16 @@ int msmd_rulebook_tiling(const int32_t* nbr, int kernel_volume, int n_rows,
                          int32_t* tiled /* [K,n_rows] or NULL */, void* workspace,
                          size_t workspace_bytes, msmd_stream_t stream);
 
+/* msmd_rulebook_tiling + msmd_rulebook_tile_prefix (128- and/or 256-row tiles; NULL to
+ * skip) + msmd_rulebook_pairs (indice_pairs NULL to skip) of one table in one call: same
+ * results, one host call instead of four (the index pass is host-bound). */
+size_t msmd_rulebook_plan_workspace_bytes(int kernel_volume, int n_rows, int rows_per_tile);
+int msmd_rulebook_plan(const int32_t* nbr, int kernel_volume, int n_rows,
+                       int rows_per_tile, int32_t* order, int32_t* tiled,
+                       int32_t* prefix128, int32_t* prefix256, int32_t* indice_pairs,
+                       int ld, int32_t* indice_num, void* workspace,
+                       size_t workspace_bytes, msmd_stream_t stream);
+
 int msmd_rulebook_tile_costs(const int32_t* nbr /* [K,n_rows] */, int kernel_volume,
                              int n_rows, const int32_t* order, int rows_per_tile,
                              int32_t* cost /* [ceil(n_rows / rows_per_tile)] */,

@@ -128,3 +128,46 @@ MSMD_EXPORT int msmd_rulebook_tiling(const int32_t* nbr, int kernel_volume, int 
               w.sorted, w.tile_seq, full > 1 ? full : 0, rows_per_tile, zigzag, order, tiled);
   return launch_status();
 }
+
+
+// ---------------------------------------------------------------------------------------
+// Everything the conv kernels want derived from ONE neighbour table, in one call: tiling
+// order + table in tile order (msmd_rulebook_tiling), the stream-K prefixes for the tile
+// heights in use (msmd_rulebook_tile_prefix: 128 and/or 256 rows), the reference pair lists
+// for wgrad (msmd_rulebook_pairs).  Same results as the separate entry points; what it
+// saves is host time in the index pass (the LC step is bound by the interpreter: four
+// Python-level calls and a dozen allocations per table become one call).
+MSMD_EXPORT size_t msmd_rulebook_plan_workspace_bytes(int kernel_volume, int n_rows,
+                                                      int rows_per_tile) {
+  return align_up(msmd_rulebook_tiling_workspace_bytes(n_rows, rows_per_tile)) +
+         align_up(msmd_rulebook_pairs_workspace_bytes(kernel_volume, n_rows));
+}
+
+MSMD_EXPORT int msmd_rulebook_plan(const int32_t* nbr, int kernel_volume, int n_rows,
+                                   int rows_per_tile, int32_t* order, int32_t* tiled,
+                                   int32_t* prefix128, int32_t* prefix256, int32_t* indice_pairs,
+                                   int ld, int32_t* indice_num, void* workspace,
+                                   size_t workspace_bytes, msmd_stream_t stream) {
+  if (!nbr || kernel_volume < 1 || n_rows < 1 || !order || !tiled) return MSMD_ERR_INVALID_ARG;
+  const size_t t_bytes = align_up(msmd_rulebook_tiling_workspace_bytes(n_rows, rows_per_tile));
+  const size_t p_bytes = align_up(msmd_rulebook_pairs_workspace_bytes(kernel_volume, n_rows));
+  if (workspace_bytes < t_bytes + (indice_pairs ? p_bytes : 0) || ((uintptr_t)workspace & 255))
+    return MSMD_ERR_WORKSPACE;
+  int rc = msmd_rulebook_tiling(nbr, kernel_volume, n_rows, rows_per_tile, order, tiled,
+                                workspace, t_bytes, stream);
+  if (rc) return rc;
+  if (prefix128) {
+    rc = msmd_rulebook_tile_prefix(tiled, kernel_volume, n_rows, n_rows, 128, prefix128, stream);
+    if (rc) return rc;
+  }
+  if (prefix256) {
+    rc = msmd_rulebook_tile_prefix(tiled, kernel_volume, n_rows, n_rows, 256, prefix256, stream);
+    if (rc) return rc;
+  }
+  if (indice_pairs) {
+    if (!indice_num || ld < n_rows) return MSMD_ERR_INVALID_ARG;
+    rc = msmd_rulebook_pairs(nbr, kernel_volume, n_rows, indice_pairs, ld, indice_num,
+                             (char*)workspace + t_bytes, p_bytes, stream);
+  }
+  return rc;
+}

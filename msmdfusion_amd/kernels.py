@@ -300,6 +300,34 @@ def rulebook_tiling(nbr, want_table=True):
     return order, tiled
 
 
+def rulebook_plan(nbr, tile_rows=(), want_pairs=False, ld=None):
+    """rulebook_tiling + tile_prefix (for each height in tile_rows, 128 / 256) +
+    rulebook_pairs of one table in ONE library call.
+    -> dict(order, tiled, prefix={rows: tensor}, pairs=(pairs, num) | None)"""
+    _need_cuda(nbr)
+    kvol, n = nbr.shape
+    t = nbr.contiguous()
+    dev = t.device
+    order = torch.empty((n,), dtype=torch.int32, device=dev)
+    tiled = torch.empty_like(t)
+    pre = {r: torch.empty(((n + r - 1) // r + 1,), dtype=torch.int32, device=dev)
+           for r in set(tile_rows)}
+    if any(r not in (128, 256) for r in pre):
+        raise ValueError("tile heights are 128 or 256 rows")
+    pairs = num = None
+    ld = n if ld is None else int(ld)
+    if want_pairs:
+        pairs = torch.empty((kvol, 2, ld), dtype=torch.int32, device=dev)
+        num = torch.empty((kvol,), dtype=torch.int32, device=dev)
+    nbytes = lib.msmd_rulebook_plan_workspace_bytes(kvol, n, TILE_ROWS)
+    ws = _ws(nbytes, dev)
+    check(lib.msmd_rulebook_plan(_p(t), kvol, n, TILE_ROWS, _p(order), _p(tiled), _p(pre.get(128)),
+                                 _p(pre.get(256)), _p(pairs), ld, _p(num), _p(ws), nbytes,
+                                 _stream()), "msmd_rulebook_plan")
+    return dict(order=order, tiled=tiled, prefix=pre,
+                pairs=(pairs, num) if want_pairs else None)
+
+
 _TILE_COUNTERS = {}
 
 

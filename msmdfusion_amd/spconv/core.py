@@ -57,11 +57,33 @@ class IndiceData:
         weight gradient will be needed and, for a conv of c_in -> c_out channels,
         the tiling order / tile-ordered table its kernels will ask for -- so that
         the feature pass enqueues no index work and never waits on the host."""
-        if need_grad:
-            self.pairs()
         if c_in is not None:
             from .functional import _use_split, _wants_order
             kvol = self.nbr_fwd.shape[0]
+            # one library call for what the split kernels want from each table (tiling
+            # order, table in tile order, stream-K prefix, pair lists) instead of four:
+            # the index pass is bound by host time (DESIGN.md 8.5)
+            fwd_split = _use_split(c_in, c_out, kvol, self.n_in)
+            bwd_split = need_grad and _use_split(c_out, c_in, kvol, self.n_out)
+            if kvol <= 31 and self.n_out > 0 and self._tiled_fwd is None and \
+                    (fwd_split or (bwd_split and self.is_subm)):
+                rows = {K.split_tile_rows(c_out)} if fwd_split else set()
+                if bwd_split and self.is_subm:
+                    rows.add(K.split_tile_rows(c_in))
+                plan = K.rulebook_plan(self.nbr_fwd, rows, need_grad and self._pairs is None,
+                                       ld=max(self.n_in, self.n_out, 1))
+                self._order_fwd, self._tiled_fwd = (plan["order"],), (plan["tiled"],)
+                self._prefix_fwd.update(plan["prefix"])
+                if plan["pairs"] is not None:
+                    self._pairs = plan["pairs"]
+            if bwd_split and not self.is_subm and kvol <= 31 and self.n_in > 0 and \
+                    self._tiled_bwd is None:
+                plan = K.rulebook_plan(self.nbr_bwd, {K.split_tile_rows(c_in)})
+                self._order_bwd, self._tiled_bwd = (plan["order"],), (plan["tiled"],)
+                self._prefix_bwd.update(plan["prefix"])
+        if need_grad:
+            self.pairs()
+        if c_in is not None:
             if _use_split(c_in, c_out, kvol, self.n_in):
                 self.prefix_fwd(c_out)
             elif _wants_order(c_in, c_out):
