@@ -382,6 +382,19 @@ def main():
             b4 = run_workload("lc_b4", args, dev, rank, world, False)
             b4["metric"] = WORKLOADS["lc_b4"]["metric"]
             out["also"]["configs[2] @ 4/GPU"] = b4
+            # BASELINE.json's configs[2] names bf16: the same path with plain bf16 conv
+            # operands (one plane, one product; fp32 accumulation, features / BN / BEV stay
+            # fp32 in HBM) -- a second line, the headline keeps the reference's fp32 arithmetic
+            os.environ["MSMD_CONV_PLANES"] = "1"
+            try:
+                for key, wl in (("configs[2] bf16 operands", "lc"),
+                                ("configs[2] @ 4/GPU bf16 operands", "lc_b4")):
+                    r = run_workload(wl, args, dev, rank, world, False)
+                    r["metric"] = WORKLOADS[wl]["metric"]
+                    r["dtype"] = "bf16 conv operands, f32 accumulate and storage"
+                    out["also"][key] = r
+            finally:
+                os.environ.pop("MSMD_CONV_PLANES", None)
     if rank == 0:
         print(json.dumps(out))
     D.shutdown()

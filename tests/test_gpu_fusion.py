@@ -350,3 +350,29 @@ def test_process_prefetch_matches_inline_lc(dev):
             pf.retire(ticket)
     finally:
         pf.close()
+
+
+@pytest.mark.gpu
+def test_lc_path_bf16_operands(dev, monkeypatch):
+    """BASELINE configs[2] names bf16: MSMD_CONV_PLANES=1 runs every split conv of the LC
+    path (encoder + fusion stack, forward, dgrad, wgrad) on plain bf16 operands with fp32
+    accumulation.  Same voxel sets and row order as the fp32-equivalent default (the index
+    pass does not depend on it); features within bf16 rounding of it; finite gradients."""
+    import proc_prefetch_helper as H
+    model = H.build_model(dev)
+    clouds, virt = H.make_batch(dev)
+    prepared = model.prepare(clouds, virt)
+    with torch.no_grad():
+        want = model(clouds, virt, prepared=prepared)
+    monkeypatch.setenv("MSMD_CONV_PLANES", "1")
+    with torch.no_grad():
+        got = model(clouds, virt, prepared=model.prepare(clouds, virt))
+    assert got.shape == want.shape
+    assert torch.equal(got != 0, want != 0) or \
+        float(((got != 0) != (want != 0)).float().mean()) < 1e-3     # same occupied cells
+    rel = float((got - want).norm() / want.norm())
+    assert 1e-5 < rel < 3e-2, rel          # bf16 operands: ~2^-9 per product, 30 layers deep
+    out = model(clouds, virt, prepared=model.prepare(clouds, virt))
+    out.mean().backward()
+    grads = [p.grad for n, p in model.named_parameters() if p.grad is not None]
+    assert grads and all(torch.isfinite(g).all() for g in grads)
