@@ -206,10 +206,9 @@ class SparseFusionPath(nn.Module):
         return x, mm_dense.view(n, c * d, h, w)
 
     def _side_stream(self, device, stage=0):
-        pool = getattr(self, "_side", None)
-        if pool is None or pool[0].device != device:
-            # high priority: the FPS workgroups are 1024 threads x 128 registers -- a whole
-            # CU each -- and must win the CU when one drains between the main stream's
-            # chip-filling persistent kernels, or the search starts late
-            pool = self._side = [torch.cuda.Stream(device=device, priority=-1) for _ in range(4)]
-        return pool[stage]
+        # high priority: the FPS workgroups are 1024 threads x 128 registers -- a whole
+        # CU each -- and must win the CU when one drains between the main stream's
+        # chip-filling persistent kernels, or the search starts late.  Process-wide
+        # streams (slots 8..11; the prefetcher owns the low slots): see prefetch.side_stream
+        from .prefetch import side_stream
+        return side_stream(device, -1, slot=8 + stage)

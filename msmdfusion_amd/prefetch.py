@@ -19,6 +19,24 @@ from concurrent.futures import ThreadPoolExecutor
 import torch
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, priority=-1, slot=0):
+    """Process-wide side streams, created once per (device, priority, slot).  torch hands
+    out streams from a pool of 32 per priority, round robin: objects that each create their
+    own (one prefetcher + four search streams per model) start to ALIAS after a few models
+    have lived in the process, and two chains that were meant to overlap serialise on one
+    queue (bench.py's later workloads ran up to 40 % slower than the same workload first)."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           int(priority), int(slot))
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
+    return s
+
+
 class IndexPrefetcher:
 
     def __init__(self, prepare_fn, device, priority=-1, threaded=True, depth=1):
@@ -41,8 +59,8 @@ class IndexPrefetcher:
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
         self.depth = max(int(depth), 1) if threaded else 1
-        self._sides = [torch.cuda.Stream(device=self.device, priority=priority)
-                       for _ in range(self.depth)] if self.on_gpu else [None]
+        self._sides = [side_stream(self.device, priority, slot=i)
+                       for i in range(self.depth)] if self.on_gpu else [None]
         self.side = self._sides[0]
         self._next = 0
         self._retired = collections.deque()
