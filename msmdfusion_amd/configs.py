@@ -30,6 +30,21 @@ _PTS_NECK = dict(type="SECONDFPN", in_channels=[128, 256], out_channels=[256, 25
                  upsample_strides=[1, 2], norm_cfg=_BN2D,
                  upsample_cfg=dict(type="deconv", bias=False), use_conv_for_no_stride=True)
 
+_OUT_SIZE_FACTOR = 8
+_PTS_BBOX_HEAD = dict(
+    type="TransFusionHead", num_proposals=200, auxiliary=True, in_channels=256 * 2,
+    hidden_channel=128, num_classes=10, num_decoder_layers=1, num_heads=8,
+    learnable_query_pos=False, initialize_by_heatmap=True, nms_kernel_size=3, ffn_channel=256,
+    dropout=0.1, bn_momentum=0.1, activation="relu",
+    common_heads=dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2)),
+    bbox_coder=dict(type="TransFusionBBoxCoder", pc_range=POINT_CLOUD_RANGE[:2],
+                    voxel_size=VOXEL_SIZE[:2], out_size_factor=_OUT_SIZE_FACTOR,
+                    post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+                    score_threshold=0.0, code_size=10))
+_TEST_CFG_PTS = dict(dataset="nuScenes", grid_size=[1440, 1440, 40],
+                     out_size_factor=_OUT_SIZE_FACTOR, pc_range=POINT_CLOUD_RANGE[0:2],
+                     voxel_size=VOXEL_SIZE[:2], nms_type=None)
+
 TRANSFUSION_L = dict(
     model=dict(type="TransFusionDetector", pts_voxel_layer=_PTS_VOXEL_LAYER,
                pts_voxel_encoder=_PTS_VOXEL_ENCODER, pts_middle_encoder=_PTS_MIDDLE_ENCODER,
@@ -98,3 +113,11 @@ def build_bev_tail(cfg, compute_dtype=None, rows=True):
         return {k: v for k, v in d.items() if k != "type"}
     return BevTail(SPPModuleRows(), SECONDRows(**args(m["pts_backbone"])),
                    SECONDFPNRows(**args(m["pts_neck"])), compute_dtype=None)
+
+
+def build_head(cfg=None, rows=False):
+    """pts_bbox_head of configs/MSMDFusion_nusc_voxel_LC.py:207-241 with its test_cfg
+    (:260-268): TransFusionHead, LiDAR branch (msmdfusion_amd/head.py)."""
+    from .head import TransFusionHead
+    args = {k: v for k, v in _PTS_BBOX_HEAD.items() if k != "type"}
+    return TransFusionHead(test_cfg=dict(_TEST_CFG_PTS), rows=rows, **args)

@@ -137,3 +137,32 @@ def test_bev_tail_rows_end_to_end(dev):
     # KRSC copy to the next layer)
     with torch.no_grad():
         assert torch.equal(rows(x)[0], ya)
+
+
+def test_head_on_gpu_after_the_row_tail(dev):
+    """LC config end of the chain: joint BEV map -> tail on rows -> TransFusionHead (its
+    512 -> 128 shared_conv on the row kernels too): same predictions as the torch path,
+    boxes decoded."""
+    import copy
+    from msmdfusion_amd import configs as C
+    torch.manual_seed(0)
+    tail = C.build_bev_tail(C.MSMDFUSION_LC).to(dev).eval()
+    head_rows = C.build_head(rows=True).to(dev).eval()
+    head_ref = C.build_head(rows=False).to(dev).eval()
+    head_ref.load_state_dict(copy.deepcopy(head_rows.state_dict()))
+    x = torch.randn(2, 640, 180, 180, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        feat = tail(x)[0]
+        a, b = head_rows(feat), head_ref(feat.contiguous())
+    (pa,), (pb,) = a[0], b[0]
+    assert tuple(pa["center"].shape) == (2, 2, 200) and tuple(pa["heatmap"].shape) == (2, 10, 200)
+    # the proposals are an argsort of the heatmap: identical inputs up to rounding give the
+    # same top-200 except at near-ties; compare the dense heatmap and, where the query sets
+    # agree, the predictions
+    assert float((pa["dense_heatmap"] - pb["dense_heatmap"]).abs().max()) <= \
+        1e-4 * float(pb["dense_heatmap"].abs().max())
+    same = head_rows.query_labels == head_ref.query_labels
+    assert float(same.float().mean()) > 0.9
+    boxes = head_rows.get_bboxes(a)
+    assert len(boxes) == 2 and boxes[0]["bboxes"].shape[1] == 9
+    assert torch.isfinite(boxes[0]["bboxes"]).all()
