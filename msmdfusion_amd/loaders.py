@@ -25,8 +25,9 @@ FOREGROUND_DIR = "FOREGROUND_MIXED_6NN_WITH_DEPTH"
 
 
 class LidarPointsView:
-    """The two attributes of mmdet3d's LiDARPoints the hot path reads
-    (`fg_pts.tensor`, MSMDFusion.py:221; `points_dim`)."""
+    """The slice of mmdet3d's LiDARPoints the loaders and the hot path use: `.tensor`
+    (float32 [n, dim]; MSMDFusion.py:221 reads it), `points_dim`, `new_point`, `cat`,
+    row / column indexing (core/points/base_points.py)."""
 
     def __init__(self, array, points_dim=None):
         import torch
@@ -35,6 +36,20 @@ class LidarPointsView:
 
     def __len__(self):
         return self.tensor.shape[0]
+
+    def new_point(self, data):
+        return LidarPointsView(data)
+
+    @staticmethod
+    def cat(points_list):
+        import torch
+        return LidarPointsView(torch.cat([p.tensor for p in points_list], 0).numpy())
+
+    def __getitem__(self, item):
+        import torch
+        if isinstance(item, np.ndarray) and item.dtype == np.bool_:
+            item = torch.from_numpy(item)
+        return LidarPointsView(self.tensor[item].numpy())
 
 
 def foreground_path(lidar_path, directory=FOREGROUND_DIR, suffix=".pkl.npy"):
@@ -174,4 +189,76 @@ class LoadForeground2DFromMultiSweeps:
             fg_info = self.merge_sweep(fg_info, sweep_info, sweep)
         fg_info["fg_points"] = [LidarPointsView(p, p.shape[-1]) for p in fg_info["fg_points"]]
         results["foreground2D_info"] = fg_info
+        return results
+
+
+def read_points(path, load_dim):
+    """LoadPointsFromFile._load_points / LoadPointsFromMultiSweeps._load_points
+    (loading.py:541-561): raw float32 records (.bin) or an .npy array."""
+    pts = np.load(path) if path.endswith(".npy") else np.fromfile(path, dtype=np.float32)
+    return np.copy(pts).reshape(-1, load_dim)
+
+
+class LoadPointsFromFile:
+    """loading.py `LoadPointsFromFile` for LiDAR coordinates: results['points'] =
+    the file's first `use_dim` columns (an int n means range(n))."""
+
+    def __init__(self, coord_type="LIDAR", load_dim=6, use_dim=(0, 1, 2), shift_height=False,
+                 use_color=False, **kwargs):
+        if coord_type != "LIDAR" or shift_height or use_color:
+            raise NotImplementedError("only plain LIDAR point files are built")
+        self.load_dim = load_dim
+        self.use_dim = list(range(use_dim)) if isinstance(use_dim, int) else list(use_dim)
+
+    def __call__(self, results):
+        pts = read_points(results["pts_filename"], self.load_dim)[:, self.use_dim]
+        results["points"] = LidarPointsView(pts)
+        return results
+
+
+class LoadPointsFromMultiSweeps:
+    """loading.py:503-636: the key frame's points (time column zeroed) followed by up to
+    `sweeps_num` earlier sweeps, each moved into the key frame's coordinates
+    (p @ R^T + t), optionally without the points within `radius` of the sensor in x AND y,
+    time column = ts - sweep_ts; finally the `use_dim` columns."""
+
+    def __init__(self, sweeps_num=10, load_dim=5, use_dim=(0, 1, 2, 4), pad_empty_sweeps=False,
+                 remove_close=False, test_mode=False, **kwargs):
+        self.sweeps_num, self.load_dim, self.use_dim = sweeps_num, load_dim, list(use_dim)
+        self.pad_empty_sweeps, self.remove_close, self.test_mode = \
+            pad_empty_sweeps, remove_close, test_mode
+
+    @staticmethod
+    def _remove_close(points, radius=1.0):
+        arr = points if isinstance(points, np.ndarray) else points.tensor.numpy()
+        close = (np.abs(arr[:, 0]) < radius) & (np.abs(arr[:, 1]) < radius)
+        return points[~close]
+
+    def __call__(self, results):
+        points = results["points"]
+        points.tensor[:, 4] = 0
+        sweeps = [points]
+        ts = results["timestamp"]
+        if self.pad_empty_sweeps and len(results["sweeps"]) == 0:
+            for _ in range(self.sweeps_num):
+                sweeps.append(self._remove_close(points) if self.remove_close else points)
+        else:
+            n = len(results["sweeps"])
+            if n <= self.sweeps_num:
+                choices = np.arange(n)
+            elif self.test_mode:
+                choices = np.arange(self.sweeps_num)
+            else:
+                choices = np.random.choice(n, self.sweeps_num, replace=False)
+            for idx in choices:
+                sweep = results["sweeps"][idx]
+                pts = read_points(sweep["data_path"], self.load_dim)
+                if self.remove_close:
+                    pts = self._remove_close(pts)
+                pts[:, :3] = pts[:, :3] @ np.asarray(sweep["sensor2lidar_rotation"]).T
+                pts[:, :3] += np.asarray(sweep["sensor2lidar_translation"])
+                pts[:, 4] = ts - sweep["timestamp"] / 1e6
+                sweeps.append(points.new_point(pts))
+        points = points.cat(sweeps)
+        results["points"] = points[:, self.use_dim]
         return results

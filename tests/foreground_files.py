@@ -46,3 +46,19 @@ def make_tree(root, seed=0):
                            sensor2lidar_rotation=rot,
                            sensor2lidar_translation=rng.randn(3) * 0.5))
     return dict(pts_filename=key, timestamp=1.5e9, sweeps=sweeps)
+
+
+def add_lidar_files(results, seed=0):
+    """Writes the key frame's and the sweeps' raw .bin point files (5 float32 per point,
+    a few points near the sensor) and returns `results` with pts_filename / data_path set."""
+    rng = np.random.RandomState(1000 + seed)
+
+    def cloud(path, n):
+        p = np.concatenate([rng.randn(n, 3) * [20, 20, 2], rng.rand(n, 1), np.zeros((n, 1))], 1)
+        p[:5, :2] = rng.rand(5, 2) - 0.5              # inside remove_close's 1 m box
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        p.astype(np.float32).tofile(path)
+    cloud(results["pts_filename"], 300)
+    for i, sw in enumerate(results["sweeps"]):
+        cloud(sw["data_path"], 200 + 10 * i)
+    return results

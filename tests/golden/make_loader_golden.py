@@ -24,6 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import foreground_files as FF  # noqa: E402
 
 REF = "/root/reference/mmdet3d/datasets/pipelines/my_loading_multi_proj.py"
+REF_LOADING = "/root/reference/mmdet3d/datasets/pipelines/loading.py"
 OUT = os.path.join(ROOT, "tests", "golden", "loader_vectors.npz")
 
 
@@ -47,6 +48,39 @@ def reference_classes():
     return ns
 
 
+class _FileClient:                       # mmcv.FileClient(backend='disk')
+    def __init__(self, **kw):
+        pass
+
+    def get(self, path):
+        return open(path, "rb").read()
+
+
+class _PointsBox(_Points):               # BasePoints: holder + new_point / cat / indexing
+    def new_point(self, data):
+        return _PointsBox(data)
+
+    def cat(self, items):
+        return _PointsBox(torch.cat([p.tensor for p in items], 0).numpy())
+
+    def __getitem__(self, item):
+        if isinstance(item, np.ndarray) and item.dtype == np.bool_:
+            item = torch.from_numpy(item)
+        return _PointsBox(self.tensor[item].numpy())
+
+
+def reference_multisweep_class():
+    import types
+    tree = ast.parse(open(REF_LOADING).read())
+    body = [n for n in tree.body if isinstance(n, ast.ClassDef)
+            and n.name == "LoadPointsFromMultiSweeps"]
+    ns = {"np": np, "PIPELINES": _Registry(), "BasePoints": _PointsBox,
+          "mmcv": types.SimpleNamespace(FileClient=_FileClient,
+                                        check_file_exist=lambda p: None)}
+    exec(compile(ast.Module(body=body, type_ignores=[]), REF_LOADING, "exec"), ns)
+    return ns["LoadPointsFromMultiSweeps"]
+
+
 def main():
     ns = reference_classes()
     out = {}
@@ -68,6 +102,15 @@ def main():
                     out["multi_%s_%d" % (key, cam)] = np.asarray(a)
             for cam, p in enumerate(info["fg_points"]):
                 out["multi_fg_points_%d" % cam] = p.tensor.numpy()
+            # LiDAR sweeps (loading.py:503-636) over raw .bin files of the same tree
+            FF.add_lidar_files(results, seed=5)
+            key = np.fromfile(results["pts_filename"], dtype=np.float32).reshape(-1, 5)
+            Ref = reference_multisweep_class()
+            for tag, kw in (("plain", {}), ("noclose", dict(remove_close=True)),
+                            ("one", dict(sweeps_num=1, test_mode=True))):
+                res = Ref(use_dim=[0, 1, 2, 3, 4], **kw)(
+                    dict(copy.deepcopy(results), points=_PointsBox(key.copy())))
+                out["sweeps_" + tag] = res["points"].tensor.numpy()
         finally:
             os.chdir(cwd)
     np.savez_compressed(OUT, **out)

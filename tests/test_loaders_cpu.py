@@ -99,3 +99,21 @@ def test_kitti_branch_and_unknown_dataset(tmp_path, monkeypatch):
     np.testing.assert_array_equal(info["fg_pixels"][0][:7], payload["virtual_pixel_indices"])
     with pytest.raises(NotImplementedError):
         L.LoadForeground2D("WaymoDataset")(dict(pts_filename="a/b/c.bin"))
+
+
+def test_multi_sweep_lidar_loader_matches_the_reference(tree):
+    """LoadPointsFromFile + LoadPointsFromMultiSweeps (loading.py:503-636) over raw .bin
+    files: concatenation order, sweep -> key-frame transform, time column, remove_close."""
+    gold = np.load(GOLD)
+    res0 = FF.add_lidar_files(copy.deepcopy(tree), seed=5)
+    for tag, kw in (("plain", {}), ("noclose", dict(remove_close=True)),
+                    ("one", dict(sweeps_num=1, test_mode=True))):
+        res = L.LoadPointsFromFile(load_dim=5, use_dim=5)(copy.deepcopy(res0))
+        assert tuple(res["points"].tensor.shape) == (300, 5)
+        res = L.LoadPointsFromMultiSweeps(use_dim=[0, 1, 2, 3, 4], **kw)(res)
+        np.testing.assert_array_equal(res["points"].tensor.numpy(), gold["sweeps_" + tag])
+    # default use_dim drops the intensity column
+    res = L.LoadPointsFromMultiSweeps()(L.LoadPointsFromFile(load_dim=5, use_dim=5)(
+        copy.deepcopy(res0)))
+    assert res["points"].tensor.shape[1] == 4
+    np.testing.assert_array_equal(res["points"].tensor.numpy(), gold["sweeps_plain"][:, [0, 1, 2, 4]])
