@@ -385,13 +385,23 @@ def main():
             # BASELINE.json's configs[2] names bf16: the same path with plain bf16 conv
             # operands (one plane, one product; fp32 accumulation, features / BN / BEV stay
             # fp32 in HBM) -- a second line, the headline keeps the reference's fp32 arithmetic
-            os.environ["MSMD_CONV_PLANES"] = "1"
             try:
+                os.environ["MSMD_CONV_PLANES"] = "1"
                 for key, wl in (("configs[2] bf16 operands", "lc"),
                                 ("configs[2] @ 4/GPU bf16 operands", "lc_b4")):
                     r = run_workload(wl, args, dev, rank, world, False)
                     r["metric"] = WORKLOADS[wl]["metric"]
                     r["dtype"] = "bf16 conv operands, f32 accumulate and storage"
+                    out["also"][key] = r
+                # two bf16 planes per operand (three products): max error 4.3e-6 of the
+                # layer's output scale -- 20x inside north_star's 1e-4, no longer the
+                # fp32-equivalent of the headline
+                os.environ["MSMD_CONV_PLANES"] = "2"
+                for key, wl in (("configs[1] two bf16 planes", "transfusion_l"),
+                                ("configs[2] @ 4/GPU two bf16 planes", "lc_b4")):
+                    r = run_workload(wl, args, dev, rank, world, False)
+                    r["metric"] = WORKLOADS[wl]["metric"]
+                    r["dtype"] = "two bf16 planes per conv operand (3 products), f32 accumulate"
                     out["also"][key] = r
             finally:
                 os.environ.pop("MSMD_CONV_PLANES", None)
