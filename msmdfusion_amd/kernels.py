@@ -55,8 +55,25 @@ def _need_bzyx(*index_tensors):
             raise ValueError("expected [N,4] (b,z,y,x) voxel indices, got %s" % (tuple(t.shape),))
 
 
+_WS_CACHE = {}
+_WS_CACHE_MAX = 1 << 30
+
+
 def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    """Scratch for one library call (or a count -> host read -> fill pair).  Grow-only
+    buffer per (device, stream): every user is stream-ordered behind the previous one, a
+    stream is driven by one thread at a time, and nothing returned to callers aliases the
+    scratch -- so ~250 allocator calls per LC step (two threads contending for the caching
+    allocator's lock) become dictionary look-ups."""
+    nbytes = max(int(nbytes), 256)
+    if nbytes > _WS_CACHE_MAX:
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    key = (device.index, _raw_stream(device.index))
+    buf = _WS_CACHE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _WS_CACHE[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8,
+                                           device=device)
+    return buf
 
 
 def _expand3(v):
@@ -575,8 +592,8 @@ def bn_act_forward(x, residual, gamma, beta, running_mean, running_var, training
     n, c = xx.shape
     dev = xx.device
     y = torch.empty_like(xx)
-    mean = torch.empty((c,), dtype=torch.float32, device=dev)
-    invstd = torch.empty((c,), dtype=torch.float32, device=dev)
+    stats = torch.empty((2, c), dtype=torch.float32, device=dev)
+    mean, invstd = stats[0], stats[1]
     nbytes = lib.msmd_bn_workspace_bytes(n, c)
     ws = _ws(nbytes, dev)
     res = None if residual is None else residual.contiguous().float()
@@ -595,8 +612,8 @@ def bn_act_backward(x, y, dy, gamma, save_mean, save_invstd, training, relu, wan
     dev = xx.device
     dx = torch.empty_like(xx)
     dres = torch.empty_like(xx) if want_residual else None
-    dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
-    dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+    dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
+    dgamma, dbeta = dgb[0], dgb[1]
     nbytes = lib.msmd_bn_workspace_bytes(n, c)
     ws = _ws(nbytes, dev)
     check(lib.msmd_bn_act_bwd_f32(_p(xx), _p(y), _p(g), n, c, _p(gamma), _p(save_mean),
