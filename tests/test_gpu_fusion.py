@@ -323,6 +323,55 @@ def test_prefetched_step_through_ddp(dev):
 
 
 @pytest.mark.gpu
+def test_prefetched_lc_step_through_ddp(dev):
+    """The LC path the way `bench.py --gpus N` runs a rank: FusionBackbone under
+    DistributedDataParallel (RCCL backend, world size 1), the index pass on the threaded
+    IndexPrefetcher with its four search streams, distributed.TrainStep (prepared batch as a
+    forward keyword, clip, fused AdamW) for several steps.  First-step BEV map equals the bare
+    module's; every step's loss and every trained parameter stay finite."""
+    import socket
+    import torch.distributed as dist
+    import proc_prefetch_helper as H
+    from msmdfusion_amd import distributed as D
+    from msmdfusion_amd.prefetch import IndexPrefetcher
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0,
+                            world_size=1, device_id=dev)
+    try:
+        model = H.build_model(dev)
+        clouds, virt = H.make_batch(dev)
+        with torch.no_grad():
+            want = model(clouds, virt).clone()
+        params = [p for p in model.parameters() if p.requires_grad]
+        # wrap_data_parallel() hands a lone rank the bare module; the point here is the
+        # wrapper's hooks and buckets around the LC step, so build it directly
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index],
+                                                        gradient_as_bucket_view=True)
+        assert D.rccl_ranks() == 1
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+        pf = IndexPrefetcher(model.prepare, dev, threaded=True)
+        seen = []
+
+        def loss_fn(bev):
+            seen.append(bev.detach())
+            return bev.float().square().mean()
+        step = D.TrainStep(net, params, opt, loss_fn, pf, 10.0)
+        step.prime((clouds, virt))
+        losses = [step((clouds, virt)) for _ in range(4)]
+        torch.cuda.synchronize()
+        assert torch.equal(seen[0], want)
+        assert all(torch.isfinite(l).item() for l in losses)
+        assert float(losses[-1].detach()) != float(losses[0].detach())          # the optimizer moved the weights
+        assert all(torch.isfinite(p).all() for p in params)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 def test_process_prefetch_matches_inline_lc(dev):
     """prepare() in a worker PROCESS (flat IPC buffers + pickled skeleton,
     msmdfusion_amd/prefetch_proc.py) feeds the same feature pass as prepare() inline:
