@@ -569,6 +569,53 @@ int msmd_nn_assign(const int32_t* group_idx /* [m,nsample] ball-query out */,
                    int nsample, int nq, int32_t* query_nn /* [nq], -1 init by callee */,
                    int32_t* scratch /* [nq] */, msmd_stream_t stream);
 
+/* ------------------------------------------------------------------------ *
+ * f3 (training half)  TransFusionHead.loss: target assignment and heat-map loss
+ * replaces: iou3d_cuda.boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap)
+ *           (mmdet3d/ops/iou3d/src/iou3d.cpp:70-98, kernel iou3d_kernel.cu:36-264) and
+ *           its caller BaseInstance3DBoxes.overlaps
+ *           (mmdet3d/core/bbox/structures/base_box3d.py:384-438), reached from
+ *           HungarianAssigner3D.assign (core/bbox/assigners/hungarian_assigner.py:125)
+ * ------------------------------------------------------------------------ */
+/* Overlap AREA of rotated BEV rectangles (x1, y1, x2, y2, angle), out[na, nb]. */
+int msmd_boxes_overlap_bev_f32(const float* boxes_a /* [na,5] */, int na,
+                               const float* boxes_b /* [nb,5] */, int nb,
+                               float* out /* [na,nb] */, msmd_stream_t stream);
+/* 3-D IoU (mode 0) / IoF over boxes_a (mode 1) of LiDAR boxes
+ * (x, y, z_bottom, dx, dy, dz, yaw, ...) for a whole batch: sample s compares its na
+ * rows of boxes_a with its first nb_valid[s] rows of boxes_b (nb_valid NULL: all nb);
+ * columns past nb_valid[s] are written as 0.  out[batch, na, nb]. */
+int msmd_boxes_iou3d_f32(const float* boxes_a /* [batch,na,lda] */, int lda,
+                         const float* boxes_b /* [batch,nb,ldb] */, int ldb,
+                         const int32_t* nb_valid /* [batch] or NULL */, int batch,
+                         int na, int nb, int mode, float* out, msmd_stream_t stream);
+
+/* replaces: the per-box loop gaussian_radius -> draw_heatmap_gaussian of
+ *           TransFusionHead.get_targets_single
+ *           (mmdet3d/models/dense_heads/transfusion_head.py:1186-1210;
+ *           mmdet3d/core/utils/gaussian.py:5-53)
+ * heatmap[planes, h, w] (caller zero-fills; plane = sample * classes + class) takes the
+ * maximum with exp(-(dx^2 + dy^2) / (2 (d/6)^2)), d = 2 radius + 1, evaluated in double
+ * and rounded to float, clipped to the map.  plane < 0 or radius < 0: box skipped. */
+int msmd_heatmap_gaussian_f32(const int32_t* plane /* [n] */,
+                              const int32_t* center_x /* [n] */,
+                              const int32_t* center_y /* [n] */,
+                              const int32_t* radius /* [n] */, int n, int planes, int h,
+                              int w, float* heatmap, msmd_stream_t stream);
+
+/* replaces: clip_sigmoid (mmdet3d/models/utils/clip_sigmoid.py) + mmdet's
+ *           GaussianFocalLoss(alpha=2, gamma=4) as called at transfusion_head.py:1247-1249.
+ * p = clamp(sigmoid(logit), clip, 1 - clip);
+ * loss_i = -log(p + 1e-12) (1-p)^2 [target == 1] - log(1 - p + 1e-12) p^2 (1-target)^4.
+ * sums[0] = sum of loss_i, sums[1] = number of cells with target == 1 (the avg_factor the
+ * reference reads back with .item()); grad (optional) = d loss_i / d logit_i.
+ * Deterministic: per-block partials in double, summed in block order. */
+size_t msmd_gaussian_focal_workspace_bytes(int64_t n);
+int msmd_gaussian_focal_f32(const float* logits, const float* target, int64_t n,
+                            float clip, float* grad /* [n] or NULL */,
+                            float* sums /* [2] */, void* workspace,
+                            size_t workspace_bytes, msmd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

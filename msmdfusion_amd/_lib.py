@@ -87,6 +87,11 @@ SIGNATURES = {
                                 _vp, _vp, _vp, _vp, _vp]),
     "msmd_fg_scatter_add_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "msmd_depth_canvas_workspace_bytes": (_sz, [_i, _i, _i]),
+    "msmd_boxes_overlap_bev_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "msmd_boxes_iou3d_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "msmd_heatmap_gaussian_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "msmd_gaussian_focal_workspace_bytes": (_sz, [_i64]),
+    "msmd_gaussian_focal_f32": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp, _sz, _vp]),
     "msmd_depth_canvas_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "msmd_sparse_add_workspace_bytes": (_sz, [_i, _ip]),
     "msmd_sparse_add_count": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _sz, _vp]),

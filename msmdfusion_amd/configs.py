@@ -40,7 +40,23 @@ _PTS_BBOX_HEAD = dict(
     bbox_coder=dict(type="TransFusionBBoxCoder", pc_range=POINT_CLOUD_RANGE[:2],
                     voxel_size=VOXEL_SIZE[:2], out_size_factor=_OUT_SIZE_FACTOR,
                     post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
-                    score_threshold=0.0, code_size=10))
+                    score_threshold=0.0, code_size=10),
+    loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2, alpha=0.25, reduction="mean",
+                  loss_weight=1.0),
+    loss_bbox=dict(type="L1Loss", reduction="mean", loss_weight=0.25),
+    loss_heatmap=dict(type="GaussianFocalLoss", reduction="mean", loss_weight=1.0))
+# train_cfg.pts of configs/MSMDFusion_nusc_voxel_LC.py:242-259
+_TRAIN_CFG_PTS = dict(
+    dataset="nuScenes",
+    assigner=dict(type="HungarianAssigner3D",
+                  iou_calculator=dict(type="BboxOverlaps3D", coordinate="lidar"),
+                  cls_cost=dict(type="FocalLossCost", gamma=2, alpha=0.25, weight=0.15),
+                  reg_cost=dict(type="BBoxBEVL1Cost", weight=0.25),
+                  iou_cost=dict(type="IoU3DCost", weight=0.25)),
+    pos_weight=-1, gaussian_overlap=0.1, min_radius=2, grid_size=[1440, 1440, 40],
+    voxel_size=VOXEL_SIZE, out_size_factor=_OUT_SIZE_FACTOR,
+    code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2],
+    point_cloud_range=POINT_CLOUD_RANGE)
 _TEST_CFG_PTS = dict(dataset="nuScenes", grid_size=[1440, 1440, 40],
                      out_size_factor=_OUT_SIZE_FACTOR, pc_range=POINT_CLOUD_RANGE[0:2],
                      voxel_size=VOXEL_SIZE[:2], nms_type=None)
@@ -117,7 +133,9 @@ def build_bev_tail(cfg, compute_dtype=None, rows=True):
 
 def build_head(cfg=None, rows=False):
     """pts_bbox_head of configs/MSMDFusion_nusc_voxel_LC.py:207-241 with its test_cfg
-    (:260-268): TransFusionHead, LiDAR branch (msmdfusion_amd/head.py)."""
+    (:260-268) and train_cfg (:242-259): TransFusionHead, LiDAR branch (msmdfusion_amd/head.py,
+    head_loss.py)."""
     from .head import TransFusionHead
     args = {k: v for k, v in _PTS_BBOX_HEAD.items() if k != "type"}
-    return TransFusionHead(test_cfg=dict(_TEST_CFG_PTS), rows=rows, **args)
+    return TransFusionHead(test_cfg=dict(_TEST_CFG_PTS), train_cfg=dict(_TRAIN_CFG_PTS), rows=rows,
+                           **args)

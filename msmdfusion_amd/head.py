@@ -8,8 +8,10 @@ Built here: the path the LC config takes (`fuse_img` unset, `initialize_by_heatm
 one decoder layer, configs/MSMDFusion_nusc_voxel_LC.py:207-241) -- forward_single's
 heatmap-initialised queries, the decoder layers over the flattened BEV map, the prediction
 heads, and get_bboxes' score composition + box decoding without NMS (`nms_type=None`).
-Not built: the image-fusion decoder stages (`fuse_img=True`), target assignment
-(HungarianAssigner3D) and the losses -- this head is the inference / forward half.
+The training half -- get_targets (HungarianAssigner3D, heat-map targets) and loss
+(:1051-1286) -- lives in msmdfusion_amd/head_loss.py and is reached through this class's
+`get_targets` / `loss`.  Not built: the image-fusion decoder stages (`fuse_img=True`), the
+HeuristicAssigner and NMS variants the configs do not use.
 
 Parameter names and shapes are the reference's (`shared_conv.weight`,
 `heatmap_head.0.conv.weight`, `decoder.0.self_attn.in_proj_weight`,
@@ -176,7 +178,7 @@ class TransFusionHead(nn.Module):
                  initialize_by_heatmap=False, nms_kernel_size=1, ffn_channel=256, dropout=0.1,
                  bn_momentum=0.1, activation="relu", common_heads=None, num_heatmap_convs=2,
                  bias="auto", bbox_coder=None, test_cfg=None, train_cfg=None, fuse_img=False,
-                 rows=False, **unused):
+                 loss_cls=None, loss_bbox=None, loss_heatmap=None, rows=False, **unused):
         super().__init__()
         if fuse_img:
             raise NotImplementedError("TransFusionHead: the image-fusion stages are not built "
@@ -215,6 +217,14 @@ class TransFusionHead(nn.Module):
         y_size = test_cfg["grid_size"][1] // test_cfg["out_size_factor"]
         self.bev_pos = self.create_2D_grid(x_size, y_size)
         self.query_labels = None
+        from . import head_loss as HL
+        self.loss_cls = HL.build_loss(loss_cls or dict(type="FocalLoss"))        # :609-611
+        self.loss_bbox = HL.build_loss(loss_bbox or dict(type="L1Loss"))
+        self.loss_heatmap = HL.build_loss(loss_heatmap or dict(type="GaussianFocalLoss"))
+        self.bbox_assigner = None                        # _init_assigner_sampler (:778-792);
+        if train_cfg is not None:                        # the sampler is PseudoSampler: none
+            self.bbox_assigner = HL.build_assigner(train_cfg["assigner"])
+        self.heatmap_painter = HL.HeatmapPainter()
 
     @staticmethod
     def create_2D_grid(x_size, y_size):
@@ -300,6 +310,19 @@ class TransFusionHead(nn.Module):
         res = tuple(map(list, zip(*[self.forward_single(x) for x in feats])))
         assert len(res) == 1, "only support one level features."
         return res
+
+    def get_targets(self, gt_bboxes_3d, gt_labels_3d, preds_dict):
+        """:1051-1090 (whole batch at once, head_loss.get_targets)."""
+        from . import head_loss as HL
+        return HL.get_targets(self, gt_bboxes_3d, gt_labels_3d, preds_dict)
+
+    def loss(self, gt_bboxes_3d, gt_labels_3d, preds_dicts, **kwargs):
+        """:1221-1286 -> dict(loss_heatmap, layer_-1_loss_cls, layer_-1_loss_bbox, ...,
+        matched_ious)."""
+        if self.train_cfg is None or self.bbox_assigner is None:
+            raise RuntimeError("TransFusionHead.loss needs train_cfg (assigner, code_weights, ...)")
+        from . import head_loss as HL
+        return HL.loss(self, gt_bboxes_3d, gt_labels_3d, preds_dicts)
 
     def get_bboxes(self, preds_dicts):
         """:1285-1379 with nms_type None: score = sigmoid(heatmap) * query heatmap score *

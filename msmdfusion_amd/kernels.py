@@ -748,6 +748,83 @@ def depth_canvas(pixels, plane, planes, h, w):
     return canvas, bad
 
 
+# ------------------------------------------------ head targets / loss (row f3)
+def boxes_overlap_bev(boxes_a, boxes_b):
+    """iou3d_cuda.boxes_overlap_bev_gpu: rotated rectangles (x1, y1, x2, y2, angle) ->
+    overlap AREAS [na, nb]."""
+    _need_cuda(boxes_a, boxes_b)
+    a, b = boxes_a.contiguous().float(), boxes_b.contiguous().float()
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != 5 or b.shape[1] != 5:
+        raise ValueError("boxes must be [n,5] (x1, y1, x2, y2, angle)")
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    check(lib.msmd_boxes_overlap_bev_f32(_p(a), a.shape[0], _p(b), b.shape[0], _p(out), _stream()),
+          "msmd_boxes_overlap_bev_f32")
+    return out
+
+
+def boxes_iou3d(boxes_a, boxes_b, nb_valid=None, mode="iou"):
+    """BaseInstance3DBoxes.overlaps for LiDAR boxes (x, y, z_bottom, dx, dy, dz, yaw, ...).
+    [na, ca] x [nb, cb] -> [na, nb], or batched [B, na, ca] x [B, nb, cb] (+ nb_valid [B]:
+    rows of boxes_b in use per sample) -> [B, na, nb]."""
+    _need_cuda(boxes_a, boxes_b)
+    if mode not in ("iou", "iof"):
+        raise ValueError("mode must be 'iou' or 'iof'")
+    a, b = boxes_a.contiguous().float(), boxes_b.contiguous().float()
+    single = a.dim() == 2
+    if single:
+        a, b = a[None], b[None]
+    if a.dim() != 3 or b.dim() != 3 or a.shape[0] != b.shape[0] or a.shape[2] < 7 or b.shape[2] < 7:
+        raise ValueError("boxes must be [B,n,>=7] with equal B (or [n,>=7])")
+    batch, na, nb = a.shape[0], a.shape[1], b.shape[1]
+    if nb_valid is not None:
+        _need_cuda(nb_valid)
+        nb_valid = nb_valid.contiguous().int()
+        if nb_valid.numel() != batch:
+            raise ValueError("nb_valid must hold one count per sample")
+    out = torch.empty((batch, na, nb), dtype=torch.float32, device=a.device)
+    check(lib.msmd_boxes_iou3d_f32(_p(a), a.shape[2], _p(b), b.shape[2],
+                                   _p(nb_valid) if nb_valid is not None else None, batch, na, nb,
+                                   0 if mode == "iou" else 1, _p(out), _stream()),
+          "msmd_boxes_iou3d_f32")
+    return out[0] if single else out
+
+
+def heatmap_gaussian(heatmap, plane, center_x, center_y, radius):
+    """heatmap [planes, H, W] (or [B, C, H, W]) float32, updated in place: maximum with one
+    Gaussian bump per box (plane = sample * C + class; plane < 0 or radius < 0 skips)."""
+    _need_cuda(heatmap, plane, center_x, center_y, radius)
+    if heatmap.dtype != torch.float32 or not heatmap.is_contiguous() or heatmap.dim() < 3:
+        raise ValueError("heatmap must be a contiguous float32 [..., H, W] buffer")
+    h, w = heatmap.shape[-2:]
+    planes = heatmap.numel() // (h * w)
+    n = plane.numel()
+    args = [t.contiguous().int() for t in (plane, center_x, center_y, radius)]
+    if any(t.numel() != n for t in args):
+        raise ValueError("plane / center / radius must have one entry per box")
+    check(lib.msmd_heatmap_gaussian_f32(_p(args[0]), _p(args[1]), _p(args[2]), _p(args[3]), n,
+                                        planes, h, w, _p(heatmap), _stream()),
+          "msmd_heatmap_gaussian_f32")
+    return heatmap
+
+
+def gaussian_focal(logits, target, clip=1e-4, want_grad=True):
+    """clip_sigmoid + GaussianFocalLoss(alpha=2, gamma=4), unreduced sums.
+    -> (sums [2] = (sum of losses, cells with target == 1), grad like logits | None)"""
+    _need_cuda(logits, target)
+    x, t = logits.contiguous().float(), target.contiguous().float()
+    if x.shape != t.shape:
+        raise ValueError("logits and target must have the same shape")
+    n = x.numel()
+    sums = torch.empty((2,), dtype=torch.float32, device=x.device)
+    grad = torch.empty_like(x) if want_grad else None
+    nbytes = lib.msmd_gaussian_focal_workspace_bytes(n)
+    ws = _ws(nbytes, x.device)
+    check(lib.msmd_gaussian_focal_f32(_p(x), _p(t), n, float(clip),
+                                      _p(grad) if grad is not None else None, _p(sums), _p(ws),
+                                      nbytes, _stream()), "msmd_gaussian_focal_f32")
+    return sums, grad
+
+
 def sparse_add(feat_a, idx_a, feat_b, idx_b, batch_size, spatial_shape):
     """-> (out_indices, out_feat, map_a, map_b)"""
     _need_bzyx(idx_a, idx_b)

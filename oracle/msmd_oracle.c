@@ -599,3 +599,122 @@ ORC_API void orc_nn_assign(const int32_t* group_idx, const int32_t* rep_nn,
       query_nn[group_idx[(size_t)r * nsample + s]] = rep_nn[r];
   }
 }
+
+/* ------------------------------------------------------------------------
+ * Rotated BEV overlap of two box sets -- the algorithm of
+ * mmdet3d/ops/iou3d/src/iou3d_kernel.cu:36-239 (box_overlap and its helpers),
+ * entry boxes_overlap_kernel :250-264 / boxes_overlap_bev_gpu iou3d.cpp:70-98,
+ * used by BaseInstance3DBoxes.overlaps (core/bbox/structures/base_box3d.py:384-438).
+ * The reference has NO CPU twin of this kernel (CUDA only), so this is a
+ * restatement in float arithmetic, pinned by the known answers of the
+ * reference's tests/test_utils/test_box3d.py:897-936 and by an independent fp64
+ * polygon clip (tests/test_head_loss_cpu.py).  Not bit-comparable with the CUDA
+ * build (nvcc contracts a*b+c, device cosf/atan2f differ in the last ulp).
+ *
+ * Boxes are (x1, y1, x2, y2, angle).  Quirks kept: corners are turned by
+ * R(-angle) about the box centre (rot = (dx*c + dy*s, -dx*s + dy*c)); a corner
+ * counts as inside the other box with a 1e-5 margin; edge crossings need both
+ * strict "straddle" products > 0; the vertex list (up to 24 entries, duplicates
+ * allowed) is bubble-sorted by atan2 about its mean and summed as a fan from
+ * vertex 0.
+ */
+typedef struct { float x, y; } orc_pt;
+
+static float orc_cross3(orc_pt a, orc_pt b, orc_pt o) {
+  return (a.x - o.x) * (b.y - o.y) - (b.x - o.x) * (a.y - o.y);
+}
+
+static int orc_edge_hit(orc_pt p1, orc_pt p0, orc_pt q1, orc_pt q0, orc_pt* hit) {
+  /* bounding rectangles of the two segments must touch */
+  if (!(fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+        fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y)))
+    return 0;
+  float s1 = orc_cross3(q0, p1, p0), s2 = orc_cross3(p1, q1, p0);
+  float s3 = orc_cross3(p0, q1, q0), s4 = orc_cross3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+  float s5 = orc_cross3(q1, p1, p0);
+  if (fabsf(s5 - s1) > 1e-8f) {
+    hit->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    hit->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {                                  /* general line-line solve */
+    float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    float d = a0 * b1 - a1 * b0;
+    hit->x = (b0 * c1 - b1 * c0) / d;
+    hit->y = (a1 * c0 - a0 * c1) / d;
+  }
+  return 1;
+}
+
+static int orc_inside(const float* box, orc_pt p) {
+  const float margin = 1e-5f;
+  float cx = (box[0] + box[2]) / 2, cy = (box[1] + box[3]) / 2;
+  float c = cosf(-box[4]), s = sinf(-box[4]);
+  float rx = (p.x - cx) * c + (p.y - cy) * s + cx;
+  float ry = -(p.x - cx) * s + (p.y - cy) * c + cy;
+  return rx > box[0] - margin && rx < box[2] + margin && ry > box[1] - margin &&
+         ry < box[3] + margin;
+}
+
+static void orc_corners(const float* box, orc_pt* out /* 5, closed */) {
+  float cx = (box[0] + box[2]) / 2, cy = (box[1] + box[3]) / 2;
+  float c = cosf(box[4]), s = sinf(box[4]);
+  const float xs[4] = {box[0], box[2], box[2], box[0]};
+  const float ys[4] = {box[1], box[1], box[3], box[3]};
+  for (int k = 0; k < 4; ++k) {
+    float dx = xs[k] - cx, dy = ys[k] - cy;
+    out[k].x = dx * c + dy * s + cx;
+    out[k].y = -dx * s + dy * c + cy;
+  }
+  out[4] = out[0];
+}
+
+static float orc_box_overlap(const float* a, const float* b) {
+  orc_pt ca[5], cb[5], v[24], mean = {0.f, 0.f};
+  orc_corners(a, ca);
+  orc_corners(b, cb);
+  int n = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (orc_edge_hit(ca[i + 1], ca[i], cb[j + 1], cb[j], &v[n])) {
+        mean.x += v[n].x;
+        mean.y += v[n].y;
+        ++n;
+      }
+  for (int k = 0; k < 4; ++k) {
+    if (orc_inside(a, cb[k])) {
+      mean.x += cb[k].x;
+      mean.y += cb[k].y;
+      v[n++] = cb[k];
+    }
+    if (orc_inside(b, ca[k])) {
+      mean.x += ca[k].x;
+      mean.y += ca[k].y;
+      v[n++] = ca[k];
+    }
+  }
+  mean.x /= n;                               /* n == 0: NaN, never read */
+  mean.y /= n;
+  for (int j = 0; j < n - 1; ++j)
+    for (int i = 0; i < n - j - 1; ++i)
+      if (atan2f(v[i].y - mean.y, v[i].x - mean.x) >
+          atan2f(v[i + 1].y - mean.y, v[i + 1].x - mean.x)) {
+        orc_pt t = v[i];
+        v[i] = v[i + 1];
+        v[i + 1] = t;
+      }
+  float area = 0.f;
+  for (int k = 0; k < n - 1; ++k) {
+    float ux = v[k].x - v[0].x, uy = v[k].y - v[0].y;
+    float wx = v[k + 1].x - v[0].x, wy = v[k + 1].y - v[0].y;
+    area += ux * wy - uy * wx;
+  }
+  return (float)(fabs((double)area) / 2.0);
+}
+
+ORC_API void orc_boxes_overlap_bev(const float* boxes_a, int na, const float* boxes_b, int nb,
+                                   float* out /* [na, nb] */) {
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < nb; ++j)
+      out[(size_t)i * nb + j] = orc_box_overlap(boxes_a + 5 * i, boxes_b + 5 * j);
+}
