@@ -27,6 +27,7 @@
 #include "common.hpp"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace msmd {
 namespace {
@@ -1386,6 +1387,217 @@ __global__ __launch_bounds__(256, GA == 1 ? 2 : 1) void spconv_wgrad_split_buf_k
 }
 
 
+// The lean kernel with slabs as wide as the layer needs (round 2, late).  Above, a lane
+// always carries 4 channels of its side, so a slab is 64 x 64 and an 80- or 96-wide layer
+// (the LC fusion blocks: 80, 96, 128, 192) runs 2 x 2 slabs of which three are mostly
+// zeros -- 64 MFMA tiles for 25 (80 x 80) or 36 (96 x 96) tiles of work, and the conversion
+// work likewise.  Here the lanes of a REMAINDER slab carry W = 1 (16 channels left) or W = 2
+// (32 left) channels each (b32 / b64 loads: the 16 lanes of a pair still read one contiguous
+// 64 / 128-byte piece), which makes the slab W tiles wide on that side: 80 x 80 = slabs of
+// 16 + 4 + 4 + 1 tiles.  Same operands, same products, same per-slab sums as the kernel
+// above: bit-identical partials.  One launch; the slab shape is uniform per workgroup.
+template <int NP, int WA, int WB>
+__device__ __forceinline__ void wgrad_var_body(
+    const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
+    const unsigned* s_in, const unsigned* s_out, f32x4* red, int a0, int b0, int cnt,
+    float* __restrict__ dst /* [cin][cout] partial of this (k, chunk) */, int dbg) {
+  using P = Products<NP>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rs_a =
+      __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)kOobOffset, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b =
+      __builtin_amdgcn_make_buffer_rsrc((void*)dout, 0, (int)kOobOffset, 0x00020000);
+  const unsigned cola = (unsigned)(a0 + WA * i) * 4u, colb = (unsigned)(b0 + WB * i) * 4u;
+  const bool in_a = a0 + WA * i < cin, in_b = b0 + WB * i < cout;
+
+  f32x4 acc[WA][WB];
+#pragma unroll
+  for (int a = 0; a < WA; ++a)
+#pragma unroll
+    for (int b = 0; b < WB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  unsigned ra[8][WA], rb[8][WB];   // this lane's 8 pairs x W channels (fp32 bits)
+  auto load_w = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, unsigned* out, auto w) {
+    constexpr int W = decltype(w)::value;
+    if constexpr (W == 4) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+      out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+    } else if constexpr (W == 2) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+      out[0] = v[0]; out[1] = v[1];
+    } else {
+      out[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+    }
+  };
+  auto fetch = [&](int step) {
+    const int e0 = 32 * step + 8 * g;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32x4 oa4 = *(const u32x4*)(s_in + e0 + 4 * h), ob4 = *(const u32x4*)(s_out + e0 + 4 * h);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const unsigned fa = (oa4[s2] == kOobOffset || !in_a) ? kOobOffset : oa4[s2] + cola;
+        load_w(rs_a, fa, ra[4 * h + s2], std::integral_constant<int, WA>{});
+        const unsigned fb = (ob4[s2] == kOobOffset || !in_b) ? kOobOffset : ob4[s2] + colb;
+        load_w(rs_b, fb, rb[4 * h + s2], std::integral_constant<int, WB>{});
+      }
+    }
+  };
+  auto split_side = [&](auto& r, auto* op, auto w) {
+    constexpr int W = decltype(w)::value;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int a = 0; a < W; ++a) {
+        float v0 = __uint_as_float(r[2 * t][a]), v1 = __uint_as_float(r[2 * t + 1][a]);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+          unsigned hi;
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+          op[a][pl][t] = hi;
+          if (pl + 1 < NP) {
+            v0 = v0 - __uint_as_float(hi << 16);
+            v1 = v1 - __uint_as_float(hi & 0xffff0000u);
+          }
+        }
+      }
+  };
+  const int n_steps = (cnt + 31) / 32;
+  if (wave < n_steps) fetch(wave);
+  for (int step = wave; step < n_steps; step += 4) {
+    u32x4 oa[WA][NP], ob[WB][NP];
+    split_side(ra, oa, std::integral_constant<int, WA>{});
+    split_side(rb, ob, std::integral_constant<int, WB>{});
+    if (step + 4 < n_steps) fetch(step + 4);   // in flight under the MFMAs below
+    if (dbg & 4) {
+#pragma unroll
+      for (int a = 0; a < WA; ++a)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) asm volatile("" ::"v"(oa[a][pl]));
+#pragma unroll
+      for (int b = 0; b < WB; ++b)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) asm volatile("" ::"v"(ob[b][pl]));
+      continue;
+    }
+    __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+    for (int t = 0; t < P::n; ++t)
+#pragma unroll
+      for (int a = 0; a < WA; ++a)
+#pragma unroll
+        for (int b = 0; b < WB; ++b)
+          acc[a][b] = mfma_bf16(oa[a][P::a[t]], ob[b][P::b[t]], acc[a][b]);
+    __builtin_amdgcn_s_setprio(0);
+  }
+  // cross-wave sum, fixed tree order (w0+w2) + (w1+w3): deterministic
+  constexpr int T = WA * WB;
+  __syncthreads();   // everyone is done with the index arrays (red aliases them)
+  if (wave >= 2) {
+#pragma unroll
+    for (int a = 0; a < WA; ++a)
+#pragma unroll
+      for (int b = 0; b < WB; ++b) red[((wave - 2) * T + a * WB + b) * 64 + lane] = acc[a][b];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int a = 0; a < WA; ++a)
+#pragma unroll
+      for (int b = 0; b < WB; ++b) acc[a][b] += red[(wave * T + a * WB + b) * 64 + lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int a = 0; a < WA; ++a)
+#pragma unroll
+      for (int b = 0; b < WB; ++b) red[(a * WB + b) * 64 + lane] = acc[a][b];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int cb = b0 + WB * i;
+#pragma unroll
+    for (int a = 0; a < WA; ++a) {
+      f32x4 v[WB];
+#pragma unroll
+      for (int b = 0; b < WB; ++b) v[b] = acc[a][b] + red[(a * WB + b) * 64 + lane];
+      // D of tile (a,b): lane (col n = i, g) reg r -> ci = a0 + WA(4g+r) + a, co = b0 + WB n + b
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = a0 + WA * (4 * g + r) + a;
+        if (ci < cin && cb < cout) {
+          float* o = dst + (size_t)ci * cout + cb;
+          if constexpr (WB == 4) *(f32x4*)o = (f32x4){v[0][r], v[1][r], v[2][r], v[3][r]};
+          else if constexpr (WB == 2) *(f32x2*)o = (f32x2){v[0][r], v[1][r]};
+          else *o = v[0][r];
+        }
+      }
+    }
+  }
+}
+
+// slabs of a side: full 64-channel ones, then the remainder (16 -> W=1, 32 -> W=2, else a
+// masked W=4 slab)
+__host__ __device__ inline int wgrad_var_slabs(int c) { return (c + 63) / 64; }
+__device__ __forceinline__ int wgrad_var_width(int c, int slab) {
+  const int rem = c - 64 * slab;
+  return rem == 16 ? 1 : rem == 32 ? 2 : 4;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256, 2) void spconv_wgrad_split_var_kernel(
+    const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
+    const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
+    int kvol, float* __restrict__ partial /* [K][nchunks][cin][cout] */, int dbg) {
+  constexpr int CHUNK = kWgradSplitChunk;
+  __shared__ __attribute__((aligned(16))) char lds_raw[2 * 16 * 64 * sizeof(f32x4)];
+  unsigned* s_in = (unsigned*)lds_raw;       // BYTE OFFSETS of the rows (or the OOB offset)
+  unsigned* s_out = s_in + CHUNK;
+  static_assert(2 * CHUNK * sizeof(int) <= sizeof(lds_raw), "index arrays must fit");
+  const int SB = wgrad_var_slabs(cout);
+  int k, chunk, slab;
+  if (!wgrad_work(nchunks, kvol, wgrad_var_slabs(cin) * SB, chunk, k, slab)) return;
+  const int Pk = num[k];
+  const int p_begin = chunk * CHUNK;
+  if (p_begin >= Pk) return;
+  const int cnt = (Pk - p_begin) < CHUNK ? (Pk - p_begin) : CHUNK;
+  const int sa = slab / SB, sb = slab % SB;
+  {
+    const int32_t* pin = pairs + ((size_t)k * 2 + 0) * ld + p_begin;
+    const int32_t* pout = pairs + ((size_t)k * 2 + 1) * ld + p_begin;
+    const unsigned rowa = (unsigned)cin * 4u, rowb = (unsigned)cout * 4u;
+    for (int e = threadIdx.x; e < CHUNK; e += 256) {   // past the end: "no pair"
+      int ia = e < cnt ? pin[e] : -1, ib = e < cnt ? pout[e] : -1;
+      if (dbg & 1) { ia = ia < 0 ? ia : (ia & 4095); ib = ib < 0 ? ib : (ib & 4095); }
+      if (dbg & 2) { ia = -1; ib = -1; }
+      s_in[e] = ia >= 0 ? (unsigned)ia * rowa : kOobOffset;
+      s_out[e] = ib >= 0 ? (unsigned)ib * rowb : kOobOffset;
+    }
+  }
+  __syncthreads();
+  float* dst = partial + ((size_t)k * nchunks + chunk) * cin * cout;
+  const int wa = wgrad_var_width(cin, sa), wb = wgrad_var_width(cout, sb);
+#define MSMD_VAR_CASE(A, B)                                                                  \
+  case A * 8 + B:                                                                            \
+    wgrad_var_body<NP, A, B>(in, cin, dout, cout, s_in, s_out, (f32x4*)lds_raw, 64 * sa,     \
+                             64 * sb, cnt, dst, dbg);                                        \
+    break
+  switch (wa * 8 + wb) {
+    MSMD_VAR_CASE(4, 4);
+    MSMD_VAR_CASE(4, 2);
+    MSMD_VAR_CASE(4, 1);
+    MSMD_VAR_CASE(2, 4);
+    MSMD_VAR_CASE(2, 2);
+    MSMD_VAR_CASE(2, 1);
+    MSMD_VAR_CASE(1, 4);
+    MSMD_VAR_CASE(1, 2);
+    MSMD_VAR_CASE(1, 1);
+  }
+#undef MSMD_VAR_CASE
+}
+
+
 // wgrad, 128 x 128 slabs with the operand conversion SHARED through LDS (round 2).
 // Ablating the lean kernel above (MSMD_WGRAD_DBG) shows its conversion phase alone is 52 %
 // of its time and adds to -- does not overlap with -- the MFMA phase: with 64 x 64 slabs
@@ -1719,6 +1931,22 @@ int wgrad_split_partials(const float* in_feat, int c_in, const float* d_out, int
     else
       MSMD_LAUNCH(spconv_wgrad_split_shared_kernel<1>, gs, dim3(256), 0, st, in_feat, c_in,
                   d_out, c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
+    return launch_status();
+  }
+  // slabs as wide as the layer needs (80 = 64 + 16, 96 = 64 + 32): default
+  static const int var_env = env_int2("MSMD_WGRAD_VAR", 1);
+  if (buf && var_env && !wide && !ranges) {
+    g_wgrad_ranges = false;
+    const dim3 gv(wgrad_grid(nchunks, kvol, wgrad_var_slabs(c_in) * wgrad_var_slabs(c_out)));
+    if (np == 3)
+      MSMD_LAUNCH(spconv_wgrad_split_var_kernel<3>, gv, dim3(256), 0, st, in_feat, c_in, d_out,
+                  c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
+    else if (np == 2)
+      MSMD_LAUNCH(spconv_wgrad_split_var_kernel<2>, gv, dim3(256), 0, st, in_feat, c_in, d_out,
+                  c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
+    else
+      MSMD_LAUNCH(spconv_wgrad_split_var_kernel<1>, gv, dim3(256), 0, st, in_feat, c_in, d_out,
+                  c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
     return launch_status();
   }
   g_wgrad_ranges = buf && ranges;

@@ -327,7 +327,8 @@ def test_split_conv_strided(dev, ks, st, pd, cin, cout):
 
 @pytest.mark.parametrize("planes", [3, 2])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128), (128, 64), (128, 128), (192, 64),
-                                      (80, 80), (80, 96), (96, 128), (68, 100)])
+                                      (80, 80), (80, 96), (96, 128), (68, 100), (96, 96),
+                                      (144, 80), (112, 160)])
 def test_split_wgrad(dev, cin, cout, planes):
     """msmd_spconv_wgrad_split against the oracle (SubM and strided pair lists,
     ragged chunk tails, [K,Cin,Cout] and KRSC outputs)."""

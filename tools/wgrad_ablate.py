@@ -37,14 +37,23 @@ for pad in [1, 1, [0, 1, 1]]:
     idx, _, _, shape = K.rulebook_conv(idx, 4, shape, 3, 2, pad)
 stages.append((idx, shape))
 out = []
-for si, cin, cout in [(2, 64, 64), (2, 128, 128), (3, 192, 192), (1, 96, 96)]:
+save = os.environ.get("MSMD_WGRAD_SAVE")       # directory: keep every dw (bit-compare two settings)
+for si, cin, cout in [(2, 64, 64), (2, 128, 128), (3, 192, 192), (1, 96, 96), (0, 80, 80),
+                      (0, 80, 96), (1, 96, 128), (2, 128, 192)]:
     idx, shape = stages[si]
     n = idx.shape[0]
     pairs, num = K.rulebook_pairs(K.rulebook_subm(idx, 4, shape, 3))
     P = int(num.sum())
-    f, g = torch.randn(n, cin, device=dev), torch.randn(n, cout, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(cin * 1000 + cout)
+    f = torch.randn(n, cin, device=dev, generator=gen)
+    g = torch.randn(n, cout, device=dev, generator=gen)
+    if save:
+        os.makedirs(save, exist_ok=True)
+        torch.save(K.conv_wgrad_split(f, g, pairs, num, 3).cpu(),
+                   os.path.join(save, "dw_%d_%d_%d.pt" % (si, cin, cout)))
     t = timed(lambda: K.conv_wgrad_split(f, g, pairs, num, 3))
     out.append("%d->%d %.0f us (%.0f TF)" % (cin, cout, t, 2.0 * P * cin * cout / t / 1e6))
-print("DBG=%s BUF=%s WIDE=%s | " % (os.environ.get("MSMD_WGRAD_DBG", "0"),
-                                   os.environ.get("MSMD_WGRAD_BUF", "1"),
-                                   os.environ.get("MSMD_WGRAD_WIDE", "0")) + " | ".join(out))
+print("DBG=%s BUF=%s WIDE=%s VAR=%s | " % (os.environ.get("MSMD_WGRAD_DBG", "0"),
+                                          os.environ.get("MSMD_WGRAD_BUF", "1"),
+                                          os.environ.get("MSMD_WGRAD_WIDE", "0"),
+                                          os.environ.get("MSMD_WGRAD_VAR", "1")) + " | ".join(out))
