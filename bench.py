@@ -30,8 +30,16 @@ import os
 import sys
 import time
 
-import torch
-import torch.nn.functional as F
+# One rank drives one GPU: its few host-side tensor ops (index lists, box targets) must not
+# fan out over every core of the node.  torch's intra-op pool defaults to all 256 hardware
+# threads; on a box whose cgroup grants 16 CPUs their spinning exhausts the quota and the
+# kernel throttles the whole process for the rest of each 100 ms period (measured with
+# /sys/fs/cgroup/cpu.stat: LC line 117 -> 128 samples/s, the head's step 33 -> 13 ms).
+# torch.distributed.run sets OMP_NUM_THREADS=1 for multi-rank launches already.
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -66,6 +74,15 @@ WORKLOADS = {
              "channels-last pixel rows by the sparse-conv kernels (fp32-equivalent), "
              "fwd+bwd+AdamW, 2 x (28.7k LiDAR + 50k virtual pts)/GPU, fp32",
         spg=MSMDFUSION_LC["samples_per_gpu"], bev_channels=512, settle=16),
+    "lc_full": dict(
+        metric="samples/sec MSMDFusion fwd+bwd nuScenes 0.075m voxel (MSMDFusion-LC LiDAR + "
+               "virtual-point path from points to losses)",
+        name="configs[2] + rows f1 + f3: the MSMDFusion-LC sparse path, bev_fusion (SPPModule) "
+             "+ SECOND + SECONDFPN, TransFusionHead (200 heat-map queries, 1 decoder layer) and "
+             "its loss (Hungarian targets for 40 synthetic boxes per sample, focal / L1 / Gaussian "
+             "focal), fwd+bwd+AdamW, 2 x (28.7k LiDAR + 50k virtual pts)/GPU, fp32 (image backbone "
+             "out of scope: virtual points arrive with their 49 image channels)",
+        spg=MSMDFUSION_LC["samples_per_gpu"], bev_channels=0, settle=16),
     "transfusion_l": dict(
         metric="samples/sec TransFusion-L voxel backbone fwd+bwd (nuScenes 0.075m voxel)",
         name="configs[1]: TransFusion-L voxel backbone (voxelize+VFE+SparseEncoder->BEV), "
@@ -177,6 +194,42 @@ class FusionTailBackbone(FusionBackbone):
         return self.tail(super().forward(points, virtual, prepared=prepared))[0]
 
 
+class FusionDetector(FusionTailBackbone):
+    """MSMDFusionDetector.forward_train's point branch (MSMDFusion.py:494-560 ->
+    forward_pts_train :562-590): extract_pts_feat, pts_bbox_head, its loss.  forward()
+    returns the summed losses of the batch's (synthetic, fixed) ground truth."""
+
+    def __init__(self, sample_ids=(), boxes_per_sample=40):
+        super().__init__()
+        import numpy as np
+        from msmdfusion_amd.configs import build_head
+        from msmdfusion_amd.head_loss import LiDARBoxes
+        self.head = build_head(MSMDFUSION_LC, rows=True)
+        self.gt_boxes, self.gt_labels = [], []
+        for i in sample_ids:                       # nuScenes-like sizes inside the range
+            rs = np.random.RandomState(1000 + i)
+            g = boxes_per_sample
+            b = np.zeros((g, 9), np.float32)
+            b[:, 0:2] = rs.uniform(-50, 50, (g, 2))
+            b[:, 2] = rs.uniform(-2.5, -0.5, g)
+            b[:, 3:6] = rs.uniform((0.5, 0.5, 1.0), (2.5, 6.0, 3.0), (g, 3))
+            b[:, 6] = rs.uniform(-3.14, 3.14, g)
+            b[:, 7:9] = rs.uniform(-5, 5, (g, 2))
+            self.gt_boxes.append(LiDARBoxes(torch.from_numpy(b)))
+            self.gt_labels.append(torch.from_numpy(rs.randint(0, 10, g).astype(np.int64)))
+
+    def _apply(self, fn, *a, **kw):                # ground truth travels with the module
+        out = super()._apply(fn, *a, **kw)
+        self.gt_boxes = [type(b)(fn(b.tensor)) for b in self.gt_boxes]
+        self.gt_labels = [fn(l) for l in self.gt_labels]
+        return out
+
+    def forward(self, points, virtual, prepared=None):
+        feats = FusionTailBackbone.forward(self, points, virtual, prepared=prepared)
+        losses = self.head.loss(self.gt_boxes, self.gt_labels, self.head(feats))
+        return sum(v for k, v in losses.items() if "loss" in k)
+
+
 def lc_worker_init(sample_ids, seed):
     """Runs in the index worker process (msmdfusion_amd/prefetch_proc.py): the synthetic
     data source and the index half of the LC step.  Weights play no part in prepare();
@@ -193,6 +246,19 @@ def lc_worker_init(sample_ids, seed):
     return produce
 
 
+def effective_cpus():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup's CPU quota
+    (threads beyond it only get the whole group throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(workload, seed=0, budget_s=14.0, max_samples=24):
     """The host baseline on a bounded sample: whole synthetic samples through the
     oracle port (oracle/baseline.py), one after the other, until ~budget_s of CPU
@@ -202,7 +268,7 @@ def cpu_baseline(workload, seed=0, budget_s=14.0, max_samples=24):
     from oracle import oracle as O
     # memory-bound gather/scatter loops stop scaling well before the socket is
     # full (256 hardware threads were slower than 8 here): cap at 32
-    cores = O.set_threads(min(os.cpu_count() or 1, 32))
+    cores = O.set_threads(min(effective_cpus(), 32))
     one = B.lc_sample if workload.startswith("lc") else B.transfusion_l_sample
     runs = []
     t_all = time.perf_counter()
@@ -240,10 +306,12 @@ def run_workload(workload, args, dev, rank, world, profile):
     from msmdfusion_amd.prefetch import IndexPrefetcher
 
     wl = WORKLOADS[workload]
-    lc = workload in ("lc", "lc_tail", "lc_b4")
+    lc = workload in ("lc", "lc_tail", "lc_b4", "lc_full")
     spg = wl["spg"]
     torch.manual_seed(0)
-    model = (FusionTailBackbone() if workload == "lc_tail" else FusionBackbone() if lc
+    ids = D.shard_sample_ids(rank, world, spg)      # disjoint samples per rank (weak scaling)
+    model = (FusionDetector(ids) if workload == "lc_full" else
+             FusionTailBackbone() if workload == "lc_tail" else FusionBackbone() if lc
              else Backbone()).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     net = D.wrap_data_parallel(model, device_ids=[dev.index])
@@ -252,13 +320,15 @@ def run_workload(workload, args, dev, rank, world, profile):
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01,
                             fused=os.environ.get("MSMD_FUSED_ADAMW", "1") == "1")
 
-    ids = D.shard_sample_ids(rank, world, spg)      # disjoint samples per rank (weak scaling)
     clouds = [torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in ids]
     batch = (clouds,)
     if lc:
         batch = (clouds, [torch.from_numpy(S.virtual_points(i)).to(dev) for i in ids])
-    target = torch.randn(spg, wl["bev_channels"], 180, 180, device=dev)
-    if lc:      # the LC path hands its BEV map over channels-last (see FusionBackbone.forward)
+    if workload == "lc_full":       # the module returns its loss: (loss * 1).mean()
+        target = torch.ones((), device=dev)
+    else:
+        target = torch.randn(spg, wl["bev_channels"], 180, 180, device=dev)
+    if lc and workload != "lc_full":      # the LC path hands its BEV map over channels-last (see FusionBackbone.forward)
         target = target.contiguous(memory_format=torch.channels_last)
 
     prefetch = None
@@ -379,6 +449,9 @@ def main():
             tail = run_workload("lc_tail", args, dev, rank, world, False)
             tail["metric"] = WORKLOADS["lc_tail"]["metric"]
             out["also"]["configs[2]+f1"] = tail
+            full = run_workload("lc_full", args, dev, rank, world, False)
+            full["metric"] = WORKLOADS["lc_full"]["metric"]
+            out["also"]["configs[2]+f1+f3"] = full
             b4 = run_workload("lc_b4", args, dev, rank, world, False)
             b4["metric"] = WORKLOADS["lc_b4"]["metric"]
             out["also"]["configs[2] @ 4/GPU"] = b4

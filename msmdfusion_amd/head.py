@@ -21,10 +21,25 @@ load unchanged.  Everything is torch / rocBLAS work except the 512 -> 128 3x3
 is the channels-last map the row tail produces.
 """
 import copy
+import os
 
 import torch
 from torch import nn
 from torch.nn import functional as F
+
+
+class Conv1d(nn.Conv1d):
+    """nn.Conv1d (same parameters, same state-dict keys); a kernel-size-1 convolution runs as
+    the matrix product it is.  MIOpen serves these through its 3x3 Winograd kernels --
+    0.6 ms per launch on the 32 400 key positions of the LC map, 32 launches (20 ms) per
+    training step for the head's position embeddings and prediction heads; rocBLAS needs
+    ~30 us for the same product."""
+
+    def forward(self, x):
+        if self.kernel_size != (1,) or self.stride != (1,) or self.groups != 1 or x.dim() != 3:
+            return super().forward(x)
+        y = torch.matmul(self.weight[:, :, 0], x)
+        return y if self.bias is None else y + self.bias[:, None]
 
 
 class ConvModule(nn.Module):
@@ -35,7 +50,7 @@ class ConvModule(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias="auto",
                  conv="Conv1d", norm="BN1d"):
         super().__init__()
-        conv_cls = {"Conv1d": nn.Conv1d, "Conv2d": nn.Conv2d}[conv]
+        conv_cls = {"Conv1d": Conv1d, "Conv2d": nn.Conv2d}[conv]
         norm_cls = {"BN1d": nn.BatchNorm1d, "BN2d": nn.BatchNorm2d, None: None}[norm]
         if bias == "auto":
             bias = norm_cls is None
@@ -57,9 +72,9 @@ class PositionEmbeddingLearned(nn.Module):
     def __init__(self, input_channel, num_pos_feats=288):
         super().__init__()
         self.position_embedding_head = nn.Sequential(
-            nn.Conv1d(input_channel, num_pos_feats, kernel_size=1),
+            Conv1d(input_channel, num_pos_feats, kernel_size=1),
             nn.BatchNorm1d(num_pos_feats), nn.ReLU(inplace=True),
-            nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
+            Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
 
     def forward(self, xyz):
         return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
@@ -122,8 +137,8 @@ class FFN(nn.Module):
                 layers.append(ConvModule(c_in, head_conv, final_kernel, 1, final_kernel // 2,
                                          bias=bias))
                 c_in = head_conv
-            layers.append(nn.Conv1d(head_conv, classes, final_kernel, 1, final_kernel // 2,
-                                    bias=True))
+            layers.append(Conv1d(head_conv, classes, final_kernel, 1, final_kernel // 2,
+                                 bias=True))
             setattr(self, name, nn.Sequential(*layers))
 
     def init_weights(self):
@@ -197,7 +212,7 @@ class TransFusionHead(nn.Module):
                 ConvModule(hidden_channel, hidden_channel, 3, padding=1, bias=bias, conv="Conv2d",
                            norm="BN2d"),
                 nn.Conv2d(hidden_channel, num_classes, 3, padding=1, bias=bool(bias)))
-            self.class_encoding = nn.Conv1d(num_classes, hidden_channel, 1)
+            self.class_encoding = Conv1d(num_classes, hidden_channel, 1)
         else:
             self.query_feat = nn.Parameter(torch.randn(1, hidden_channel, num_proposals))
             self.query_pos = nn.Parameter(torch.rand([1, num_proposals, 2]),
@@ -216,6 +231,7 @@ class TransFusionHead(nn.Module):
         x_size = test_cfg["grid_size"][0] // test_cfg["out_size_factor"]
         y_size = test_cfg["grid_size"][1] // test_cfg["out_size_factor"]
         self.bev_pos = self.create_2D_grid(x_size, y_size)
+        self._bev_pos_cache = {}
         self.query_labels = None
         from . import head_loss as HL
         self.loss_cls = HL.build_loss(loss_cls or dict(type="FocalLoss"))        # :609-611
@@ -242,26 +258,59 @@ class TransFusionHead(nn.Module):
             if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
                 m.momentum = self.bn_momentum
 
+    def _bev_pos_on(self, device, batch):
+        """bev_pos.repeat(B, 1, 1).to(device) (:800) without its per-call host work: the
+        reference repeats 64 800 floats on the CPU and copies them from pageable memory --
+        a blocking copy that drains the stream -- in every forward."""
+        key = (device, batch)
+        if self._bev_pos_cache.get("key") != key:
+            self._bev_pos_cache = {"key": key,
+                                   "value": self.bev_pos.to(device).repeat(batch, 1, 1)}
+        return self._bev_pos_cache["value"]
+
     def _shared_conv(self, inputs):
+        """-> (feature map [B, C, H, W] contiguous, its pixel rows | None, grid | None)"""
         if self.rows and inputs.is_cuda:
             from .grid_conv import grid_conv2d, map_of, rows_of
             rows, grid = rows_of(inputs)
             y, grid = grid_conv2d(rows.contiguous(), grid, self.shared_conv.weight, 1, 1, 1)
             if self.shared_conv.bias is not None:
                 y = y + self.shared_conv.bias
-            return map_of(y, grid).contiguous()
-        return self.shared_conv(inputs)
+            return map_of(y, grid).contiguous(), y, grid
+        return self.shared_conv(inputs), None, None
+
+    def _heatmap(self, lidar_feat, rows, grid):
+        """heatmap_head (:686-692): ConvModule 3x3 + Conv2d 3x3 -> class heat-map logits.  On
+        the row path both convolutions run on the sparse-conv kernels (the class conv with
+        its output channels zero-padded to the kernels' narrowest width, 32): MIOpen's fp32
+        Winograd kernels need 11 ms per training step for this pair at 180 x 180."""
+        if rows is None or os.environ.get("MSMD_HEAD_HEATMAP_ROWS", "1") != "1":
+            return self.heatmap_head(lidar_feat)
+        from .grid_conv import grid_conv2d, map_of
+        from .spconv import functional as Fsp
+        block, last = self.heatmap_head[0], self.heatmap_head[1]
+        y, grid = grid_conv2d(rows, grid, block.conv.weight, 1, 1, 1)
+        if block.conv.bias is not None:
+            y = y + block.conv.bias
+        y = Fsp.bn_act(y, block.bn, relu=True)
+        c = last.weight.shape[0]
+        width = max(32, (c + 3) // 4 * 4)
+        z, grid = grid_conv2d(y, grid, F.pad(last.weight, (0, 0, 0, 0, 0, 0, 0, width - c)), 1, 1, 1)
+        z = z[:, :c]
+        if last.bias is not None:
+            z = z + last.bias
+        return map_of(z.contiguous(), grid).contiguous()
 
     def forward_single(self, inputs):
         """:795-1027, fuse_img False.  inputs [B, C, H, W] -> [dict] with center, height,
         dim, rot, vel, heatmap ([B, *, num_proposals * layers] when auxiliary) and, for
         heatmap-initialised queries, query_heatmap_score and dense_heatmap."""
         B = inputs.shape[0]
-        lidar_feat = self._shared_conv(inputs)
+        lidar_feat, rows, grid = self._shared_conv(inputs)
         flat = lidar_feat.reshape(B, lidar_feat.shape[1], -1)
-        bev_pos = self.bev_pos.repeat(B, 1, 1).to(lidar_feat.device)
+        bev_pos = self._bev_pos_on(lidar_feat.device, B)
         if self.initialize_by_heatmap:
-            dense_heatmap = self.heatmap_head(lidar_feat)
+            dense_heatmap = self._heatmap(lidar_feat, rows, grid)
             heatmap = dense_heatmap.detach().sigmoid()
             pad = self.nms_kernel_size // 2
             local_max = torch.zeros_like(heatmap)
@@ -271,8 +320,8 @@ class TransFusionHead(nn.Module):
             keep = {"nuScenes": (8, 9), "Waymo": (1, 2)}.get(dataset, ())
             for c in keep:                     # small classes: every cell is its own maximum
                 local_max[:, c] = heatmap[:, c]
-            heatmap = (heatmap * (heatmap == local_max)).view(B, heatmap.shape[1], -1)
-            top = heatmap.view(B, -1).argsort(dim=-1, descending=True)[..., :self.num_proposals]
+            heatmap = (heatmap * (heatmap == local_max)).reshape(B, heatmap.shape[1], -1)
+            top = heatmap.reshape(B, -1).argsort(dim=-1, descending=True)[..., :self.num_proposals]
             top_class = top // heatmap.shape[-1]
             top_index = top % heatmap.shape[-1]
             query_feat = flat.gather(index=top_index[:, None, :].expand(-1, flat.shape[1], -1),

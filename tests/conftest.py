@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# torch's intra-op pool defaults to every hardware thread of the node; under a cgroup CPU
+# quota their spinning gets the whole test process throttled (see bench.py)
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

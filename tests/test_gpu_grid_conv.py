@@ -166,3 +166,36 @@ def test_head_on_gpu_after_the_row_tail(dev):
     boxes = head_rows.get_bboxes(a)
     assert len(boxes) == 2 and boxes[0]["bboxes"].shape[1] == 9
     assert torch.isfinite(boxes[0]["bboxes"]).all()
+
+
+def test_head_heatmap_rows_train_mode_gradients(dev):
+    """shared_conv + heatmap_head (ConvModule with batch statistics + class conv with its 10
+    outputs padded to 32) on the row kernels against the torch / MIOpen path: logits and the
+    gradients of every parameter involved."""
+    import copy
+    from msmdfusion_amd import configs as C
+    torch.manual_seed(1)
+    head_rows = C.build_head(rows=True).to(dev).train()
+    head_ref = C.build_head(rows=False).to(dev).train()
+    head_ref.load_state_dict(copy.deepcopy(head_rows.state_dict()))
+    x = torch.randn(2, 512, 60, 60, device=dev)
+    w = torch.randn(2, 10, 60, 60, device=dev)
+    outs = []
+    for head in (head_rows, head_ref):
+        feat, rows, grid = head._shared_conv(x)
+        assert (rows is None) == (head is head_ref)
+        hm = head._heatmap(feat, rows, grid)
+        assert hm.is_contiguous() and tuple(hm.shape) == (2, 10, 60, 60)
+        (hm * w).mean().backward()
+        outs.append(hm.detach())
+    scale = float(outs[1].abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-4 * scale
+    for name in ("shared_conv.weight", "shared_conv.bias", "heatmap_head.0.conv.weight",
+                 "heatmap_head.0.bn.weight", "heatmap_head.0.bn.bias", "heatmap_head.1.weight",
+                 "heatmap_head.1.bias"):
+        ga = dict(head_rows.named_parameters())[name].grad
+        gb = dict(head_ref.named_parameters())[name].grad
+        rel = float((ga - gb).norm() / gb.norm().clamp(min=1e-12))
+        assert rel < 2e-3, (name, rel)
+    assert torch.allclose(head_rows.heatmap_head[0].bn.running_var,
+                          head_ref.heatmap_head[0].bn.running_var, rtol=1e-4)
