@@ -104,6 +104,19 @@ int msmd_rulebook_subm3d(const int32_t* indices /* [n,4] */, int n,
                          int32_t* nbr /* [K,n] */, void* workspace,
                          size_t workspace_bytes, msmd_stream_t stream);
 
+/* The same table through an occupancy bitmap of the grid instead of the hash (1 bit per
+ * cell, a popcount prefix per 256-cell block, a rank -> row table): cost = a clear and a
+ * counting pass over batch_size * D*H*W / 8 bytes plus ~9 word reads per voxel, against 27
+ * random slot reads per voxel for the hash -- the better choice for large voxel sets and
+ * for the small grids of the deeper stages.  Identical output (duplicates keep the last
+ * row). */
+size_t msmd_rulebook_subm_bitmap_workspace_bytes(int n, int batch_size,
+                                                 const int* spatial_shape);
+int msmd_rulebook_subm3d_bitmap(const int32_t* indices, int n, int batch_size,
+                                const int* spatial_shape, const int* ksize,
+                                int32_t* nbr, void* workspace, size_t workspace_bytes,
+                                msmd_stream_t stream);
+
 /* ------------------------------------------------------------------------ *
  * a6  Strided (regular) sparse conv rulebook, two phases with one host read
  * replaces: sparse_conv_ext.get_indice_pairs_3d(..., subM=0)

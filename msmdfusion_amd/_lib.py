@@ -42,6 +42,8 @@ SIGNATURES = {
     "msmd_voxel_mean": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "msmd_rulebook_subm_workspace_bytes": (_sz, [_i]),
     "msmd_rulebook_subm3d": (_i, [_vp, _i, _i, _ip, _ip, _vp, _vp, _sz, _vp]),
+    "msmd_rulebook_subm_bitmap_workspace_bytes": (_sz, [_i, _i, _ip]),
+    "msmd_rulebook_subm3d_bitmap": (_i, [_vp, _i, _i, _ip, _ip, _vp, _vp, _sz, _vp]),
     "msmd_rulebook_conv_workspace_bytes": (_sz, [_i, _ip]),
     "msmd_rulebook_conv3d_count": (_i, [_vp, _i, _i, _ip, _ip, _ip, _ip, _vp, _vp, _sz, _vp]),
     "msmd_rulebook_conv3d_fill": (_i, [_vp, _i, _i, _ip, _ip, _ip, _ip, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

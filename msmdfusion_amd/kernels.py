@@ -5,6 +5,7 @@ computation is a call into libmsmd_hip.so on torch's current stream.  All
 functions require CUDA (ROCm) tensors and raise otherwise -- no CPU path.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -169,7 +170,25 @@ def conv_output_size(in_shape, ksize, stride, padding, dilation=(1, 1, 1)):
             for i in range(3)]
 
 
-def rulebook_subm(indices, batch_size, spatial_shape, ksize):
+# SubM index: "hash" (2N-slot table, cost ~ voxels), "bitmap" (occupancy words of the grid,
+# cost ~ grid cells + a third of the hash's per-voxel cost) or "auto" by size
+_SUBM_INDEX = os.environ.get("MSMD_SUBM_INDEX", "auto")
+_SUBM_BITMAP_WORDS_PER_VOXEL = float(os.environ.get("MSMD_SUBM_BITMAP_WORDS_PER_VOXEL", "100"))
+_SUBM_BITMAP_MIN_VOXELS = int(os.environ.get("MSMD_SUBM_BITMAP_MIN_VOXELS", "60000"))
+
+
+def subm_index_method(n, batch_size, spatial_shape, method=None):
+    method = method or _SUBM_INDEX
+    if method != "auto":
+        return method
+    words = int(batch_size) * int(spatial_shape[0]) * int(spatial_shape[1]) * int(spatial_shape[2]) / 32
+    # the bitmap's clear + count (~3 ps per 32-cell word) against what it saves per voxel
+    # (~0.3 ns), and not below the size where either is launch-bound anyway
+    return "bitmap" if n >= _SUBM_BITMAP_MIN_VOXELS and words <= _SUBM_BITMAP_WORDS_PER_VOXEL * n \
+        else "hash"
+
+
+def rulebook_subm(indices, batch_size, spatial_shape, ksize, method=None):
     """-> nbr[K,N] int32 (output-stationary neighbour table)."""
     _need_bzyx(indices)
     _need_cuda(indices)
@@ -177,6 +196,14 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize):
     n = idx.shape[0]
     ks = _expand3(ksize)
     nbr = torch.empty((kernel_volume(ks), n), dtype=torch.int32, device=idx.device)
+    if subm_index_method(n, batch_size, spatial_shape, method) == "bitmap":
+        nbytes = lib.msmd_rulebook_subm_bitmap_workspace_bytes(n, int(batch_size),
+                                                               int3(spatial_shape))
+        ws = _ws(nbytes, idx.device)
+        check(lib.msmd_rulebook_subm3d_bitmap(_p(idx), n, int(batch_size), int3(spatial_shape),
+                                              int3(ks), _p(nbr), _p(ws), nbytes, _stream()),
+              "msmd_rulebook_subm3d_bitmap")
+        return nbr
     nbytes = lib.msmd_rulebook_subm_workspace_bytes(n)
     ws = _ws(nbytes, idx.device)
     check(lib.msmd_rulebook_subm3d(_p(idx), n, int(batch_size), int3(spatial_shape), int3(ks),

@@ -86,7 +86,9 @@ def _check_rulebook(dev, idx, batch, shape, subm, ks, st, pd):
     oi, pr, nm, osz = O.get_indice_pairs(idx, batch, shape, ks, st, pd, 1, subm)
     d_idx = t(idx, dev)
     if subm:
-        nbr = K.rulebook_subm(d_idx, batch, shape, ks)
+        nbr = K.rulebook_subm(d_idx, batch, shape, ks, method="hash")
+        # the occupancy-bitmap index builds the identical table
+        assert torch.equal(K.rulebook_subm(d_idx, batch, shape, ks, method="bitmap"), nbr)
         # SubM keeps input order: compare raw rows
         exp = np.full((nm.shape[0], idx.shape[0]), -1, np.int32)
         for k in range(nm.shape[0]):
@@ -147,6 +149,30 @@ def test_rulebook_edges(dev):
     assert K.rulebook_subm(empty, 1, shape, 3).shape == (27, 0)
     oi, f, b, _ = K.rulebook_conv(empty, 1, shape, 3, 2, 1)
     assert oi.shape[0] == 0 and f.shape == (27, 0)
+
+
+def test_rulebook_subm_index_methods(dev):
+    """hash and bitmap SubM indices: duplicate coordinates (both keep the LAST row, as the
+    CPU reference's grid does, geometry.h:277-282), cells at the word boundaries of the
+    bitmap, a line kernel, and the automatic choice by size."""
+    from msmdfusion_amd import kernels as K
+    shape = [3, 5, 70]
+    rows = [[0, 1, 2, x] for x in (0, 30, 31, 32, 33, 63, 64, 65, 69)]
+    rows += [[1, 1, 2, 31], [1, 1, 2, 32], [0, 1, 2, 31], [1, 2, 4, 69], [1, 2, 4, 0], [0, 1, 2, 31]]
+    idx = np.array(rows, np.int32)
+    d = t(idx, dev)
+    for ks in (3, [1, 1, 3], [3, 1, 1], 5):
+        a = K.rulebook_subm(d, 2, shape, ks, method="hash")
+        b = K.rulebook_subm(d, 2, shape, ks, method="bitmap")
+        assert torch.equal(a, b), ks
+    centre = K.rulebook_subm(d, 2, shape, 3, method="bitmap")[13].cpu().numpy()
+    assert centre[2] == 14 and centre[11] == 14 and centre[14] == 14    # last duplicate wins
+    assert K.subm_index_method(720000, 1, [41, 1440, 1440]) == "bitmap"
+    assert K.subm_index_method(38000, 2, [41, 1440, 1440]) == "hash"
+    big = S.random_voxel_indices(90000, 2, [21, 300, 300], seed=5)
+    assert K.subm_index_method(big.shape[0], 2, [21, 300, 300]) == "bitmap"
+    assert torch.equal(K.rulebook_subm(t(big, dev), 2, [21, 300, 300], 3),
+                       K.rulebook_subm(t(big, dev), 2, [21, 300, 300], 3, method="hash"))
 
 
 # ------------------------------------------------------------------ convolution

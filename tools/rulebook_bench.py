@@ -55,13 +55,25 @@ def case(name, clouds, voxel_size, shape, max_voxels):
                 GBps=round(vox_bytes / us / 1e3, 1), frac_hbm=round(vox_bytes / us / 1e3 / HBM_PEAK, 4))]
     idx = torch.cat([F.pad(r[1], (1, 0), value=i) for i, r in enumerate(res)]).contiguous()
     n = idx.shape[0]
-    us, nbr = timed(lambda: K.rulebook_subm(idx, b, shape, 3))
     t = 1 << max((2 * n - 1).bit_length(), 6)
-    sub_bytes = 16 * n + 8 * t + 4 * 27 * n
-    out.append(dict(kernel="rulebook_subm3d 3x3x3", case=name, voxels=n,
-                    pairs=int((nbr >= 0).sum()), us=round(us, 1), algo_MB=round(sub_bytes / 1e6, 2),
-                    GBps=round(sub_bytes / us / 1e3, 1),
-                    frac_hbm=round(sub_bytes / us / 1e3 / HBM_PEAK, 4)))
+    sub_bytes = 16 * n + 8 * t + 4 * 27 * n            # index rows + hash slots + the table
+    auto = K.subm_index_method(n, b, shape)
+    for method in ("hash", "bitmap"):
+        us, nbr = timed(lambda: K.rulebook_subm(idx, b, shape, 3, method=method))
+        out.append(dict(kernel="rulebook_subm3d 3x3x3 (%s index%s)"
+                               % (method, ", the automatic choice" if method == auto else ""),
+                        case=name, voxels=n, pairs=int((nbr >= 0).sum()), us=round(us, 1),
+                        algo_MB=round(sub_bytes / 1e6, 2), GBps=round(sub_bytes / us / 1e3, 1),
+                        frac_hbm=round(sub_bytes / us / 1e3 / HBM_PEAK, 4)))
+    # the deeper stages' grids (stride-2 outputs): same voxels-per-sample order, 8x fewer cells
+    idx2, _, _, shape2 = K.rulebook_conv(idx, b, shape, 3, 2, 1, need_bwd=False)
+    n2 = idx2.shape[0]
+    for method in ("hash", "bitmap"):
+        us, _ = timed(lambda: K.rulebook_subm(idx2, b, list(shape2), 3, method=method))
+        out.append(dict(kernel="rulebook_subm3d 3x3x3, stage-1 grid %s (%s index%s)"
+                               % ("x".join(map(str, shape2)), method, ", the automatic choice"
+                                  if method == K.subm_index_method(n2, b, shape2) else ""),
+                        case=name, voxels=n2, us=round(us, 1)))
     us, (oi, nf, nb_, osz) = timed(lambda: K.rulebook_conv(idx, b, shape, 3, 2, 1))
     words = (b * osz[0] * osz[1] * osz[2] + 31) // 32
     cv_bytes = 32 * n + 8 * words + 4 * 27 * (oi.shape[0] + n) + 16 * oi.shape[0]
