@@ -38,11 +38,16 @@ import time
 # torch.distributed.run sets OMP_NUM_THREADS=1 for multi-rank launches already.
 os.environ.setdefault("OMP_NUM_THREADS", "8")
 
-import torch  # noqa: E402
-import torch.nn.functional as F  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# ... and the rank's threads stay on a few CPUs (before anything creates threads): unpinned,
+# the same binary on the same box reads 100-133 samples/s from run to run, pinned 128-130
+from msmdfusion_amd.hostcpu import pin_host_threads  # noqa: E402
+PINNED_CPUS = pin_host_threads()
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
 
 PEAK_BF16_MFMA_TFLOPS = 2516.6   # 256 CUs x 4096 flop/clk x 2.4 GHz, dense
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
@@ -264,10 +269,16 @@ def cpu_baseline(workload, seed=0, budget_s=14.0, max_samples=24):
     oracle port (oracle/baseline.py), one after the other, until ~budget_s of CPU
     work is done (the first one also warms the OpenMP pool and the page cache and
     is not counted when more follow)."""
+    from msmdfusion_amd.hostcpu import unpinned
+    with unpinned():         # the rank's own threads are pinned to four CPUs: not this leg
+        return _cpu_baseline(workload, seed, budget_s, max_samples)
+
+
+def _cpu_baseline(workload, seed, budget_s, max_samples):
     from oracle import baseline as B
     from oracle import oracle as O
     # memory-bound gather/scatter loops stop scaling well before the socket is
-    # full (256 hardware threads were slower than 8 here): cap at 32
+    # full: cap at 32, and at what the cgroup grants
     cores = O.set_threads(min(effective_cpus(), 32))
     one = B.lc_sample if workload.startswith("lc") else B.transfusion_l_sample
     runs = []
@@ -352,8 +363,16 @@ def run_workload(workload, args, dev, rank, world, profile):
     # Setup, untimed: let torch's caching allocator reach its steady state before
     # the W warm-up steps.  The LC path allocates on four streams (record_stream
     # defers block reuse) and needs ~16 steps before no step calls hipMalloc any more.
-    for _ in range(wl["settle"] if (lc or prefetch is not None) else 2):
+    # ... and the GPU its clocks: from idle they ramp over several hundred ms of load (the
+    # configs[1] line reads 326 samples/s after 15 untimed steps = 0.14 s, 454 after 70), so
+    # the untimed setup also lasts at least MSMD_BENCH_SETTLE_S seconds of stepping
+    settle_s = float(os.environ.get("MSMD_BENCH_SETTLE_S", "1.5"))
+    t_settle, n_settle = time.perf_counter(), 0
+    while n_settle < (wl["settle"] if (lc or prefetch is not None) else 2) or \
+            time.perf_counter() - t_settle < settle_s:
         step(batch)
+        n_settle += 1
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(batch)
     if args.diag and rank == 0:     # host enqueue time vs device time, outside the timed region
