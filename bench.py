@@ -37,6 +37,10 @@ import time
 # /sys/fs/cgroup/cpu.stat: LC line 117 -> 128 samples/s, the head's step 33 -> 13 ms).
 # torch.distributed.run sets OMP_NUM_THREADS=1 for multi-rank launches already.
 os.environ.setdefault("OMP_NUM_THREADS", "8")
+# The LC step keeps six streams busy (feature pass, index prefetch, four neighbour-search
+# streams); the HIP runtime multiplexes a process's streams onto 4 hardware queues by default.
+# One queue each: 129.4 -> 131.9-133.5 samples/s (read before the runtime initialises).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
