@@ -23,7 +23,9 @@ if not os.path.exists(LIB_PATH):
         "`make -C msmdfusion_amd/csrc` (hipcc, --offload-arch=gfx950). "
         "msmdfusion_amd has no fallback path.")
 
-lib = C.CDLL(LIB_PATH)
+# MSMD_PYDLL=1 (experiment): keep the interpreter lock across library calls -- no hand-over to
+# the other Python thread at every launch; see DESIGN.md 8.5 for what it measured
+lib = (C.PyDLL if os.environ.get("MSMD_PYDLL") == "1" else C.CDLL)(LIB_PATH)
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _i64 = C.c_int64

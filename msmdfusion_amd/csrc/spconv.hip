@@ -516,9 +516,11 @@ __global__ __launch_bounds__(256) void row_mask_kernel(const int32_t* __restrict
 
 // The same key in 32 bits (K <= 31), for the in-library radix sort (tiling.hip).
 __global__ __launch_bounds__(256) void row_key32_kernel(const int32_t* __restrict__ nbr, int kvol,
-                                                        int n, uint32_t* __restrict__ key) {
+                                                        int n, uint32_t* __restrict__ key,
+                                                        int32_t* __restrict__ row_ids) {
   int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= n) return;
+  if (row_ids) row_ids[o] = o;          // the sort's payload (was a launch of its own)
   unsigned v = 0, ranked = 0;
   for (int k = 0; k < kvol; ++k)
     if (nbr[(size_t)k * n + o] >= 0) {
@@ -535,7 +537,8 @@ __global__ __launch_bounds__(256) void row_key32_kernel(const int32_t* __restric
 // tile t = positions [t * rows, (t+1) * rows) of `order`.  One block per tile.
 __global__ __launch_bounds__(128) void tile_cost_kernel(const int32_t* __restrict__ nbr, int kvol,
                                                         int n, const int32_t* __restrict__ order,
-                                                        int rows, int32_t* __restrict__ cost) {
+                                                        int rows, int32_t* __restrict__ cost,
+                                                        int32_t* __restrict__ tile_ids) {
   __shared__ unsigned long long u;
   if (threadIdx.x == 0) u = 0;
   __syncthreads();
@@ -548,7 +551,10 @@ __global__ __launch_bounds__(128) void tile_cost_kernel(const int32_t* __restric
   }
   if (v) atomicOr(&u, v);
   __syncthreads();
-  if (threadIdx.x == 0) cost[blockIdx.x] = kvol - __popcll(u);
+  if (threadIdx.x == 0) {
+    cost[blockIdx.x] = kvol - __popcll(u);
+    if (tile_ids) tile_ids[blockIdx.x] = blockIdx.x;      // the tile sort's payload
+  }
 }
 
 // ------------------------------------------------------------------ wgrad --
@@ -836,16 +842,17 @@ MSMD_EXPORT int msmd_rulebook_row_masks(const int32_t* nbr, int kernel_volume, i
 
 namespace msmd {
 // for tiling.hip: 32-bit sort keys (and how many of their bits matter) / tile costs
-void launch_row_keys(const int32_t* nbr, int kvol, int n, uint32_t* keys, int* key_bits,
-                     hipStream_t st) {
-  MSMD_LAUNCH(row_key32_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, nbr, kvol, n, keys);
+void launch_row_keys(const int32_t* nbr, int kvol, int n, uint32_t* keys, int32_t* row_ids,
+                     int* key_bits, hipStream_t st) {
+  MSMD_LAUNCH(row_key32_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, nbr, kvol, n, keys,
+              row_ids);
   *key_bits = kvol == 27 ? 27 : (kvol <= 15 ? 2 * kvol + 1 : 32);
   if (*key_bits > 32) *key_bits = 32;
 }
 void launch_tile_costs(const int32_t* nbr, int kvol, int n, const int32_t* order, int rows,
-                       int32_t* cost, hipStream_t st) {
+                       int32_t* cost, int32_t* tile_ids, hipStream_t st) {
   MSMD_LAUNCH(tile_cost_kernel, dim3(ceil_div(n, rows)), dim3(128), 0, st, nbr, kvol, n, order,
-              rows, cost);
+              rows, cost, tile_ids);
 }
 }  // namespace msmd
 
@@ -857,7 +864,8 @@ MSMD_EXPORT int msmd_rulebook_tile_costs(const int32_t* nbr, int kernel_volume, 
     return MSMD_ERR_INVALID_ARG;
   if (n_rows == 0) return MSMD_OK;
   MSMD_LAUNCH(tile_cost_kernel, dim3(ceil_div(n_rows, rows_per_tile)), dim3(128), 0,
-              (hipStream_t)stream, nbr, kernel_volume, n_rows, order, rows_per_tile, cost);
+              (hipStream_t)stream, nbr, kernel_volume, n_rows, order, rows_per_tile, cost,
+              (int32_t*)nullptr);
   return launch_status();
 }
 

@@ -19,17 +19,12 @@
 
 namespace msmd {
 // defined in spconv.hip
-void launch_row_keys(const int32_t* nbr, int kvol, int n, uint32_t* keys, int* key_bits,
-                     hipStream_t st);
+void launch_row_keys(const int32_t* nbr, int kvol, int n, uint32_t* keys, int32_t* row_ids,
+                     int* key_bits, hipStream_t st);
 void launch_tile_costs(const int32_t* nbr, int kvol, int n, const int32_t* order, int rows,
-                       int32_t* cost, hipStream_t st);
+                       int32_t* cost, int32_t* tile_ids, hipStream_t st);
 
 namespace {
-
-__global__ __launch_bounds__(256) void iota_kernel(int32_t* a, int n) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) a[i] = i;
-}
 
 // order[p] = sorted[tile_seq[t] * rows + p % rows] for the full tiles, the partial last
 // tile stays last; tiled[k][p] = nbr[k][order[p]].
@@ -109,15 +104,13 @@ MSMD_EXPORT int msmd_rulebook_tiling(const int32_t* nbr, int kernel_volume, int 
   hipStream_t st = (hipStream_t)stream;
   const int n = n_rows, full = n / rows_per_tile;
   int key_bits = 32;
-  launch_row_keys(nbr, kernel_volume, n, w.keys, &key_bits, st);
-  MSMD_LAUNCH(iota_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, w.vals, n);
+  launch_row_keys(nbr, kernel_volume, n, w.keys, w.vals, &key_bits, st);   // keys + row ids
   size_t cb = w.cub_bytes;
   if (hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.keys, w.keys_out, w.vals, w.sorted, n, 0,
                                          key_bits, st) != hipSuccess)
     return MSMD_ERR_LAUNCH;
   if (full > 1) {
-    launch_tile_costs(nbr, kernel_volume, n, w.sorted, rows_per_tile, w.cost, st);
-    MSMD_LAUNCH(iota_kernel, dim3(ceil_div(full, 256)), dim3(256), 0, st, w.tile_ids, full);
+    launch_tile_costs(nbr, kernel_volume, n, w.sorted, rows_per_tile, w.cost, w.tile_ids, st);
     cb = w.cub_bytes;
     if (hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.cost, w.cost_out, w.tile_ids, w.tile_seq,
                                            full, 0, 6, st) != hipSuccess)   // cost <= 31
