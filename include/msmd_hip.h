@@ -629,6 +629,18 @@ int msmd_gaussian_focal_f32(const float* logits, const float* target, int64_t n,
                             float* sums /* [2] */, void* workspace,
                             size_t workspace_bytes, msmd_stream_t stream);
 
+/* ------------------------------------------------------------------------ *
+ * Counts the host waits for (a5/a6/a17 callers): no reference counterpart -- the
+ * reference reads such counts with .item() / torch::_unique's implicit sync.
+ * Any `int32_t* n_out` / `count` output of this header may point into pinned host
+ * memory mapped for the device (hipHostMalloc; msmd_host_device_pointer gives the
+ * address to pass); msmd_host_wait_i32 then spins until the producing kernel has
+ * replaced `sentinel` in that slot -- no device->host copy, no stream synchronisation.
+ * Returns MSMD_ERR_LAUNCH when nothing arrives within timeout_us. */
+int msmd_host_device_pointer(void* host_ptr, void** device_ptr);
+int msmd_host_wait_i32(const int32_t* slot, int32_t sentinel, int64_t timeout_us,
+                       int32_t* value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,8 @@ SIGNATURES = {
     "msmd_voxel_mean": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "msmd_rulebook_subm_workspace_bytes": (_sz, [_i]),
     "msmd_rulebook_subm3d": (_i, [_vp, _i, _i, _ip, _ip, _vp, _vp, _sz, _vp]),
+    "msmd_host_device_pointer": (_i, [_vp, C.POINTER(C.c_void_p)]),
+    "msmd_host_wait_i32": (_i, [_vp, _i, _i64, _ip]),
     "msmd_rulebook_subm_bitmap_workspace_bytes": (_sz, [_i, _i, _ip]),
     "msmd_rulebook_subm3d_bitmap": (_i, [_vp, _i, _i, _ip, _ip, _vp, _vp, _sz, _vp]),
     "msmd_rulebook_conv_workspace_bytes": (_sz, [_i, _ip]),
