@@ -147,6 +147,22 @@ int msmd_rulebook_conv3d_fill(const int32_t* indices, int n, int batch_size,
                               void* workspace, size_t workspace_bytes,
                               msmd_stream_t stream);
 
+/* A chain of strided convs whose input set is the previous one's output set
+ * (SparseEncoder: sparse_encoder.py:175-187, only SubM convs in between): all levels
+ * counted back to back -- level l+1 is marked from level l's occupancy bitmap -- so the
+ * host reads n_out[0..levels) ONCE instead of once per level (the reference's
+ * getIndicePairs syncs per conv).  out_shapes / ksizes / strides / paddings: [levels][3].
+ * The workspace is the concatenation of the per-level msmd_rulebook_conv_workspace_bytes
+ * blocks (each rounded up to 256 bytes): afterwards msmd_rulebook_conv3d_fill runs per
+ * level on its own block, level l's input rows being level l-1's out_indices. */
+size_t msmd_rulebook_conv_chain_workspace_bytes(int batch_size, int levels,
+                                                const int* out_shapes);
+int msmd_rulebook_conv3d_count_chain(const int32_t* indices, int n, int batch_size,
+                                     int levels, const int* out_shapes, const int* ksizes,
+                                     const int* strides, const int* paddings,
+                                     int32_t* n_out /* [levels] */, void* workspace,
+                                     size_t workspace_bytes, msmd_stream_t stream);
+
 /* nbr table -> reference rulebook format: indice_pairs[K,2,ld] (-1 padded,
  * pairs of one offset sorted by output row) and indice_num[K]
  * (spconv_ops.h:55-59).  n_rows = number of output rows of `nbr`. */

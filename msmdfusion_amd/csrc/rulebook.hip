@@ -182,6 +182,41 @@ __global__ __launch_bounds__(256) void conv_mark(const int32_t* __restrict__ idx
     bitmap_set(bits, cell_id(r.x, z, y, x, g.shape));
 }
 
+// The same marking pass with the INPUT set given as the occupancy bitmap of its grid (the
+// previous strided conv's output bitmap) instead of a row list: what lets a chain of strided
+// convs count all its output sets back to back, without the host reading one count before
+// the next level can start (msmd_rulebook_conv3d_count_chain).
+__global__ __launch_bounds__(256) void conv_mark_from_bits(const uint32_t* __restrict__ in_bits,
+                                                           long in_words, int in_d, int in_h,
+                                                           int in_w, Geom g, uint32_t* bits) {
+  const long wi = (long)blockIdx.x * 256 + threadIdx.x;
+  if (wi >= in_words) return;
+  uint32_t word = in_bits[wi];
+  while (word) {
+    const int bit = __ffs(word) - 1;
+    word &= word - 1;
+    uint32_t c = (uint32_t)(wi * 32 + bit);
+    const int x = c % in_w;
+    c /= in_w;
+    const int y = c % in_h;
+    c /= in_h;
+    const int z = c % in_d, b = c / in_d;
+    for (int kz = 0; kz < g.ks[0]; ++kz) {
+      int oz;
+      if (!out_coord(z, kz, g.pd[0], g.st[0], g.shape[0], &oz)) continue;
+      for (int ky = 0; ky < g.ks[1]; ++ky) {
+        int oy;
+        if (!out_coord(y, ky, g.pd[1], g.st[1], g.shape[1], &oy)) continue;
+        for (int kx = 0; kx < g.ks[2]; ++kx) {
+          int ox;
+          if (out_coord(x, kx, g.pd[2], g.st[2], g.shape[2], &ox))
+            bitmap_set(bits, cell_id(b, oz, oy, ox, g.shape));
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void conv_fill(const int32_t* __restrict__ idx, int n, Geom g,
                                                  const uint32_t* __restrict__ bits,
                                                  const int* __restrict__ prefix, int n_out,
@@ -405,6 +440,65 @@ MSMD_EXPORT int msmd_rulebook_conv3d_count(const int32_t* indices, int n, int ba
     MSMD_LAUNCH(conv_mark, dim3(ceil_div(n, 256), g.kvol), dim3(256), 0, st, indices, n, g,
                        w.bits);
   device_scan(PopcCount{w.bits}, StorePrefix{w.prefix}, (int)w.words, w.tiles, n_out, -1, st);
+  return launch_status();
+}
+
+// A chain of strided convs (each one's input set = the previous one's output set, as in
+// SparseEncoder where only set-preserving SubM convs sit between them): the output sets of
+// ALL levels are marked and counted back to back -- level l+1 from level l's bitmap -- and
+// the host reads the `levels` counts once instead of once per level.  The workspace is the
+// concatenation of the per-level msmd_rulebook_conv_workspace_bytes blocks (256-byte
+// aligned), so msmd_rulebook_conv3d_fill runs per level on its own block afterwards.
+MSMD_EXPORT size_t msmd_rulebook_conv_chain_workspace_bytes(int batch_size, int levels,
+                                                            const int* out_shapes) {
+  if (levels < 1 || !out_shapes) return 0;
+  size_t total = 0;
+  for (int l = 0; l < levels; ++l)
+    total += align_up(msmd_rulebook_conv_workspace_bytes(batch_size, out_shapes + 3 * l));
+  return total;
+}
+
+MSMD_EXPORT int msmd_rulebook_conv3d_count_chain(const int32_t* indices, int n, int batch_size,
+                                                 int levels, const int* out_shapes,
+                                                 const int* ksizes, const int* strides,
+                                                 const int* paddings, int32_t* n_out,
+                                                 void* workspace, size_t workspace_bytes,
+                                                 msmd_stream_t stream) {
+  if (levels < 1 || !out_shapes || !ksizes || !strides || !paddings || !n_out)
+    return MSMD_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && !indices)) return MSMD_ERR_INVALID_ARG;
+  if (workspace_bytes < msmd_rulebook_conv_chain_workspace_bytes(batch_size, levels, out_shapes) ||
+      ((uintptr_t)workspace & 255))
+    return MSMD_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  ConvWs prev{};
+  const int* prev_shape = nullptr;
+  for (int l = 0; l < levels; ++l) {
+    Geom g;
+    int rc = check_geom(out_shapes + 3 * l, ksizes + 3 * l, strides + 3 * l, paddings + 3 * l,
+                        batch_size, &g);
+    if (rc) return rc;
+    const size_t bytes = align_up(msmd_rulebook_conv_workspace_bytes(batch_size, out_shapes + 3 * l));
+    Arena a(base, bytes);
+    ConvWs w;
+    carve_conv(a, &w, batch_size, out_shapes + 3 * l);
+    if (!a.ok()) return MSMD_ERR_WORKSPACE;
+    hipMemsetAsync(w.bits, 0, sizeof(uint32_t) * w.words, st);
+    if (l == 0) {
+      if (n > 0)
+        MSMD_LAUNCH(conv_mark, dim3(ceil_div(n, 256), g.kvol), dim3(256), 0, st, indices, n, g,
+                    w.bits);
+    } else {
+      MSMD_LAUNCH(conv_mark_from_bits, dim3(ceil_div((long)prev.words, 256)), dim3(256), 0, st,
+                  (const uint32_t*)prev.bits, (long)prev.words, prev_shape[0], prev_shape[1],
+                  prev_shape[2], g, w.bits);
+    }
+    device_scan(PopcCount{w.bits}, StorePrefix{w.prefix}, (int)w.words, w.tiles, n_out + l, -1, st);
+    prev = w;
+    prev_shape = out_shapes + 3 * l;
+    base += bytes;
+  }
   return launch_status();
 }
 

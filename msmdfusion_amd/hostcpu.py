@@ -58,6 +58,26 @@ def base_cpus():
     return base
 
 
+def quota_cpus():
+    """CPUs' worth of time the cgroup grants (cpu.max quota / period), or None."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1, int(quota) // int(period))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def within_quota(cpus=None):
+    """As many CPUs of the job's mask as the cgroup's quota pays for.  A process confined to
+    them cannot exceed the quota, whatever thread pools it starts -- which is what keeps the
+    kernel from throttling it for the rest of every 100 ms period."""
+    cpus = sorted(base_cpus() if cpus is None else cpus)
+    q = quota_cpus()
+    return cpus if q is None or q >= len(cpus) else cpus[:q]
+
+
 def pin_host_threads(local_rank=None, cpus_per_rank=4):
     """Restrict the calling thread (and every thread it creates from now on) to this rank's
     CPUs.  MSMD_PIN=0 disables it, MSMD_PIN_CPUS='a-b,c' names the CPUs outright.
@@ -79,15 +99,16 @@ def pin_host_threads(local_rank=None, cpus_per_rank=4):
 
 
 class unpinned:
-    """with unpinned(): the calling thread may run (and create threads) on every CPU of the
-    job again -- for a CPU-side leg such as bench.py's cpu_baseline."""
+    """with unpinned(): the calling thread may run (and create threads) on the job's CPUs
+    again, as many as the cgroup's quota pays for -- for a CPU-side leg such as bench.py's
+    cpu_baseline."""
 
     def __enter__(self):
         self.saved = None
         if hasattr(os, "sched_setaffinity"):
             self.saved = os.sched_getaffinity(0)
             try:
-                os.sched_setaffinity(0, base_cpus())
+                os.sched_setaffinity(0, within_quota())
             except OSError:
                 self.saved = None
         return self

@@ -296,6 +296,50 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, ne
     return out_idx, nbr_fwd, nbr_bwd, out_shape
 
 
+def rulebook_conv_chain(indices, batch_size, spatial_shape, geoms, need_bwd=True):
+    """A chain of strided convs, each over the previous one's output set: geoms = [(ksize,
+    stride, padding), ...].  All output sets are counted on the device back to back and the
+    counts read ONCE.  -> [(out_indices, nbr_fwd, nbr_bwd | None, out_shape), ...], tensor for
+    tensor what rulebook_conv gives level by level."""
+    _need_bzyx(indices)
+    _need_cuda(indices)
+    idx = indices.contiguous().int()
+    dev = idx.device
+    levels = len(geoms)
+    ks = [_expand3(g[0]) for g in geoms]
+    st = [_expand3(g[1]) for g in geoms]
+    pd = [_expand3(g[2]) for g in geoms]
+    shapes, shape = [], list(spatial_shape)
+    for l in range(levels):
+        shape = conv_output_size(shape, ks[l], st[l], pd[l])
+        shapes.append(list(shape))
+    flat = lambda rows: (C.c_int * (3 * levels))(*[int(v) for r in rows for v in r])  # noqa: E731
+    f_shapes, f_ks, f_st, f_pd = flat(shapes), flat(ks), flat(st), flat(pd)
+    nbytes = lib.msmd_rulebook_conv_chain_workspace_bytes(int(batch_size), levels, f_shapes)
+    ws = _ws(nbytes, dev)
+    counts = torch.empty((levels,), dtype=torch.int32, device=dev)
+    check(lib.msmd_rulebook_conv3d_count_chain(_p(idx), idx.shape[0], int(batch_size), levels,
+                                               f_shapes, f_ks, f_st, f_pd, _p(counts), _p(ws),
+                                               nbytes, _stream()),
+          "msmd_rulebook_conv3d_count_chain")
+    ms = counts.tolist()                                    # the chain's one host read
+    out, off, base = [], 0, ws.data_ptr()
+    for l in range(levels):
+        n, m, kvol = idx.shape[0], int(ms[l]), kernel_volume(ks[l])
+        lvl_bytes = lib.msmd_rulebook_conv_workspace_bytes(int(batch_size), int3(shapes[l]))
+        out_idx = torch.empty((m, 4), dtype=torch.int32, device=dev)
+        nbr_fwd = torch.empty((kvol, m), dtype=torch.int32, device=dev)
+        nbr_bwd = torch.empty((kvol, n), dtype=torch.int32, device=dev) if need_bwd else None
+        check(lib.msmd_rulebook_conv3d_fill(_p(idx), n, int(batch_size), int3(shapes[l]),
+                                            int3(ks[l]), int3(st[l]), int3(pd[l]), m, _p(out_idx),
+                                            _p(nbr_fwd), _p(nbr_bwd), C.c_void_p(base + off),
+                                            lvl_bytes, _stream()), "msmd_rulebook_conv3d_fill")
+        out.append((out_idx, nbr_fwd, nbr_bwd, shapes[l]))
+        off += (lvl_bytes + 255) // 256 * 256
+        idx = out_idx
+    return out
+
+
 def rulebook_pairs(nbr, ld=None):
     """nbr[K,M] -> (indice_pairs[K,2,ld], indice_num[K]): the reference's
     rulebook format (spconv_ops.h:55-59), pairs sorted by output row."""

@@ -65,6 +65,11 @@ class SparseEncoder(nn.Module):
         # conv_input and after every encoder layer: with block_type='basicblock' the
         # strided conv closes a stage, with 'conv_module' it opens the next one, so
         # the sets cannot be derived from the list of strided convs alone
+        # the four strided convs as one chain: one host read for their four output counts
+        chain = list(convs(self.conv_input))
+        for layer in self.encoder_layers:
+            chain += list(convs(layer))
+        planned.seed_strided_chain(chain + list(convs(self.conv_out)))
         t = planned.plan(convs(self.conv_input), need_grad)
         stages = [(t.indices, list(t.spatial_shape))]
         for layer in self.encoder_layers:

@@ -8,6 +8,8 @@ SparseConvTensor(features, indices, spatial_shape, batch_size) with
 """
 from typing import List, Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -245,6 +247,29 @@ class SparseConvTensor:
                             list(stride), list(padding), list(dilation), subm)
         self._rb_cache[ident] = rb
         return rb
+
+    def seed_strided_chain(self, convs):
+        """The strided convs of `convs` (execution order) as ONE chain: when every conv
+        between two of them keeps the voxel set (SubM), each strided conv's input set is the
+        previous one's output set, and all their output sets can be counted on the device
+        back to back with a single host read (kernels.rulebook_conv_chain) instead of one
+        read per conv.  The rulebooks land in the shared cache under the keys plan() /
+        forward() will look up; results are those of the level-by-level path."""
+        strided = [c for c in convs if not c.subm and not getattr(c, "conv1x1", False)]
+        if len(strided) < 2 or os.environ.get("MSMD_CONV_CHAIN", "1") != "1" or \
+                any(d != 1 for c in strided for d in c.dilation):
+            return
+        geoms = [(list(c.kernel_size), list(c.stride), list(c.padding)) for c in strided]
+        idx, shape = self.indices, list(self.spatial_shape)
+        for c, (out_idx, nbr_fwd, nbr_bwd, out_shape) in zip(
+                strided, K.rulebook_conv_chain(idx, self.batch_size, shape, geoms)):
+            ident = (idx.data_ptr(), idx.shape[0], tuple(shape), tuple(c.kernel_size),
+                     tuple(c.stride), tuple(c.padding), tuple(c.dilation), False)
+            self._rb_cache[ident] = IndiceData(out_idx, idx, nbr_fwd, nbr_bwd, False, list(shape),
+                                               list(out_shape), list(c.kernel_size),
+                                               list(c.stride), list(c.padding), list(c.dilation),
+                                               None)
+            idx, shape = out_idx, list(out_shape)
 
     def plan(self, convs, need_grad, strided_outputs=None):
         """Index-only pre-pass: build (or fetch) the rulebook of every sparse

@@ -151,6 +151,29 @@ def test_rulebook_edges(dev):
     assert oi.shape[0] == 0 and f.shape == (27, 0)
 
 
+def test_rulebook_conv_chain_equals_level_by_level(dev):
+    """msmd_rulebook_conv3d_count_chain: SparseEncoder's four strided convs (k3 s2 p1 twice,
+    k3 s2 p(0,1,1), k(3,1,1) s(2,1,1) p0) counted back to back from each other's bitmaps, one
+    host read -- tensor for tensor the level-by-level rulebooks."""
+    from msmdfusion_amd import kernels as K
+    geoms = [(3, 2, 1), (3, 2, 1), (3, 2, [0, 1, 1]), ([3, 1, 1], [2, 1, 1], 0)]
+    for seed, batch, shape, n in ((1, 2, [41, 200, 176], 20000), (2, 3, [25, 64, 64], 3000),
+                                  (3, 1, [41, 16, 16], 1)):
+        idx = t(S.random_voxel_indices(n, batch, shape, seed=seed), dev)
+        chain = K.rulebook_conv_chain(idx, batch, shape, geoms)
+        cur, cur_shape = idx, shape
+        for (ks, st, pd), got in zip(geoms, chain):
+            want = K.rulebook_conv(cur, batch, cur_shape, ks, st, pd)
+            assert list(got[3]) == list(want[3])
+            for a, b in zip(got[:3], want[:3]):
+                assert torch.equal(a, b)
+            cur, cur_shape = want[0], want[3]
+        assert chain[-1][0].shape[0] > 0
+    empty = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    for out_idx, fwd, bwd, _ in K.rulebook_conv_chain(empty, 1, [41, 16, 16], geoms):
+        assert out_idx.shape[0] == 0 and fwd.shape[1] == 0
+
+
 def test_rulebook_subm_index_methods(dev):
     """hash and bitmap SubM indices: duplicate coordinates (both keep the LAST row, as the
     CPU reference's grid does, geometry.h:277-282), cells at the word boundaries of the
