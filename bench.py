@@ -371,16 +371,8 @@ def run_workload(workload, args, dev, rank, world, profile):
     # configs[1] line reads 326 samples/s after 15 untimed steps = 0.14 s, 454 after 70), so
     # the untimed setup also lasts at least MSMD_BENCH_SETTLE_S seconds of stepping
     settle_s = float(os.environ.get("MSMD_BENCH_SETTLE_S", "1.5"))
-    t_settle, n_settle = time.perf_counter(), 0
-    min_settle = wl["settle"] if (lc or prefetch is not None) else 2
-    while True:
-        more = n_settle < min_settle or time.perf_counter() - t_settle < settle_s
-        if world > 1:       # every rank must take the same number of (all-reducing) steps
-            more = D.global_max(1.0 if more else 0.0, device=dev) > 0.5
-        if not more:
-            break
-        step(batch)
-        n_settle += 1
+    D.settle_steps(lambda: step(batch), wl["settle"] if (lc or prefetch is not None) else 2,
+                   settle_s, device=dev)      # same count on every rank (each step all-reduces)
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(batch)

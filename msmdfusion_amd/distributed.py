@@ -61,6 +61,26 @@ def global_max(value, device=None):
     return float(t.item())
 
 
+def settle_steps(step_fn, min_steps, seconds, device=None, clock=None):
+    """Untimed setup steps before a measurement: at least `min_steps`, and for at least
+    `seconds` of wall time (allocator pools and GPU clocks reach their steady state) -- with
+    every rank taking the SAME number of steps, because each step all-reduces gradients: a rank
+    that stopped one step early would leave the others waiting in a collective.
+    -> steps taken."""
+    import time
+    clock = clock or time.perf_counter
+    multi = dist.is_initialized() and dist.get_world_size() > 1
+    t0, n = clock(), 0
+    while True:
+        more = n < min_steps or clock() - t0 < seconds
+        if multi:
+            more = global_max(1.0 if more else 0.0, device=device) > 0.5
+        if not more:
+            return n
+        step_fn()
+        n += 1
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -47,8 +47,14 @@ def _worker(rank, world, port, out):
         acc = flat if acc is None else acc + flat
     ok_grad = torch.allclose(grads, acc / world, atol=1e-6)
     tmax = D.global_max(1.0 + rank)
+    # time-based settle: rank 1's clock runs three times as fast, both must take its count
+    ticks = iter(range(10 ** 6))
+    fake = (lambda: next(ticks) * (0.1 if rank == 0 else 0.3))
+    taken = []
+    n = D.settle_steps(lambda: (taken.append(1), dist.all_reduce(torch.ones(1)))[0], 2, 1.0,
+                       clock=fake)
     D.barrier()
-    out[rank] = (ids, bool(ok_grad), tmax)
+    out[rank] = (ids, bool(ok_grad), tmax, n, len(taken))
     dist.destroy_process_group()
 
 
@@ -58,9 +64,11 @@ def test_two_rank_gloo_data_parallel():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    ids0, ok0, t0 = out[0]
-    ids1, ok1, t1 = out[1]
+    ids0, ok0, t0, n0, steps0 = out[0]
+    ids1, ok1, t1, n1, steps1 = out[1]
     assert ok0 and ok1
+    # rank 0's clock alone would stop after 5 steps; it goes on until rank 1's is done
+    assert n0 == n1 == steps0 == steps1 and n0 >= 2
     assert t0 == t1 == 2.0                      # max over ranks
     assert len(set(ids0) | set(ids1)) == 8 and not set(ids0) & set(ids1)
     assert ids0 == [24, 25, 26, 27] and ids1 == [28, 29, 30, 31]
