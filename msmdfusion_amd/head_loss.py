@@ -299,8 +299,9 @@ def weight_reduce_loss(loss, weight=None, reduction="mean", avg_factor=None):
     if weight is not None:
         loss = loss * weight
     if avg_factor is None:
-        return {"none": loss, "mean": loss.mean(), "sum": loss.sum()}[reduction] \
-            if reduction != "none" else loss
+        if reduction == "mean":
+            return loss.mean()
+        return loss.sum() if reduction == "sum" else loss
     if reduction == "mean":
         return loss.sum() / avg_factor
     if reduction != "none":
