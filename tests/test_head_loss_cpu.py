@@ -89,6 +89,36 @@ def test_oracle_overlap_bev_against_a_polygon_clip():
     np.testing.assert_allclose(own, own.T, rtol=1e-4, atol=1e-4)
 
 
+def test_oracle_overlap_bev_invariances():
+    """Properties any rotated-rectangle overlap has, at the float tolerance of the algorithm:
+    a rigid motion of the pair changes nothing, a contained box overlaps by its own area,
+    separated boxes by zero, and the 3-D IoU of a box with its vertically shifted copy is the
+    height overlap's share."""
+    rs = np.random.RandomState(11)
+    n = 40
+    ctr, size, ang = rs.uniform(-3, 3, (n, 2)), rs.uniform(0.5, 4, (n, 2)), rs.uniform(-3, 3, n)
+
+    def boxes(c, a):
+        return np.concatenate([c - size / 2, c + size / 2, a[:, None]], 1).astype(np.float32)
+    base = OH.boxes_overlap_bev(boxes(ctr, ang)[:20], boxes(ctr, ang)[20:])
+    # the kernel turns corners by R(-angle): turning the scene by +phi moves centres by R(-phi)
+    phi = 0.7
+    c, s_ = np.cos(phi), np.sin(phi)
+    moved = np.stack([ctr[:, 0] * c + ctr[:, 1] * s_, -ctr[:, 0] * s_ + ctr[:, 1] * c], 1) + [5.0, -2.0]
+    turned = OH.boxes_overlap_bev(boxes(moved, ang + phi)[:20], boxes(moved, ang + phi)[20:])
+    np.testing.assert_allclose(turned, base, rtol=2e-4, atol=2e-4)
+    big = np.array([[-4, -3, 4, 3, 0.4]], np.float32)
+    small = np.array([[-0.5, -0.25, 0.5, 0.25, 1.1]], np.float32)
+    assert abs(float(OH.boxes_overlap_bev(big, small)[0, 0]) - 0.5) < 1e-5
+    far = np.array([[20, 20, 21, 21, 0.3]], np.float32)
+    assert float(OH.boxes_overlap_bev(big, far)[0, 0]) == 0.0
+    box = np.array([[1.0, 2.0, -1.0, 2.0, 4.0, 1.5, 0.6]], np.float32)
+    up = box.copy()
+    up[0, 2] += 0.5                                  # 1.0 of 1.5 in common: IoU = 1 / 2
+    np.testing.assert_allclose(OH.boxes_iou3d(box, up), [[0.5]], rtol=1e-5)
+    np.testing.assert_allclose(OH.boxes_iou3d(box, up, "iof"), [[2.0 / 3.0]], rtol=1e-5)
+
+
 def test_oracle_gaussian_reference_known_answer():
     heat = np.zeros((128, 128), np.float32)
     OH.draw_heatmap_gaussian(heat, (64, 64), 2)
