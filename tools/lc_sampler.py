@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Where the two host threads of the pipelined LC step spend their WALL time: a sampler thread
+looks at both threads' Python stacks every ~0.2 ms (sys._current_frames) and attributes the
+sample to the innermost frame inside this repository -- a thread blocked in a library or torch
+call, or waiting for the interpreter lock on its way out of one, shows up at the calling line.
+
+    python tools/lc_sampler.py [steps]
+"""
+import collections
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (pins the process, sets the runtime knobs)
+import torch  # noqa: E402
+from msmdfusion_amd import distributed as D  # noqa: E402
+from msmdfusion_amd import synthetic as S  # noqa: E402
+from msmdfusion_amd.prefetch import IndexPrefetcher  # noqa: E402
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = bench.FusionBackbone().to(dev).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+    clouds = [torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in range(2)]
+    batch = (clouds, [torch.from_numpy(S.virtual_points(i)).to(dev) for i in range(2)])
+    target = torch.randn(2, 640, 180, 180, device=dev).contiguous(memory_format=torch.channels_last)
+    sys.setswitchinterval(0.0005)
+    pf = IndexPrefetcher(model.prepare, dev, threaded=True)
+    step = D.TrainStep(model, params, opt, lambda bev: (bev * target).mean(), pf, 10.0)
+    step.prime(batch)
+    D.settle_steps(lambda: step(batch), 16, 1.5, device=dev)
+
+    main_tid = threading.get_ident()
+    counts = {"main": collections.Counter(), "index": collections.Counter()}
+    totals = collections.Counter()
+    stop = threading.Event()
+
+    def where(frame):
+        inner = None
+        f = frame
+        while f is not None:
+            fn = f.f_code.co_filename
+            if fn.startswith(ROOT) and "tools/lc_sampler" not in fn:
+                inner = "%s:%d %s" % (os.path.relpath(fn, ROOT), f.f_lineno, f.f_code.co_name)
+                break
+            f = f.f_back
+        leaf = "%s:%d" % (os.path.basename(frame.f_code.co_filename), frame.f_lineno)
+        return inner or "(outside) " + leaf
+
+    def sampler():
+        names = {}
+        while not stop.is_set():
+            time.sleep(0.0002)
+            if not names:
+                names = {t.ident: t.name for t in threading.enumerate()}
+            for tid, frame in sys._current_frames().items():
+                if tid == main_tid:
+                    key = "main"
+                elif names.get(tid, "").startswith("msmd-index"):
+                    key = "index"
+                else:
+                    if tid not in names:
+                        names = {t.ident: t.name for t in threading.enumerate()}
+                    continue
+                counts[key][where(frame)] += 1
+                totals[key] += 1
+
+    th = threading.Thread(target=sampler, name="sampler", daemon=True)
+    torch.cuda.synchronize()
+    th.start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(batch)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    stop.set()
+    th.join()
+    print("%.2f ms/step with the sampler running (%d steps)" % (ms, steps))
+    for key in ("index", "main"):
+        print("---- %s thread: %d samples; ms per step by innermost repository frame" % (key, totals[key]))
+        for loc, c in counts[key].most_common(28):
+            print("  %6.2f ms  %s" % (c / max(totals[key], 1) * ms, loc))
+
+
+if __name__ == "__main__":
+    main()
