@@ -48,7 +48,11 @@ sys.path.insert(0, ROOT)
 # ... and the rank's threads stay on a few CPUs (before anything creates threads): unpinned,
 # the same binary on the same box reads 100-133 samples/s from run to run, pinned 128-130
 from msmdfusion_amd.hostcpu import pin_host_threads  # noqa: E402
-PINNED_CPUS = pin_host_threads()
+# (only as a program: a test session that imports this module for its model classes keeps
+# its own CPUs -- pinned to four, the oracle's OpenMP loops made the GPU suite five times
+# slower; tools that want the bench's placement set MSMD_PIN_ON_IMPORT=1 first)
+PINNED_CPUS = pin_host_threads() if (__name__ == "__main__" or
+                                     os.environ.get("MSMD_PIN_ON_IMPORT") == "1") else None
 
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402

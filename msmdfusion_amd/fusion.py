@@ -5,6 +5,8 @@ MSMDFusionDetector.voxelize (MSMDFusion.py:462-491), fetch_2D_voxels' voxel half
 hot path proper; virtual points arrive here as ready [N,64] tensors
 (image_glue.get_foreground2D builds them; bev.BevTail consumes the result).
 """
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -211,4 +213,4 @@ class SparseFusionPath(nn.Module):
         # chip-filling persistent kernels, or the search starts late.  Process-wide
         # streams (slots 8..11; the prefetcher owns the low slots): see prefetch.side_stream
         from .prefetch import side_stream
-        return side_stream(device, -1, slot=8 + stage)
+        return side_stream(device, int(os.environ.get("MSMD_NN_PRIORITY", "-1")), slot=8 + stage)

@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
+os.environ.setdefault("MSMD_PIN_ON_IMPORT", "1")   # the bench's thread placement
 import bench  # noqa: E402
 from msmdfusion_amd import distributed as D  # noqa: E402
 from msmdfusion_amd import synthetic as S  # noqa: E402
