@@ -12,7 +12,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # ... and the oracle's OpenMP pool: confined to as many CPUs as the quota pays for, the test
-# process cannot overrun it (the same suite took 37 s on one box and 199 s on another)
+# process cannot overrun it.  (The GPU suite runs in ~40 s; it took 199 s while importing
+# bench.py pinned the whole session to four CPUs -- bench.py pins only as a program now.)
 try:
     from msmdfusion_amd.hostcpu import within_quota
     if hasattr(os, "sched_setaffinity"):
