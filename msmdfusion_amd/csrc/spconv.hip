@@ -28,6 +28,7 @@
 #include "common.hpp"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace msmd {
 namespace {
@@ -810,6 +811,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }  // namespace
 }  // namespace msmd
 
+namespace msmd {   // spconv_wgrad_block.hip
+bool wgrad_block_supported(int c_in, int c_out, int kvol, int ld);
+size_t wgrad_block_workspace_bytes(int kvol, int c_in, int c_out);
+int wgrad_block(const float* in_feat, int c_in, const float* d_out, int c_out,
+                const int32_t* pairs, const int32_t* num, int ld, int kvol, int np,
+                float* d_weight, int krsc_out, float* ws, hipStream_t st);
+}
 using namespace msmd;
 
 MSMD_EXPORT size_t msmd_spconv_packed_weight_elems(int kernel_volume, int c_in, int c_out) {
@@ -910,8 +918,11 @@ MSMD_EXPORT size_t msmd_spconv_wgrad_workspace_bytes(int kernel_volume, int ld, 
   if (kWgradSplitChunk < chunk) chunk = kWgradSplitChunk;   // serves msmd_spconv_wgrad_split too
   size_t nchunks = (size_t)ceil_div(ld > 0 ? ld : 1, chunk);
   // + the per-(offset, chunk) pair ranges of the row-range work split (spconv_split.hip)
-  return align_up(sizeof(float) * kernel_volume * nchunks * c_in * c_out) +
-         align_up(sizeof(int32_t) * (size_t)kernel_volume * (nchunks + 1));
+  const size_t chunked = align_up(sizeof(float) * kernel_volume * nchunks * c_in * c_out) +
+                         align_up(sizeof(int32_t) * (size_t)kernel_volume * (nchunks + 1));
+  // the whole-block kernel's slots (spconv_wgrad_block.hip): one per workgroup + segment
+  const size_t block = wgrad_block_workspace_bytes(kernel_volume, c_in, c_out);
+  return chunked > block ? chunked : block;
 }
 
 namespace {
@@ -1012,6 +1023,17 @@ MSMD_EXPORT int msmd_spconv_wgrad_split(const float* in_feat, int c_in, const fl
     return launch_status();
   }
   if (!in_feat || !d_out || !indice_pairs) return MSMD_ERR_INVALID_ARG;
+  // the whole c_in x c_out block per workgroup (spconv_wgrad_block.hip) wherever both
+  // widths are multiples of 16; MSMD_WGRAD=var keeps the 64 x 64 slab kernel (A/B runs)
+  static const bool use_block = [] { const char* e = getenv("MSMD_WGRAD"); return !(e && !strcmp(e, "var")); }();
+  if (use_block && wgrad_block_supported(c_in, c_out, kernel_volume, ld) &&
+      (double)ld * 4.0 * (c_in > c_out ? c_in : c_out) < 4.0e9) {
+    if (workspace_bytes < wgrad_block_workspace_bytes(kernel_volume, c_in, c_out) ||
+        ((uintptr_t)workspace & 255))
+      return MSMD_ERR_WORKSPACE;
+    return wgrad_block(in_feat, c_in, d_out, c_out, indice_pairs, indice_num, ld, kernel_volume,
+                       planes, d_weight, krsc_out, (float*)workspace, st);
+  }
   const int chunk = kWgradSplitChunk;   // pairs per workgroup (common.hpp)
   const int nchunks = ceil_div(ld, chunk);
   if (workspace_bytes < sizeof(float) * (size_t)kernel_volume * nchunks * per_k ||
