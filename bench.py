@@ -561,6 +561,10 @@ def roofline(prof, workload):
             pairs = int(meta["num"].sum().item())
             name = "spconv_wgrad_split_kernel" if kind == "spconv_wgrad_split" \
                 else "spconv_wgrad_kernel"
+        if os.environ.get("MSMD_BENCH_LAYERS") == "1":     # per-launch lines (stderr)
+            print("[layer] %-34s %4d->%-4d pairs %8d  %7.1f us  %6.1f TF" % (
+                name, meta["c_in"], meta["c_out"], pairs, ms * 1e3,
+                2.0 * pairs * meta["c_in"] * meta["c_out"] / (ms * 1e-3) / 1e12), file=sys.stderr)
         g = groups.setdefault(name, dict(ms=0.0, flops=0.0, launches=0))
         g["ms"] += ms
         g["flops"] += 2.0 * pairs * meta["c_in"] * meta["c_out"]

@@ -194,20 +194,14 @@ __device__ __forceinline__ void load_row(__amdgpu_buffer_rsrc_t rs, unsigned off
 // v_cvt_pk_bf16_f32 of (pair 2t, pair 2t+1) is dword t of the operand: the transposition
 // the MFMA wants costs nothing.  Scalar residuals (a v_pk_add_f32 beside MFMAs costs more
 // than the two v_sub_f32 it replaces: the file is built with -fno-slp-vectorize).
-// (MSMD_WGRAD_DOT2=1: the residual v - float(bf16) as ONE v_dot2c_f32_bf16 -- 7 VALU
-// operations per operand dword instead of 11.  Measured on MI355X: the conversion phase of a
-// producer wave got SLOWER (1465 -> 1622 cycles per 32-pair step at 128 x 128: the dot
-// instruction is multi-pass) and the accumulate form did not reproduce the subtraction bit
-// for bit (test_split_wgrad failed).  Off.)
-#ifndef MSMD_WGRAD_DOT2
-#define MSMD_WGRAD_DOT2 0
-#endif
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-template <int NP, int N>
-__device__ __forceinline__ void split_rows(const unsigned (&r)[8][N], u32x4 (&op)[N][NP],
-                                           unsigned sel_lo, unsigned sel_hi) {
+// (Tried: the residual v - float(bf16) as ONE v_dot2c_f32_bf16 -- 7 VALU operations per
+// operand dword instead of 11.  Measured on MI355X: the conversion phase of a producer wave
+// got SLOWER (1465 -> 1622 cycles per 32-pair step at 128 x 128: the dot instruction is
+// multi-pass) and the accumulate form did not reproduce the subtraction bit for bit.)
+template <int NP, int N, int T0, int T1>   // operand dwords [T0, T1) of 4 (pairs 2t, 2t + 1)
+__device__ __forceinline__ void split_rows(const unsigned (&r)[8][N], u32x4 (&op)[N][NP]) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = T0; t < T1; ++t)
 #pragma unroll
     for (int a = 0; a < N; ++a) {
       float v0 = __uint_as_float(r[2 * t][a]), v1 = __uint_as_float(r[2 * t + 1][a]);
@@ -217,28 +211,29 @@ __device__ __forceinline__ void split_rows(const unsigned (&r)[8][N], u32x4 (&op
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
         op[a][pl][t] = hi;
         if (pl + 1 < NP) {   // exact residuals
-#if MSMD_WGRAD_DOT2
-          const bf16x2 h2 = __builtin_bit_cast(bf16x2, hi);
-          v0 = __builtin_amdgcn_fdot2_f32_bf16(h2, __builtin_bit_cast(bf16x2, sel_lo), v0, false);
-          v1 = __builtin_amdgcn_fdot2_f32_bf16(h2, __builtin_bit_cast(bf16x2, sel_hi), v1, false);
-#else
           v0 = v0 - __uint_as_float(hi << 16);
           v1 = v1 - __uint_as_float(hi & 0xffff0000u);
-#endif
         }
       }
     }
 }
 
-// Iteration `it` (6 q of them, q = ceil(steps / 6): no exits inside the unrolled body, so
-// the compiler's wait counts are exact) converts step it, has the rows of steps it + 1 and
-// it + 2 in flight and the pair indices of steps it + 3 and it + 4.  Buffer loads return
-// in order, so a wait for index registers drains every OLDER load: the index load of an
-// iteration is issued BEFORE its row loads and is used two iterations later -- that wait
-// leaves the 16 row loads issued since in flight.
-template <int NP, int N>
+// Eight producer waves (two per SIMD beside one consumer): wave (side, half h, parity)
+// converts the steps of its parity -- one wave alone issues ~350 instructions per step and
+// cannot keep up with the consumer's 96 MFMAs (measured: 3100 cycles of producer work per
+// 1536-cycle step); two waves taking alternate steps have two steps' time for each.
+//
+// An OWN step spans two iterations (= two barriers): part 1 (iteration s - 1) issues the
+// index load of the own step after next, the row loads of the next own step, and converts
+// the first half of step s into registers; part 2 (iteration s) converts the rest and
+// writes the step to ring slot s % 3 -- the slot is free only once barrier s - 1 has been
+// passed (the consumers read step s - 3 during iteration s - 1).  Buffer loads return in
+// order, so a wait for index registers drains every OLDER load: an own step's index load is
+// issued BEFORE its row loads; the wait for it one own step later leaves those 8 row loads
+// in flight, and they have two iterations to land.
+template <int NP, int N, int PAR>
 __device__ __forceinline__ void produce(const BlockArgs& A, const SegTab& tab, Cursor cur,
-                                        int nsteps, int q6, int side, int a0, u32x4* ring,
+                                        int nsteps, int q4, int side, int a0, u32x4* ring,
                                         int lane) {
   const int i = lane & 15, g = lane >> 4;
   const int T = side ? A.TB : A.TA, c = side ? A.cout : A.cin;
@@ -254,11 +249,12 @@ __device__ __forceinline__ void produce(const BlockArgs& A, const SegTab& tab, C
   const bool fold = A.dbg & 1, norows = A.dbg & 2;
 #endif
 
-  u32x4 idx[2][2];          // pair indices, two steps in flight
-  int idx_rem[2];           // pairs of that step from this lane's first one on (<= 0: none)
-  unsigned idx_col[2];      // byte offset of the lane's channels in the row
-  unsigned raw[kRing][8][N];
+  u32x4 idx[2];             // pair indices of the next own step but one
+  int idx_rem;              // pairs of that step from this lane's first one on (<= 0: none)
+  unsigned idx_col;         // byte offset of the lane's channels in the row
+  unsigned raw[2][8][N];    // rows of this own step and the next
   unsigned off[8];
+  u32x4 op[N][NP];
 
   // per-segment values, recomputed only when the cursor enters another segment
   int seg_id = -1;
@@ -270,32 +266,32 @@ __device__ __forceinline__ void produce(const BlockArgs& A, const SegTab& tab, C
     const int bs = side ? cur.blk % A.nbb : cur.blk / A.nbb;
     seg_col = (unsigned)(bs * T * 16) * 4u + lane_col;
   };
+  if (PAR) tab.advance(cur);   // first own step = step PAR
   seg_update();
   const unsigned lane_idx_off = (unsigned)(8 * g) * 4u;
-  int t_idx = 0;            // step the next index load is for
-  auto load_idx = [&](auto buf) {
-    constexpr int B = decltype(buf)::value;
+  int t_idx = PAR;            // step the next index load is for
+  auto load_idx = [&]() {
     // past the range: the loads still go out (any address the descriptor covers), rem = 0
     const int pos = 32 * cur.j;
     const unsigned voff = seg_idx_off + (unsigned)pos * 4u + lane_idx_off;
-    idx[B][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, (int)voff, 0, 0);
-    idx[B][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, (int)(voff + 16u), 0, 0);
-    idx_rem[B] = (t_idx < nsteps ? cur.num - pos : 0) - 8 * g;
-    idx_col[B] = seg_col;
+    idx[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, (int)voff, 0, 0);
+    idx[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, (int)(voff + 16u), 0, 0);
+    idx_rem = (t_idx < nsteps ? cur.num - pos : 0) - 8 * g;
+    idx_col = seg_col;
+    tab.advance(cur);          // the other parity's step
     tab.advance(cur);
     if (cur.seg != seg_id) seg_update();
-    ++t_idx;
+    t_idx += 2;
   };
-  auto make_offsets = [&](auto buf) {
-    constexpr int B = decltype(buf)::value;
+  auto make_offsets = [&]() {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      unsigned r = idx[B][e >> 2][e & 3];
+      unsigned r = idx[e >> 2][e & 3];
 #ifdef MSMD_WGRAD_BLOCK_DBG
       r = fold ? (r & 4095u) : r;
 #endif
-      const unsigned o = __umul24(r, row_bytes) + idx_col[B];   // rows < 2^24 (host check)
-      off[e] = e < idx_rem[B] ? o : kOob;
+      const unsigned o = __umul24(r, row_bytes) + idx_col;   // rows < 2^24 (host check)
+      off[e] = e < idx_rem ? o : kOob;
 #ifdef MSMD_WGRAD_BLOCK_DBG
       off[e] = norows ? kOob : off[e];
 #endif
@@ -306,67 +302,121 @@ __device__ __forceinline__ void produce(const BlockArgs& A, const SegTab& tab, C
 #pragma unroll
     for (int e = 0; e < 8; ++e) load_row<N>(rs_rows, off[e], raw[S][e]);
   };
-  // prologue: rows of steps 0 and 1 in flight, indices of steps 2 and 3 loaded
-  load_idx(ic<0>{});
-  load_idx(ic<1>{});
-  make_offsets(ic<0>{});
-  load_idx(ic<0>{});          // step 2
-  load_rows(ic<0>{});
-  make_offsets(ic<1>{});
-  __builtin_amdgcn_sched_barrier(0);
-  load_idx(ic<1>{});          // step 3
-  __builtin_amdgcn_sched_barrier(0);
-  load_rows(ic<1>{});
-
-  unsigned sel_lo, sel_hi;   // bf16 pairs {-1, 0} and {0, -1}
-  asm volatile("v_mov_b32 %0, 0xbf80\n\tv_mov_b32 %1, 0xbf800000" : "=v"(sel_lo), "=v"(sel_hi));
-  const bool wb_on = side == 0 && a0 == 0;   // (PROF builds: the wave that is timed)
+  const bool wb_on = side == 0 && a0 == 0 && PAR == 0;   // (PROF builds: the wave that is timed)
   (void)wb_on;
   WB_BEGIN();
-  auto iter = [&](auto slot, auto buf) {   // iteration it: slot it % 3, index buffer it % 2
+  int ring_slot = PAR;      // ring slot of the current own step (s % 3)
+  // part 1 of the own step in raw slot S: loads for later own steps, first half converted
+  auto part1 = [&](auto slot) {
     constexpr int S = decltype(slot)::value;
-    make_offsets(buf);                   // step it + 2 (indices loaded at iteration it - 2)
+#ifdef MSMD_WGRAD_BLOCK_DBG
+    if (A.dbg & 64) return;     // barriers only
+    if (A.dbg & 128) { make_offsets(); load_idx(); return; }   // no row loads issued at all
+#endif
+    make_offsets();                      // next own step (indices loaded one own step ago)
     __builtin_amdgcn_sched_barrier(0);
-    load_idx(buf);                       // step it + 4
+    load_idx();                          // the own step after next
     __builtin_amdgcn_sched_barrier(0);
-    load_rows(ic<(S + 2) % kRing>{});    // step it + 2
+    load_rows(ic<S ^ 1>{});              // next own step
     if (wb_on) WB_MARK(0);
-    u32x4 op[N][NP];
-    split_rows<NP, N>(raw[S], op, sel_lo, sel_hi);   // step it (zeros past the range)
+#ifdef MSMD_WGRAD_BLOCK_DBG
+    if (A.dbg & 4) {   // no conversion: raw bits as operands (wrong results by design)
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) op[a][pl] = (u32x4){raw[S][0][a], raw[S][1][a], raw[S][2][a], raw[S][3][a]};
+    } else
+#endif
+    split_rows<NP, N, 0, 2>(raw[S], op);
+    // (pin the half-converted operands here: the compiler otherwise sinks the conversion
+    // behind the barrier, next to the LDS writes of part 2, and the two parts are uneven)
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) asm volatile("" : "+v"(op[a][pl]));
     if (wb_on) WB_MARK(1);
-    u32x4* d = dst0 + S * slot_u;
+  };
+  auto part2 = [&](auto slot) {
+    constexpr int S = decltype(slot)::value;
+#ifdef MSMD_WGRAD_BLOCK_DBG
+    if (A.dbg & (64 | 128)) return;
+#endif
+    // (and keep the second half of the conversion on this side of the barrier)
+#pragma unroll
+    for (int e = 4; e < 8; ++e)
+#pragma unroll
+      for (int a = 0; a < N; ++a) asm volatile("" : "+v"(raw[S][e][a]));
+#ifdef MSMD_WGRAD_BLOCK_DBG
+    if (!(A.dbg & 4))
+#endif
+    split_rows<NP, N, 2, 4>(raw[S], op);
+    if (wb_on) WB_MARK(1);
+    u32x4* d = dst0 + ring_slot * slot_u;
+#ifdef MSMD_WGRAD_BLOCK_DBG
+    if (!(A.dbg & 32))
+#endif
 #pragma unroll
     for (int a = 0; a < N; ++a)
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) d[(a * NP + pl) * 64] = op[a][pl];
+    ring_slot = ring_slot >= 1 ? ring_slot - 1 : ring_slot + 2;   // (s + 2) % 3
     wait_lds();
     if (wb_on) WB_MARK(2);
+  };
+  auto bar = [&]() {
     asm volatile("s_barrier" ::: "memory");
     if (wb_on) WB_MARK(3);
   };
-  for (int it = 0; it < q6; ++it) {
-    iter(ic<0>{}, ic<0>{});
-    iter(ic<1>{}, ic<1>{});
-    iter(ic<2>{}, ic<0>{});
-    iter(ic<0>{}, ic<1>{});
-    iter(ic<1>{}, ic<0>{});
-    iter(ic<2>{}, ic<1>{});
+  // prologue: rows of the first own step in flight, indices of the second loaded
+  load_idx();
+  make_offsets();
+  __builtin_amdgcn_sched_barrier(0);
+  load_idx();
+  __builtin_amdgcn_sched_barrier(0);
+  load_rows(ic<0>{});
+  if (PAR == 0) {
+    part1(ic<0>{});          // step 0 is due in iteration 0: its first half before the loop
+    for (int it = 0; it < q4; ++it) {
+      part2(ic<0>{}); bar();
+      part1(ic<1>{}); bar();
+      part2(ic<1>{}); bar();
+      part1(ic<0>{}); bar();
+    }
+  } else {
+    for (int it = 0; it < q4; ++it) {
+      part1(ic<0>{}); bar();
+      part2(ic<0>{}); bar();
+      part1(ic<1>{}); bar();
+      part2(ic<1>{}); bar();
+    }
   }
   asm volatile("s_barrier" ::: "memory");   // the consumers are two steps behind
   asm volatile("s_barrier" ::: "memory");
 }
 
 // ------------------------------------------------------------------ consumer --
-// One consumer wave = NA x NB tiles (a quadrant of the block).  Per step: A rows in two
-// halves (the second half is read from the ring under the first half's MFMAs), the next
-// step's B operands and first A half under the second half's MFMAs.  Step m runs after
-// barrier m + 2 (the producers finished it before barrier m + 1).
+// One consumer wave = NA x NB tiles (a quadrant of the block), alone with its SIMD's matrix
+// pipe.  With three waves per SIMD a wave has 168 registers: 64 accumulators, the two B
+// halves of the step (Y, Z) and THREE single-tile A slots.  A step is 2 NA phases, each
+// multiplying one A tile by one B half (12 MFMAs at NB = 4):
+//     pass 1 (first B half, Y):   a = 0, 1, .., NA-1     (the second B half -> Z meanwhile)
+//     pass 2 (second B half, Z):  a = NA-1, .., 1, 0     (the next step's first half -> Y)
+// -- the turn reuses tile NA-1: 2 NA - 1 A reads per step, numbered l = 0 .. 2 NA - 2 (and
+// on into the next step); read l goes to slot (beta + l) % 3 and is issued TWO phases
+// before its use (one phase = 192 cycles was not enough: with the producers' 48 KB of
+// writes and 132 KB of reads per step in the LDS queues a read takes longer than that --
+// the MFMA stream ran at 62 % of its rate).  beta advances by 2 NA - 1 per step: the step
+// code is instantiated for beta = 0, 1, 2.
+// (Four half-slots of two tiles each -- every operand read once per step -- need 160 +
+// registers and spilled.)
+// Step m runs after barrier m + 1 (the producers finished it before barrier m).
 template <int NP, int NA, int NB>
 __device__ __forceinline__ void consume(const BlockArgs& A, const SegTab& tab, Cursor cur,
-                                        int nsteps, int q6, int ta0, int tb0,
+                                        int nsteps, int q4, int ta0, int tb0,
                                         const u32x4* ring, int wg, int lane) {
   using P = Prod<NP>;
-  constexpr int LO = (NA + 1) / 2, HI = NA - LO;
+  constexpr int LB = (NB + 1) / 2, HB = NB - LB;
+  constexpr int NL = 2 * NA - 1;   // A reads per step
   const int slot_u = (A.TA + A.TB) * NP * 64;
   const u32x4* a_src = ring + ta0 * NP * 64 + lane;
   const u32x4* b_src = ring + (A.TA + tb0) * NP * 64 + lane;
@@ -377,27 +427,19 @@ __device__ __forceinline__ void consume(const BlockArgs& A, const SegTab& tab, C
   for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  u32x4 bf[2][NB][NP], alo[LO][NP], ahi[HI > 0 ? HI : 1][NP];
+  u32x4 X[3][NP], Y[LB][NP], Z[HB][NP];
 
-  auto read_b = [&](auto par, int slot) {
-    constexpr int Q = decltype(par)::value;
+  auto rd_a = [&](auto xs, int slot, int t) {   // A tile t of ring slot `slot` -> X[xs]
+    constexpr int Xs = decltype(xs)::value;
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) bf[Q][b][pl] = b_src[slot * slot_u + (b * NP + pl) * 64];
+    for (int pl = 0; pl < NP; ++pl) X[Xs][pl] = a_src[slot * slot_u + (t * NP + pl) * 64];
   };
-  auto read_alo = [&](int slot) {
+  auto rd_b = [&](auto& dst, int slot, int t0, auto n) {
+    constexpr int Nn = decltype(n)::value;
 #pragma unroll
-    for (int a = 0; a < LO; ++a)
+    for (int t = 0; t < Nn; ++t)
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) alo[a][pl] = a_src[slot * slot_u + (a * NP + pl) * 64];
-  };
-  auto read_ahi = [&](int slot) {
-#pragma unroll
-    for (int a = 0; a < HI; ++a)
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl)
-        ahi[a][pl] = a_src[slot * slot_u + ((LO + a) * NP + pl) * 64];
+      for (int pl = 0; pl < NP; ++pl) dst[t][pl] = b_src[slot * slot_u + ((t0 + t) * NP + pl) * 64];
   };
   auto flush = [&]() {   // accumulators -> partial slot (workgroup + segment), fragment order
     float* dst = A.partial + (size_t)(wg + cur.seg) * slot_elems;
@@ -409,63 +451,84 @@ __device__ __forceinline__ void consume(const BlockArgs& A, const SegTab& tab, C
         acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
   };
-  int m = 0;
+  int m = 0, slot = 0;
   const bool wb_on = ta0 == 0 && tb0 == 0;   // (PROF builds: the wave that is timed)
   (void)wb_on;
   WB_BEGIN();
-  // step m (ring slot S, B registers of parity Q); its alo and bf[Q] are in registers
-  auto step = [&](auto slot, auto par) {
-    constexpr int S = decltype(slot)::value, Q = decltype(par)::value;
+  // A read number l (>= NL: of the next step) into its slot
+  auto issue = [&](auto beta, auto lc, int cur_slot, int next_slot) {
+    constexpr int Bt = decltype(beta)::value, L = decltype(lc)::value;
+    constexpr int l = L >= NL ? L - NL : L;
+    constexpr int tile = l < NA ? l : 2 * NA - 2 - l;
+    rd_a(ic<(Bt + L) % 3>{}, L >= NL ? next_slot : cur_slot, tile);
+  };
+  // step m; its A reads 0 and 1 are in flight (slots beta, beta + 1), its first B half in Y
+  auto step = [&](auto beta) {
+    constexpr int Bt = decltype(beta)::value;
     if (wb_on) WB_MARK(7);
     if (m < nsteps) {
-      __builtin_amdgcn_sched_barrier(0);
-      read_ahi(S);
-      __builtin_amdgcn_sched_barrier(0);
+      const int nslot = slot == 2 ? 0 : slot + 1;
+      // pass 1: phase p = a uses read p
 #pragma unroll
-      for (int t = 0; t < P::n; ++t)
+      for (int a = 0; a < NA; ++a) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (a == 0) rd_b(Z, slot, LB, ic<HB>{});
+        if (a == 0) issue(beta, ic<2>{}, slot, nslot);
+        if (a == 1) issue(beta, ic<3>{}, slot, nslot);
+        if (a == 2) issue(beta, ic<4>{}, slot, nslot);
+        if (a == 3) issue(beta, ic<5>{}, slot, nslot);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int a = 0; a < LO; ++a)
+        for (int t = 0; t < P::n; ++t)
 #pragma unroll
-          for (int b = 0; b < NB; ++b)
-            acc[a][b] = mfma_bf16(alo[a][P::a[t]], bf[Q][b][P::b[t]], acc[a][b]);
-      __builtin_amdgcn_sched_barrier(0);
+          for (int b = 0; b < LB; ++b)
+            acc[a][b] = mfma_bf16(X[(Bt + a) % 3][P::a[t]], Y[b][P::b[t]], acc[a][b]);
+      }
       if (wb_on) WB_MARK(4);
-      // (ahi landed long ago; said here so that no wait for it is placed AFTER the reads
-      // below -- the 4-bit counter could only express that by draining them too)
-      wait_lds();
-      // step m + 1 was complete at the last barrier (past the range: stale bytes, unused)
-      read_alo((S + 1) % kRing);
-      read_b(ic<Q ^ 1>{}, (S + 1) % kRing);
-      __builtin_amdgcn_sched_barrier(0);
+      // pass 2: phase p = NA + i uses read p - 1 (tile NA - 1 - i); the turn issues nothing
 #pragma unroll
-      for (int t = 0; t < P::n; ++t)
+      for (int i = 0; i < NA; ++i) {
+        const int a = NA - 1 - i;
+        __builtin_amdgcn_sched_barrier(0);
+        if (i == 0) rd_b(Y, nslot, 0, ic<LB>{});  // step m + 1 was complete at the last barrier
+        if (i == 1) issue(beta, ic<NA + 2>{}, slot, nslot);
+        if (i == 2) issue(beta, ic<NA + 3>{}, slot, nslot);
+        if (i == 3) issue(beta, ic<NA + 4>{}, slot, nslot);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int a = 0; a < HI; ++a)
+        for (int t = 0; t < P::n; ++t)
 #pragma unroll
-          for (int b = 0; b < NB; ++b)
-            acc[LO + a][b] = mfma_bf16(ahi[a][P::a[t]], bf[Q][b][P::b[t]], acc[LO + a][b]);
+          for (int b = 0; b < HB; ++b)
+            acc[a][LB + b] = mfma_bf16(X[(Bt + (i == 0 ? NA - 1 : NA - 1 + i)) % 3][P::a[t]],
+                                       Z[b][P::b[t]], acc[a][LB + b]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (wb_on) WB_MARK(5);
       // last step of its segment, or of this workgroup's range
       if (cur.j + 1 == cur.steps || m + 1 == nsteps) flush();
       tab.advance(cur);
+      slot = nslot;
     }
     ++m;
     if (wb_on) WB_MARK(6);
     asm volatile("s_barrier" ::: "memory");
   };
+  // the matrix pipe first: the producers take the issue slots the MFMA stream leaves
+  __builtin_amdgcn_s_setprio(3);
   asm volatile("s_barrier" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
-  read_alo(0);
-  read_b(ic<0>{}, 0);
-  for (int it = 0; it < q6; ++it) {
-    step(ic<0>{}, ic<0>{});
-    step(ic<1>{}, ic<1>{});
-    step(ic<2>{}, ic<0>{});
-    step(ic<0>{}, ic<1>{});
-    step(ic<1>{}, ic<0>{});
-    step(ic<2>{}, ic<1>{});
+  rd_a(ic<0>{}, 0, 0);
+  rd_a(ic<1>{}, 0, NA > 1 ? 1 : 0);
+  rd_b(Y, 0, 0, ic<LB>{});
+  const int total = 4 * q4;
+  int it = 0;
+  for (; it + 3 <= total; it += 3) {
+    step(ic<0>{});
+    step(ic<NL % 3>{});
+    step(ic<(2 * NL) % 3>{});
   }
+  if (it < total) { step(ic<0>{}); ++it; }
+  if (it < total) step(ic<NL % 3>{});
 }
 
 // total steps of one block's segments; S = nblk * Sk; range length per workgroup
@@ -475,7 +538,7 @@ __device__ __forceinline__ int range_len(int S, int G, int min_steps) {
 }
 
 template <int NP>
-__global__ __launch_bounds__(512) void spconv_wgrad_block_kernel(BlockArgs A) {
+__global__ __launch_bounds__(768) void spconv_wgrad_block_kernel(BlockArgs A) {
   __shared__ __attribute__((aligned(16))) u32x4 ring[kRing * 2 * kMaxTiles * NP * 64];
   __shared__ int sstep[kMaxKvol], snum[kMaxKvol], s_total;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -497,27 +560,33 @@ __global__ __launch_bounds__(512) void spconv_wgrad_block_kernel(BlockArgs A) {
   const int s0 = wg * L;
   if (s0 >= S) return;
   const int s1 = s0 + L < S ? s0 + L : S;
-  const int nsteps = s1 - s0, q6 = (nsteps + 5) / 6;
+  const int nsteps = s1 - s0, q4 = (nsteps + 3) / 4;
   SegTab tab{sstep, snum, A.kvol, nseg};
   const Cursor cur = tab.at(s0, Sk);
 
   const int n0a = side_n0(A.TA), n0b = side_n0(A.TB);
   if (wave >= 4) {
-    const int pw = wave - 4, side = pw >> 1, h = pw & 1;
+    const int pw = wave - 4, side = pw >> 2, h = (pw >> 1) & 1, par = pw & 1;
     const int T = side ? A.TB : A.TA, n0 = side ? n0b : n0a;
     const int n = h ? T - n0 : n0, a0 = h ? n0 : 0;
+#define MSMD_PRODUCE(N_)                                                                    \
+  case N_:                                                                                  \
+    if (par) produce<NP, N_, 1>(A, tab, cur, nsteps, q4, side, a0, ring, lane);             \
+    else produce<NP, N_, 0>(A, tab, cur, nsteps, q4, side, a0, ring, lane);                 \
+    break
     switch (n) {
-      case 4: produce<NP, 4>(A, tab, cur, nsteps, q6, side, a0, ring, lane); break;
-      case 3: produce<NP, 3>(A, tab, cur, nsteps, q6, side, a0, ring, lane); break;
-      default: produce<NP, 2>(A, tab, cur, nsteps, q6, side, a0, ring, lane); break;
+      MSMD_PRODUCE(4);
+      MSMD_PRODUCE(3);
+      MSMD_PRODUCE(2);
     }
+#undef MSMD_PRODUCE
   } else {
     const int wa = wave >> 1, wb = wave & 1;
     const int na = wa ? A.TA - n0a : n0a, ta0 = wa ? n0a : 0;
     const int nb = wb ? A.TB - n0b : n0b, tb0 = wb ? n0b : 0;
 #define MSMD_CONSUME(NA_, NB_)                                                              \
   case NA_ * 8 + NB_:                                                                       \
-    consume<NP, NA_, NB_>(A, tab, cur, nsteps, q6, ta0, tb0, ring, wg, lane);           \
+    consume<NP, NA_, NB_>(A, tab, cur, nsteps, q4, ta0, tb0, ring, wg, lane);               \
     break
     switch (na * 8 + nb) {
       MSMD_CONSUME(4, 4);
@@ -534,41 +603,57 @@ __global__ __launch_bounds__(512) void spconv_wgrad_block_kernel(BlockArgs A) {
   }
 }
 
-// dW = sum of a segment's partial slots in workgroup order; fragment order -> dW layout.
+// dW = sum of a segment's partial slots in workgroup order (fixed: deterministic); fragment
+// order -> dW layout.  One thread = one 16-byte piece of a (block, offset) segment's image:
+// loads are lane-linear (coalesced, 8 in flight), the four sums go to four rows of dW.
+// grid = (pieces of one offset / 256, kvol).
 __global__ __launch_bounds__(256) void wgrad_block_reduce_kernel(BlockArgs A, int G, int krsc,
                                                                  float* __restrict__ dw) {
-  const int k = blockIdx.y;
-  int Sk = 0, start_k = 0, steps_k = 0;
-  for (int q = 0; q < A.kvol; ++q) {
-    const int st = (A.num[q] + 31) >> 5;
-    if (q == k) { start_k = Sk; steps_k = st; }
-    Sk += st;
-  }
+  const int k = blockIdx.y, lane = threadIdx.x & 63;
+  // steps per offset: one wave-wide prefix instead of kvol dependent loads per thread
+  const int st_l = lane < A.kvol ? (A.num[lane] + 31) >> 5 : 0;
+  const int ex_l = wave_excl_scan(st_l, lane);
+  const int Sk = __shfl(ex_l + st_l, 63, 64);
+  const int start_k = __shfl(ex_l, k, 64), steps_k = __shfl(st_l, k, 64);
   const int nblk = A.nba * A.nbb;
   const int L = range_len(Sk * nblk, G, A.min_steps);
   const int CA = A.TA * 16, CB = A.TB * 16;
   const int n0a = side_n0(A.TA), n1a = A.TA - n0a, n0b = side_n0(A.TB), n1b = A.TB - n0b;
-  const size_t slot_elems = (size_t)A.TA * A.TB * 256;
+  const int pieces_blk = A.TA * A.TB * 64;          // f32x4 pieces of one block image
+  const size_t slot_elems = (size_t)pieces_blk * 4;
   const int per_k = A.cin * A.cout;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < per_k; e += gridDim.x * 256) {
-    const int ci = e / A.cout, co = e - ci * A.cout;
-    const int ba = ci / CA, cil = ci - ba * CA, bb = co / CB, col = co - bb * CB;
-    int ta, ia, tb, ib;
-    if (cil < 16 * n0a) { ia = cil / n0a; ta = cil - ia * n0a; }
-    else { const int c2 = cil - 16 * n0a; ia = c2 / n1a; ta = n0a + c2 - ia * n1a; }
-    if (col < 16 * n0b) { ib = col / n0b; tb = col - ib * n0b; }
-    else { const int c2 = col - 16 * n0b; ib = c2 / n1b; tb = n0b + c2 - ib * n1b; }
-    const size_t elem = ((size_t)(ta * A.TB + tb) * 64 + (ia >> 2) * 16 + ib) * 4 + (ia & 3);
-    float s = 0.f;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < nblk * pieces_blk; e += gridDim.x * 256) {
+    const int blk = e / pieces_blk, pc = e - blk * pieces_blk;
+    const int tile = pc >> 6, ln = pc & 63;
+    const int ta = tile / A.TB, tb = tile - ta * A.TB;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (steps_k > 0) {
-      const int blk = ba * A.nbb + bb, seg = blk * A.kvol + k;
+      const int seg = blk * A.kvol + k;
       const int gs = blk * Sk + start_k;
       const int g_lo = gs / L, g_hi = (gs + steps_k - 1) / L;
-      const float* src = A.partial + (size_t)seg * slot_elems + elem;
-      for (int g = g_lo; g <= g_hi; ++g) s += src[(size_t)g * slot_elems];
+      const f32x4* src = (const f32x4*)(A.partial + (size_t)seg * slot_elems) + pc;
+      const size_t stride = slot_elems / 4;
+      int g = g_lo;
+      for (; g + 8 <= g_hi + 1; g += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(g + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; g <= g_hi; ++g) s += src[(size_t)g * stride];
     }
-    if (krsc) dw[((size_t)co * A.kvol + k) * A.cin + ci] = s;   // [c_out][K][c_in]
-    else dw[(size_t)k * per_k + e] = s;
+    // piece (tile ta, tb; lane (ib = ln & 15, gq = ln >> 4)): rows ia = 4 gq + r, column ib
+    const int ba = blk / A.nbb, bb = blk - ba * A.nbb;
+    const int ib = ln & 15, gq = ln >> 4;
+    const int co = bb * CB + (tb < n0b ? n0b * ib + tb : 16 * n0b + n1b * ib + (tb - n0b));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ia = 4 * gq + r;
+      const int ci = ba * CA + (ta < n0a ? n0a * ia + ta : 16 * n0a + n1a * ia + (ta - n0a));
+      if (krsc) dw[((size_t)co * A.kvol + k) * A.cin + ci] = s[r];   // [c_out][K][c_in]
+      else dw[(size_t)k * per_k + (size_t)ci * A.cout + co] = s[r];
+    }
   }
 }
 
@@ -629,11 +714,10 @@ int wgrad_block(const float* in_feat, int c_in, const float* d_out, int c_out,
   static const int dbg = [] { const char* e = getenv("MSMD_WGRAD_DBG"); return e ? atoi(e) : 0; }();
   A.dbg = dbg;
   const int G = cu_count();
-  if (np == 3) MSMD_LAUNCH(spconv_wgrad_block_kernel<3>, dim3(G), dim3(512), 0, st, A);
-  else if (np == 2) MSMD_LAUNCH(spconv_wgrad_block_kernel<2>, dim3(G), dim3(512), 0, st, A);
-  else MSMD_LAUNCH(spconv_wgrad_block_kernel<1>, dim3(G), dim3(512), 0, st, A);
-  int rb = ceil_div(c_in * c_out, 256);
-  if (rb > 64) rb = 64;
+  if (np == 3) MSMD_LAUNCH(spconv_wgrad_block_kernel<3>, dim3(G), dim3(768), 0, st, A);
+  else if (np == 2) MSMD_LAUNCH(spconv_wgrad_block_kernel<2>, dim3(G), dim3(768), 0, st, A);
+  else MSMD_LAUNCH(spconv_wgrad_block_kernel<1>, dim3(G), dim3(768), 0, st, A);
+  const int rb = ceil_div(c_in * c_out / 4, 256);   // one thread per 16-byte piece
   MSMD_LAUNCH(wgrad_block_reduce_kernel, dim3(rb, kvol), dim3(256), 0, st, A, G, krsc_out,
               d_weight);
   return launch_status();

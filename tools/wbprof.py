@@ -32,14 +32,24 @@ for si, cin, cout in [(2, 128, 128), (1, 96, 96), (0, 80, 80), (2, 64, 64)]:
     steps = int(((num + 31) // 32).sum())
     f = torch.randn(n, cin, device=dev)
     g = torch.randn(n, cout, device=dev)
-    for _ in range(3):
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.6:      # clocks ramp for several hundred ms from idle
         K.conv_wgrad_split(f, g, pairs, num, 3)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        K.conv_wgrad_split(f, g, pairs, num, 3)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) * 100
     buf = (ctypes.c_ulonglong * 16)()
     h.msmd_debug_wbprof(buf)
     K.conv_wgrad_split(f, g, pairs, num, 3)
     h.msmd_debug_wbprof(buf)
     v = list(buf)
     its = 16 * max(1, (steps + 255) // 256)     # iterations of the 16 timed workgroups
-    print("%dx%d: %d rows, %d steps, ~%d per workgroup; cycles per iteration: %s | P %.0f C %.0f" % (
-        cin, cout, n, steps, its // 16, ", ".join("%s %.0f" % (names[j], v[j] / its) for j in range(8)),
+    print("%dx%d: %.0f us/call, %d rows, %d steps, ~%d per workgroup; cycles per iteration: %s | P %.0f C %.0f" % (
+        cin, cout, us, n, steps, its // 16, ", ".join("%s %.0f" % (names[j], v[j] / its) for j in range(8)),
         sum(v[:4]) / its, sum(v[4:8]) / its))

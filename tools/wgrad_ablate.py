@@ -15,15 +15,20 @@ from msmdfusion_amd import synthetic as S  # noqa: E402
 dev = torch.device("cuda:0")
 
 
-def timed(fn, n=10):
-    for _ in range(3):
+def timed(fn, n=20):
+    """us per call by device events, after the clocks have ramped (they take several hundred
+    ms of load from idle: a cold measurement reads up to 2x the warm one)."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.6:
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
     for _ in range(n):
         fn()
+    b.record()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e6
+    return a.elapsed_time(b) / n * 1e3
 
 
 clouds = [torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in range(4)]
