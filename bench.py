@@ -365,7 +365,13 @@ def run_workload(workload, args, dev, rank, world, profile):
             prefetch = IndexPrefetcher(model.prepare, dev, threaded=threaded,
                                        depth=int(os.environ.get("MSMD_PREFETCH_DEPTH", "1")))
     # grad_clip max_norm=10 (config); the step structure is msmdfusion_amd.distributed.TrainStep
-    step = D.TrainStep(net, params, opt, lambda bev: (bev * target).mean(), prefetch, 10.0)
+    train_step = D.TrainStep(net, params, opt, lambda bev: (bev * target).mean(), prefetch, 10.0)
+    calls = [0]          # every step of this workload, timed or not (profile normalisation)
+
+    def step(b):
+        calls[0] += 1
+        return train_step(b)
+    step.prime = train_step.prime
     step.prime(batch)
 
     # Setup, untimed: let torch's caching allocator reach its steady state before
@@ -426,6 +432,9 @@ def run_workload(workload, args, dev, rank, world, profile):
                       "parallelism": "dp%d" % world, "index_prefetch": prefetch is not None,
                       "trainable_params": sum(p.numel() for p in params)}}
     res["roofline"] = roofline(prof, workload) if prof else None
+    if rank == 0:   # tools/stream_prof.py divides a rocprofv3 trace of this run by this count
+        print("[bench] workload=%s steps_total=%d (+1 untimed check step)" % (workload, calls[0]),
+              file=sys.stderr)
     if hasattr(prefetch, "close"):
         prefetch.close()
     del step, net, model, opt, prefetch

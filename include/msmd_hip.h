@@ -521,6 +521,42 @@ int msmd_sparse_add_rows(const float* feat_a, const int32_t* map_a, int n_a,
                          msmd_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
+ * a16  GMA-Conv stage assembly (one launch each way)
+ * replaces: the index / cat / pad / mul chain of
+ *           SparseMultiModalEncoderPaint.grouped_sparse_conv
+ *           mmdet3d/models/middle_encoders/sparse_encoder_multimodal_encoderpaint_double_aware.py:349-421
+ * out rows, in this order ([c3 | c2] columns):
+ *   n_o3      only-3D rows   [ conv3[i]                       | 0 ]
+ *   n_o2      only-2D rows   [ 0 | cross_gate[nn3[i] < 0 ? n3 : nn3[i]] * feat2[rows_o2[i]] ]
+ *   n_o2_pad  zero rows (samples without an only-2D voxel, :208-225)
+ *   n_mix     mixed rows     [ feat3[rows_m3[i]] | gate[i] * feat2[rows_m2[i]] ]
+ *   n_mix_pad zero rows
+ * backward: d_conv3 = left block of the only-3D rows, d_gate = right block of the
+ * mixed rows * feat2, d_cross_gate[t] = sum over the only-2D rows whose nearest voxel is t
+ * of right block * feat2.  With `order` (the only-2D rows sorted by nearest voxel, -1 as
+ * n3) and `starts` (starts[t] .. starts[t+1] = target t's slice of `order`) the sum runs
+ * in a fixed order, one wave per target (c2 <= 64); without them: a zero fill + float
+ * atomics, like the index_add_ it replaces.  feat3 / feat2 receive no gradient.
+ * c3, c2 multiples of 4. */
+int msmd_gma_assemble_fwd_f32(const float* conv3, int n_o3, int c3, const float* cross_gate,
+                              int n3, int c2, const int64_t* nn3, const float* feat2,
+                              const int64_t* rows_o2, int n_o2, int n_o2_pad,
+                              const float* feat3, const int64_t* rows_m3, const float* gate,
+                              const int64_t* rows_m2, int n_mix, int n_mix_pad,
+                              float* out /* [rows, c3 + c2] */, msmd_stream_t stream);
+int msmd_gma_assemble_bwd_f32(const float* d_out, int n_o3, int c3, int n3, int c2,
+                              const int64_t* nn3, const float* feat2, const int64_t* rows_o2,
+                              int n_o2, int n_o2_pad, const int64_t* rows_m2, int n_mix,
+                              int n_mix_pad, float* d_conv3 /* [n_o3,c3] */,
+                              float* d_cross_gate /* [n3+1,c2] or NULL */,
+                              float* d_gate /* [n_mix,c2] or NULL */,
+                              const int64_t* order /* [n_o2] or NULL */,
+                              const int64_t* starts /* [n3+2] or NULL */,
+                              float* workspace /* ..._workspace_floats(c2) floats, with order */,
+                              msmd_stream_t stream);
+size_t msmd_gma_assemble_bwd_workspace_floats(int c2);
+
+/* ------------------------------------------------------------------------ *
  * a14  voxel_modality_split: LiDAR voxels vs virtual-point voxels
  * replaces: MSMDFusionDetector.voxel_modality_split + numba type_assign
  *           mmdet3d/models/detectors/MSMDFusion.py:27-45,251-325

@@ -105,6 +105,11 @@ SIGNATURES = {
     "msmd_sparse_add_count": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _sz, _vp]),
     "msmd_sparse_add_fill": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _ip, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "msmd_sparse_add_rows": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "msmd_gma_assemble_fwd_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp,
+                                       _i, _i, _vp, _vp]),
+    "msmd_gma_assemble_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp,
+                                       _vp, _vp, _vp, _vp, _vp]),
+    "msmd_gma_assemble_bwd_workspace_floats": (_sz, [_i]),
     "msmd_modality_split_workspace_bytes": (_sz, [_i, _ip]),
     "msmd_modality_split": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "msmd_modality_split_stats": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,

@@ -1013,6 +1013,79 @@ def sparse_add_rows(feat_a, map_a, feat_b, map_b, n_out):
     return of
 
 
+class _GmaAssemble(torch.autograd.Function):
+    """Feature assembly of a GMA-Conv stage, one launch each way (csrc/gma.hip)."""
+
+    @staticmethod
+    def forward(ctx, conv3, cross_gate, gate, feat3, feat2, nn3, rows_o2, rows_m3, rows_m2,
+                n_o2_pad, n_mix_pad, order, starts):
+        n_o3, c3 = conv3.shape
+        n3, c2 = cross_gate.shape[0] - 1, cross_gate.shape[1]
+        n_o2, n_mix = rows_o2.shape[0], rows_m3.shape[0]
+        rows = n_o3 + n_o2 + n_o2_pad + n_mix + n_mix_pad
+        out = torch.empty((rows, c3 + c2), dtype=torch.float32, device=conv3.device)
+        check(lib.msmd_gma_assemble_fwd_f32(
+            _p(conv3), n_o3, c3, _p(cross_gate), n3, c2, _p(nn3), _p(feat2), _p(rows_o2), n_o2,
+            int(n_o2_pad), _p(feat3), _p(rows_m3), _p(gate), _p(rows_m2), n_mix, int(n_mix_pad),
+            _p(out), _stream()), "msmd_gma_assemble_fwd_f32")
+        ctx.save_for_backward(feat2, nn3, rows_o2, rows_m2)
+        ctx.csr = (order, starts)
+        ctx.dims = (n_o3, c3, n3, c2, n_o2, int(n_o2_pad), n_mix, int(n_mix_pad))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        feat2, nn3, rows_o2, rows_m2 = ctx.saved_tensors
+        n_o3, c3, n3, c2, n_o2, n_o2_pad, n_mix, n_mix_pad = ctx.dims
+        d = d_out.contiguous().float()
+        need = ctx.needs_input_grad
+        d_conv3 = torch.empty((n_o3, c3), dtype=torch.float32, device=d.device)
+        d_cross = torch.empty((n3 + 1, c2), dtype=torch.float32, device=d.device) if need[1] else None
+        d_gate = torch.empty((n_mix, c2), dtype=torch.float32, device=d.device) if need[2] else None
+        ws = None
+        if ctx.csr[0] is not None and d_cross is not None:
+            ws = _ws(4 * lib.msmd_gma_assemble_bwd_workspace_floats(c2), d.device)
+        check(lib.msmd_gma_assemble_bwd_f32(
+            _p(d), n_o3, c3, n3, c2, _p(nn3), _p(feat2), _p(rows_o2), n_o2, n_o2_pad,
+            _p(rows_m2), n_mix, n_mix_pad, _p(d_conv3), _p(d_cross), _p(d_gate),
+            _p(ctx.csr[0]), _p(ctx.csr[1]), _p(ws), _stream()), "msmd_gma_assemble_bwd_f32")
+        return (d_conv3 if need[0] else None, d_cross, d_gate) + (None,) * 10
+
+
+def gma_nn_segments(nn3, n3):
+    """(order, starts) for gma_assemble's backward: the only-2D rows sorted by their nearest
+    3D voxel (-1 -> n3, stable) and, per target t in 0..n3, its slice starts[t]:starts[t+1] of
+    `order`.  Index-only (no host read): the index pass builds it ahead of the feature pass."""
+    key = torch.where(nn3 >= 0, nn3, torch.full_like(nn3, n3))
+    skey, order = torch.sort(key, stable=True)
+    starts = torch.searchsorted(skey, torch.arange(n3 + 2, device=nn3.device, dtype=skey.dtype))
+    return order.contiguous(), starts.contiguous()
+
+
+def gma_assemble(conv3, cross_gate, gate, feat3, feat2, nn3, rows_o2, rows_m3, rows_m2,
+                 n_o2_pad=0, n_mix_pad=0, segments=None):
+    """Unified features of a GMA-Conv stage (mmdet3d/models/middle_encoders/
+    sparse_encoder_multimodal_encoderpaint_double_aware.py:349-421): rows
+    [conv3 | 0], [0 | cross_gate[nn3] * feat2[rows_o2]], zero pad rows,
+    [feat3[rows_m3] | gate * feat2[rows_m2]], zero pad rows.  Gradients flow to conv3,
+    cross_gate and gate; feat3 / feat2 must not require one (the caller falls back to the
+    unfused ops otherwise).  segments = gma_nn_segments(nn3, n3): d cross_gate is then summed
+    in a fixed order (deterministic); without it by float atomics."""
+    _need_cuda(conv3, cross_gate, gate, feat3, feat2, nn3, rows_o2, rows_m3, rows_m2)
+    assert not feat3.requires_grad and not feat2.requires_grad
+    assert nn3.dtype == rows_o2.dtype == rows_m3.dtype == rows_m2.dtype == torch.int64
+    assert nn3.shape[0] == rows_o2.shape[0] and rows_m3.shape[0] == rows_m2.shape[0] == gate.shape[0]
+    assert conv3.shape[1] == feat3.shape[1] and cross_gate.shape[1] == gate.shape[1] == feat2.shape[1]
+    f = lambda t: t.contiguous().float()
+    order, starts = segments if segments is not None else (None, None)
+    if order is not None:
+        assert order.dtype == starts.dtype == torch.int64 and order.shape[0] == nn3.shape[0]
+        assert starts.shape[0] == cross_gate.shape[0] + 1
+    return _GmaAssemble.apply(f(conv3), f(cross_gate), f(gate), f(feat3), f(feat2),
+                              nn3.contiguous(), rows_o2.contiguous(), rows_m3.contiguous(),
+                              rows_m2.contiguous(), int(n_o2_pad), int(n_mix_pad), order, starts)
+
+
 def modality_split(idx_3d, idx_2d, batch_size, spatial_shape):
     """-> (mix3d[n3], mix2d[n2], pair_3d[m], pair_2d[m])"""
     _need_bzyx(idx_3d, idx_2d)

@@ -17,6 +17,8 @@ Documented deviations from the reference:
   * B.6 a query covered by several balls takes the highest representative
     index (what a sequential index_put_ leaves).
 """
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -64,6 +66,8 @@ class SparseMultiModalEncoderPaint(nn.Module):
         self.down_stride = down_stride
         self.order = order
         self.fp16_enabled = False
+        # one-launch stage assembly (kernels.gma_assemble); MSMD_FUSED_ASSEMBLY=0: the op chain
+        self.fused_assembly = os.environ.get("MSMD_FUSED_ASSEMBLY", "1") != "0"
         self.dummy_embedding_fn = lambda c, device: torch.rand(1, c).to(device)
         self.make_grouped_sparse_conv_blocks(norm_cfg)
         self.make_aggregation_block(norm_cfg)
@@ -225,6 +229,9 @@ class SparseMultiModalEncoderPaint(nn.Module):
         if plan["n_pad"]:
             nn3 = torch.cat([nn3, nn3.new_full((plan["n_pad"],), -1)])
         plan["nn3"] = nn3
+        # the rows of each nearest voxel, for the assembly's backward (no atomics there)
+        n_raw = plan["o2_bzyx"].shape[0]
+        plan["nn_segments"] = K.gma_nn_segments(nn3[:n_raw], plan["idx3"].shape[0])
         return plan
 
     def plan_stage_tensors(self, plan, idx3_5, idx2_5, syn_mix_2D, shape3, shape2, batch_size,
@@ -284,18 +291,12 @@ class SparseMultiModalEncoderPaint(nn.Module):
             torch.cuda.current_stream().wait_event(plan["ready"])
         only_3D_rows, only_2D_rows = plan["only_3D_rows"], plan["only_2D_rows"]
         o2_idx, nn3 = plan["o2_idx"], plan["nn3"]
-        o2_feat = voxel_2D.features.index_select(0, only_2D_rows)
-        if plan["n_pad"]:       # :208-225 samples without an only-2D voxel got a zero row
-            o2_feat = torch.cat([o2_feat, o2_feat.new_zeros((plan["n_pad"], o2_feat.shape[1]))], 0)
         # uncovered 2D voxels are gated by a random embedding (row -1 -> last row)
         dummy = plan["dummy"] if "dummy" in plan else \
             self.dummy_embedding_fn(c3, voxel_3D.features.device)
         cross_gating = self.cross_gate_control[stage_id](
             torch.cat([voxel_3D.features, dummy.to(voxel_3D.features.dtype)], 0))
         n3 = voxel_3D.features.shape[0]
-        o2_feat = cross_gating.index_select(
-            0, torch.where(nn3 >= 0, nn3, torch.full_like(nn3, n3))) * o2_feat
-
         planned = "unified" in plan     # plan_stage_tensors ran: voxel sets + rulebooks exist
         f3_only = voxel_3D.features.index_select(0, only_3D_rows)
         if planned:
@@ -304,11 +305,32 @@ class SparseMultiModalEncoderPaint(nn.Module):
             voxel_only_3D = spconv.SparseConvTensor(
                 f3_only, voxel_3D.indices.index_select(0, only_3D_rows)[:, zyx].contiguous(),
                 voxel_3D.spatial_shape, B)
-
         mixed_3D = voxel_3D.features.index_select(0, syn_mix_3D)
+        assert syn_mix_3D.shape[0] == syn_mix_2D.shape[0]
+        gate = self.gate_control[stage_id](mixed_3D)
+        stage = f"stage_{stage_id + 1}"
+        # One launch for the rest (csrc/gma.hip) when the stage was planned ahead and neither
+        # input tensor wants a gradient (frozen LiDAR encoder, raw virtual-point voxels: the
+        # LC training configuration); the reference's op-by-op chain otherwise -- same values.
+        fused = planned and self.fused_assembly and voxel_3D.features.is_cuda and not (
+            voxel_3D.features.requires_grad or voxel_2D.features.requires_grad)
+        if fused:
+            voxel_only_3D = getattr(self.grouped_sp_conv_blocks_3D, stage)(voxel_only_3D)
+            n_o2 = only_2D_rows.shape[0]
+            feats = K.gma_assemble(
+                voxel_only_3D.features, cross_gating, gate, voxel_3D.features, voxel_2D.features,
+                nn3[:n_o2], only_2D_rows, syn_mix_3D, syn_mix_2D, plan["n_pad"],
+                plan["mixed_pad"], segments=plan.get("nn_segments"))
+            unified = plan["unified"].replace_feature(feats)
+            return getattr(self.aggregation_blocks, stage)(unified)
+        o2_feat = voxel_2D.features.index_select(0, only_2D_rows)
+        if plan["n_pad"]:       # :208-225 samples without an only-2D voxel got a zero row
+            o2_feat = torch.cat([o2_feat, o2_feat.new_zeros((plan["n_pad"], o2_feat.shape[1]))], 0)
+        o2_feat = cross_gating.index_select(
+            0, torch.where(nn3 >= 0, nn3, torch.full_like(nn3, n3))) * o2_feat
+
         mixed_2D = voxel_2D.features.index_select(0, syn_mix_2D)
-        assert mixed_3D.shape[0] == mixed_2D.shape[0]
-        mixed_2D = self.gate_control[stage_id](mixed_3D) * mixed_2D
+        mixed_2D = gate * mixed_2D
         mixed_feat = torch.cat([mixed_3D, mixed_2D], -1)
         if planned:
             if plan["mixed_pad"]:
@@ -317,7 +339,6 @@ class SparseMultiModalEncoderPaint(nn.Module):
         else:
             mixed_idx, mixed_feat = self.pad_missing_batch_id(
                 voxel_2D.indices.index_select(0, syn_mix_2D), mixed_feat, B)
-        stage = f"stage_{stage_id + 1}"
         voxel_only_3D = getattr(self.grouped_sp_conv_blocks_3D, stage)(voxel_only_3D)
         f2 = F.pad(o2_feat, (c3, 0), mode="constant", value=0)
         f3 = F.pad(voxel_only_3D.features, (0, 64), mode="constant", value=0)

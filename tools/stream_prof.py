@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Per-stream, per-step summary of a rocprofv3 --kernel-trace CSV of one bench.py run.
+
+    python tools/stream_prof.py <kernel_trace.csv> <bench stderr log> [top]
+
+The step count comes from the run itself (bench.py prints `[bench] workload=.. steps_total=N`),
++1 for the untimed finiteness step -- never a hard-coded number.  Kernels are attributed to
+the hardware queue they ran on; the queue with the most conv time is the feature pass
+("main"), the others are the index / neighbour-search side streams.
+"""
+import collections
+import csv
+import re
+import sys
+
+
+def main():
+    trace, log = sys.argv[1], sys.argv[2]
+    top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+    steps = None
+    for line in open(log, errors="replace"):
+        m = re.search(r"steps_total=(\d+)", line)
+        if m:
+            steps = int(m.group(1)) + 1
+    if not steps:
+        sys.exit("no `steps_total=` line in %s" % log)
+    rows = list(csv.DictReader(open(trace)))
+    qcol = "Queue_Id" if "Queue_Id" in rows[0] else ("Stream_Id" if "Stream_Id" in rows[0] else None)
+    per_q = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    launches = 0
+    for r in rows:
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        e = per_q[r[qcol] if qcol else "all"][short(r["Kernel_Name"])]
+        e[0] += 1
+        e[1] += d
+        launches += 1
+    conv_time = {q: sum(v[1] for k, v in ks.items() if "spconv" in k) for q, ks in per_q.items()}
+    main_q = max(conv_time, key=conv_time.get)
+    print("steps %d (from the run), %.0f kernel launches per step, %d queues" % (
+        steps, launches / steps, len(per_q)))
+    for q, ks in sorted(per_q.items(), key=lambda kv: -sum(v[1] for v in kv[1].values())):
+        tot = sum(v[1] for v in ks.values())
+        n = sum(v[0] for v in ks.values())
+        print("\nqueue %s%s: %.3f ms of kernels per step, %.0f launches per step" % (
+            q, " (feature pass)" if q == main_q else "", tot / steps / 1e3, n / steps))
+        groups = collections.defaultdict(lambda: [0, 0.0])
+        for k, v in ks.items():
+            g = groups[group(k)]
+            g[0] += v[0]
+            g[1] += v[1]
+        print("   by group: " + ", ".join("%s %.2f ms/%d" % (g, v[1] / steps / 1e3, round(v[0] / steps))
+                                          for g, v in sorted(groups.items(), key=lambda kv: -kv[1][1])))
+        for k, v in sorted(ks.items(), key=lambda kv: -kv[1][1])[:top if q == main_q else 8]:
+            print("   %-70s %6.1f /step %8.1f us avg %7.3f ms/step" % (
+                k[:70], v[0] / steps, v[1] / v[0], v[1] / steps / 1e3))
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return name
+
+
+def group(k):
+    if "spconv_fwd" in k or "spconv_wgrad" in k or "wgrad_block" in k or "pack_weight" in k:
+        return "conv"
+    if k.startswith("msmd::bn_"):
+        return "bn"
+    if "fillBuffer" in k or "copyBuffer" in k:
+        return "fill/copy"
+    if k.startswith("msmd::"):
+        return "msmd-other"
+    if "Cijk" in k:
+        return "gemm"
+    if "rocprim" in k or "hipcub" in k:
+        return "sort/scan"
+    return "torch"
+
+
+if __name__ == "__main__":
+    main()
