@@ -259,28 +259,47 @@ struct PairCount {
     return o < n_rows && nbr[(size_t)k * n_rows + o] >= 0;
   }
 };
-struct PairEmit {
-  const int32_t* nbr;
-  int n_rows, rows_pad, ld;
-  int32_t* pairs;
-  int* tile_offs;  // exclusive prefix over all (offset,tile) tiles
-  __device__ void operator()(int e, int p, int v) const {
-    if (!v) return;
-    int k = e / rows_pad, o = e - k * rows_pad;
-    int base = tile_offs[k * (rows_pad / kScanTile)];  // first tile of offset k
-    int pos = p - base;
-    if (pos >= ld) return;
-    pairs[((size_t)k * 2 + 0) * ld + pos] = nbr[(size_t)k * n_rows + o];
-    pairs[((size_t)k * 2 + 1) * ld + pos] = o;
+// Compaction of one offset's neighbours into the reference's pair lists, with the tail of
+// both rows filled with -1 (the reference allocates indicePairs as full(-1),
+// spconv_ops.h:55-59) by the table's EMPTY entries: entry o of offset k without a
+// neighbour, the r-th such, writes position num_k + r.  No 0xFF fill of the whole
+// [K,2,ld] tensor in front (19 MB per table at 90k rows, 12 tables per LC step), no scan of
+// the tile sums, no separate count kernel: a block adds up the tile sums it needs.
+__global__ __launch_bounds__(kScanBlock) void pairs_apply_kernel(
+    const int32_t* __restrict__ nbr, int n_rows, int rows_pad, int ld, int kvol,
+    const int* __restrict__ tile_sums, int32_t* __restrict__ pairs, int32_t* __restrict__ num) {
+  __shared__ int smem[kScanBlock / 64];
+  const int tpk = rows_pad / kScanTile;
+  const int k = blockIdx.x / tpk, tile_in_k = blockIdx.x - k * tpk;
+  // pairs of this offset in front of this tile, and in the whole offset
+  int carry = block_range_sum<kScanBlock>(tile_sums, k * tpk, (int)blockIdx.x, smem);
+  const int num_k = carry + block_range_sum<kScanBlock>(tile_sums, (int)blockIdx.x, (k + 1) * tpk, smem);
+  if (tile_in_k == 0 && threadIdx.x == 0) num[k] = num_k;
+  int32_t* pin = pairs + ((size_t)k * 2 + 0) * ld;
+  int32_t* pout = pin + ld;
+  const int base = tile_in_k * kScanTile;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    const int o = base + j * kScanBlock + threadIdx.x;
+    const int src = o < n_rows ? nbr[(size_t)k * n_rows + o] : -1;
+    const int v = src >= 0;
+    int tot;
+    const int ex = block_excl_scan<kScanBlock>(v, smem, &tot);
+    const int pos = carry + ex;            // pairs of offset k in front of entry o
+    if (v) {
+      if (pos < ld) {
+        pin[pos] = src;
+        pout[pos] = o;
+      }
+    } else {
+      const int tail = num_k + (o - pos);  // o - pos = empty entries in front of o
+      if (tail < ld) {
+        pin[tail] = -1;
+        pout[tail] = -1;
+      }
+    }
+    carry += tot;
   }
-};
-__global__ void pair_counts(const int* __restrict__ tile_offs, const int* __restrict__ total,
-                            int tiles_per_k, int kvol, int32_t* __restrict__ num) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= kvol) return;
-  int lo = tile_offs[k * tiles_per_k];
-  int hi = k + 1 < kvol ? tile_offs[(k + 1) * tiles_per_k] : *total;
-  num[k] = hi - lo;
 }
 
 int check_geom(const int* shape, const int* ks, const int* st, const int* pd, int batch,
@@ -552,15 +571,20 @@ MSMD_EXPORT int msmd_rulebook_pairs(const int32_t* nbr, int kernel_volume, int n
   int* tiles = a.take<int>((size_t)kernel_volume * tpk + 1);
   int* total = a.take<int>(64);
   if (!a.ok()) return MSMD_ERR_WORKSPACE;
-  if (ld > 0)
+  // (entries past rows_pad -- ld larger than the padded table -- are not reached by the
+  // empty entries' -1 writes)
+  if (ld > rp)
     hipMemsetAsync(indice_pairs, 0xFF, sizeof(int32_t) * (size_t)kernel_volume * 2 * ld, st);
   if (n_rows == 0) {
+    if (ld > 0 && ld <= rp)
+      hipMemsetAsync(indice_pairs, 0xFF, sizeof(int32_t) * (size_t)kernel_volume * 2 * ld, st);
     hipMemsetAsync(indice_num, 0, sizeof(int32_t) * kernel_volume, st);
     return launch_status();
   }
-  device_scan(PairCount{nbr, n_rows, rp}, PairEmit{nbr, n_rows, rp, ld, indice_pairs, tiles},
-              kernel_volume * rp, tiles, total, -1, st);
-  MSMD_LAUNCH(pair_counts, dim3(ceil_div(kernel_volume, 64)), dim3(64), 0, st, tiles, total,
-                     tpk, kernel_volume, indice_num);
+  (void)total;
+  MSMD_LAUNCH(scan_tile_sums<PairCount>, dim3(kernel_volume * tpk), dim3(kScanBlock), 0, st,
+              PairCount{nbr, n_rows, rp}, kernel_volume * rp, tiles);
+  MSMD_LAUNCH(pairs_apply_kernel, dim3(kernel_volume * tpk), dim3(kScanBlock), 0, st, nbr, n_rows,
+              rp, ld, kernel_volume, (const int*)tiles, indice_pairs, indice_num);
   return launch_status();
 }

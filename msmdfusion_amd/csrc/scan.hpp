@@ -1,6 +1,9 @@
-// scan.hpp -- device-wide exclusive prefix sum in three small kernels
-// (tile sums -> single-block scan of tile sums -> apply), generic over where
-// the per-element count comes from and what is done with the prefix.
+// scan.hpp -- device-wide exclusive prefix sum in two small kernels (tile sums -> apply),
+// generic over where the per-element count comes from and what is done with the prefix.
+// (Round 3: the single-block scan of the tile sums between the two is gone -- every apply
+// block adds up the tile sums in front of it itself, a few KB from L2.  The index pass of
+// an LC step runs 44 scans on a stream whose launches queue behind the feature pass's
+// persistent kernels: a launch there costs far more than the few microseconds of its work.)
 //   Count: int operator()(int i) const          -- value of element i
 //   Emit : void operator()(int i, int prefix, int value) const
 // Used for: popcount ranks of occupancy bitmaps (strided rulebook,
@@ -38,29 +41,34 @@ __global__ __launch_bounds__(kScanBlock) void scan_tile_sums(Count count, int n,
   }
 }
 
-// One block: in-place exclusive scan of tile_sums[0..ntiles), total -> *total
-// (optionally clamped to `clamp` when clamp >= 0).
-static __global__ __launch_bounds__(1024) void scan_tiles_top(int* __restrict__ tile_sums, int ntiles,
-                                                       int* __restrict__ total, int clamp) {
-  __shared__ int smem[1024 / 64];
-  int carry = 0;
-  for (int base = 0; base < ntiles; base += 1024) {
-    int i = base + threadIdx.x;
-    int v = i < ntiles ? tile_sums[i] : 0;
-    int tot;
-    int ex = block_excl_scan<1024>(v, smem, &tot);
-    if (i < ntiles) tile_sums[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0 && total) *total = (clamp >= 0 && carry > clamp) ? clamp : carry;
+// Sum of a[lo .. hi) by the whole block (same value in every thread).  smem: BLOCK/64 ints.
+template <int BLOCK>
+__device__ __forceinline__ int block_range_sum(const int* __restrict__ a, int lo, int hi,
+                                               int* smem) {
+  int s = 0;
+  for (int i = lo + (int)threadIdx.x; i < hi; i += BLOCK) s += a[i];
+  s = wave_sum(s);
+  __syncthreads();   // smem may still be read from a previous use
+  if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = s;
+  __syncthreads();
+  int t = 0;
+#pragma unroll
+  for (int i = 0; i < BLOCK / 64; ++i) t += smem[i];
+  return t;
+}
+
+// total <- 0 for an empty input
+static __global__ void scan_empty_total(int* __restrict__ total) {
+  if (total) *total = 0;
 }
 
 template <typename Count, typename Emit>
 __global__ __launch_bounds__(kScanBlock) void scan_apply(Count count, Emit emit, int n,
-                                                         const int* __restrict__ tile_offs) {
+                                                         const int* __restrict__ tile_sums,
+                                                         int* __restrict__ total, int clamp) {
   __shared__ int smem[kScanBlock / 64];
   const int base = blockIdx.x * kScanTile;
-  int carry = tile_offs[blockIdx.x];
+  int carry = block_range_sum<kScanBlock>(tile_sums, 0, blockIdx.x, smem);
 #pragma unroll
   for (int j = 0; j < kScanItems; ++j) {
     int i = base + j * kScanBlock + threadIdx.x;
@@ -70,22 +78,23 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply(Count count, Emit emit,
     if (i < n) emit(i, carry + ex, v);
     carry += tot;
   }
+  if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+    *total = (clamp >= 0 && carry > clamp) ? clamp : carry;
 }
 
-// Host driver.  tile_sums: scratch of scan_num_tiles(n) ints.
+// Host driver.  tile_sums: scratch of scan_num_tiles(n) ints (raw tile sums afterwards).
 template <typename Count, typename Emit>
 inline void device_scan(Count count, Emit emit, int n, int* tile_sums, int* total, int clamp,
                         hipStream_t st) {
   const int nt = scan_num_tiles(n);
   if (nt == 0) {
-    MSMD_LAUNCH(scan_tiles_top, dim3(1), dim3(1024), 0, st, tile_sums, 0, total, clamp);
+    MSMD_LAUNCH(scan_empty_total, dim3(1), dim3(1), 0, st, total);
     return;
   }
   MSMD_LAUNCH(scan_tile_sums<Count>, dim3(nt), dim3(kScanBlock), 0, st, count, n,
                      tile_sums);
-  MSMD_LAUNCH(scan_tiles_top, dim3(1), dim3(1024), 0, st, tile_sums, nt, total, clamp);
   MSMD_LAUNCH((scan_apply<Count, Emit>), dim3(nt), dim3(kScanBlock), 0, st, count, emit, n,
-                     tile_sums);
+                     (const int*)tile_sums, total, clamp);
 }
 
 // ---- occupancy bitmap + popcount rank ---------------------------------------

@@ -109,7 +109,13 @@ MSMD_EXPORT int msmd_rulebook_tiling(const int32_t* nbr, int kernel_volume, int 
   if (hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.keys, w.keys_out, w.vals, w.sorted, n, 0,
                                          key_bits, st) != hipSuccess)
     return MSMD_ERR_LAUNCH;
-  if (full > 1) {
+  // Heaviest-first sequencing of whole tiles is what the DYNAMIC tile scheduler wants (LPT
+  // list scheduling); stream-K -- the split kernels' schedule -- cuts the sequence into
+  // equal cost shares wherever the tiles lie, so the cost pass and the second sort (5 of a
+  // tiling's ~12 launches on the index stream) buy nothing there.  MSMD_TILE_LPT=1 restores
+  // them (needed with MSMD_STREAMK=0).
+  static const int lpt = [] { const char* e = getenv("MSMD_TILE_LPT"); return e ? atoi(e) : 0; }();
+  if (full > 1 && lpt) {
     launch_tile_costs(nbr, kernel_volume, n, w.sorted, rows_per_tile, w.cost, w.tile_ids, st);
     cb = w.cub_bytes;
     if (hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.cost, w.cost_out, w.tile_ids, w.tile_seq,
@@ -118,7 +124,7 @@ MSMD_EXPORT int msmd_rulebook_tiling(const int32_t* nbr, int kernel_volume, int 
   }
   static const int zigzag = [] { const char* e = getenv("MSMD_TILE_ZIGZAG"); return e ? atoi(e) : 0; }();
   MSMD_LAUNCH(finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, nbr, kernel_volume, n,
-              w.sorted, w.tile_seq, full > 1 ? full : 0, rows_per_tile, zigzag, order, tiled);
+              w.sorted, w.tile_seq, full > 1 && lpt ? full : 0, rows_per_tile, zigzag, order, tiled);
   return launch_status();
 }
 

@@ -2,6 +2,8 @@
 against the CPU oracle on the same seeded inputs.  Integer results (voxel
 indices, rulebooks, set operations, FPS / ball query) must match bit for bit;
 fp32 features within 1e-4 (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -805,7 +807,9 @@ def test_sparse_add_index_then_rows_equals_fused(dev):
 def test_rulebook_tiling_one_call(dev, n, kvol):
     """msmd_rulebook_tiling against row_mask_order + permute_cols (the torch-side
     route): a permutation of the rows, the table in that order, and tiles that cost
-    the same (ties between equal keys may be broken differently)."""
+    the same (ties between equal keys may be broken differently).  The one-call tiling
+    keeps the tiles in mask order (stream-K balances them wherever they lie); the
+    heaviest-first re-sequencing of whole tiles is MSMD_TILE_LPT=1 / tile_lpt=True."""
     from msmdfusion_amd import kernels as K
     g = torch.Generator().manual_seed(n + kvol)
     nbr = torch.where(torch.rand(kvol, n, generator=g) < 0.35,
@@ -813,7 +817,7 @@ def test_rulebook_tiling_one_call(dev, n, kvol):
     order, tiled = K.rulebook_tiling(nbr)
     assert sorted(order.cpu().tolist()) == list(range(n))
     assert torch.equal(tiled, K.permute_cols(nbr, order))
-    ref = K.row_mask_order(nbr)
+    ref = K.row_mask_order(nbr, tile_lpt=os.environ.get("MSMD_TILE_LPT", "0") == "1")
 
     def unions(o):      # offsets each 128-row tile walks
         m = (nbr[:, o.long()] >= 0)

@@ -50,7 +50,7 @@ def main():
             g[1] += v[1]
         print("   by group: " + ", ".join("%s %.2f ms/%d" % (g, v[1] / steps / 1e3, round(v[0] / steps))
                                           for g, v in sorted(groups.items(), key=lambda kv: -kv[1][1])))
-        for k, v in sorted(ks.items(), key=lambda kv: -kv[1][1])[:top if q == main_q else 8]:
+        for k, v in sorted(ks.items(), key=lambda kv: -kv[1][1])[:top]:
             print("   %-70s %6.1f /step %8.1f us avg %7.3f ms/step" % (
                 k[:70], v[0] / steps, v[1] / v[0], v[1] / steps / 1e3))
 
