@@ -306,12 +306,22 @@ def _cpu_baseline(workload, seed, budget_s, max_samples):
     else:
         what = ("voxelize + all rulebooks + 21 sparse convs fwd+dgrad+wgrad; %.1f GMAC fwd; ~%.1fk "
                 "pts -> ~%.1fk voxels" % (r["gmac_fwd"], r["points"] / 1e3, r["voxels"] / 1e3))
+    # the conv part through the reference's own compiled CPU code, beside the port
+    ref = None
+    try:
+        torch.set_num_threads(cores)
+        ref = B.reference_conv_leg(seed)
+    except Exception as e:     # the leg is a report, never a reason to lose the line
+        ref = dict(error=repr(e)[:200])
     return dict(value=round(len(timed) / secs, 4), unit="samples/s", cores=cores, kind="port",
+                reference_conv=ref if ref is not None else
+                "oracle/_ref/libmsmd_ref.so (the reference's gather / torch::mm / scatter-add "
+                "loop, built from /root/reference by oracle/Makefile) is not on this box",
                 sample="%d synthetic samples (seeds %d..%d, first one untimed warm-up), each: %s; "
                        "oracle/msmd_oracle.c restatement of the reference CPU path, OpenMP %d "
-                       "threads; BN/ReLU/optimizer skipped (elementwise); the real reference loop "
-                       "(torch::mm per offset + index_add) is slower than this port; %.1f s of CPU "
-                       "work, %.2f s per sample"
+                       "threads; BN/ReLU/optimizer skipped (elementwise); reference_conv = the conv "
+                       "part alone through the reference's compiled gather / torch::mm / scatter "
+                       "loop beside the port; %.1f s of CPU work, %.2f s per sample"
                        % (len(timed), seed + (1 if len(runs) > 1 else 0), seed + len(runs) - 1,
                           what, cores, secs, secs / len(timed)))
 
@@ -467,7 +477,10 @@ def main():
         out = {"metric": WORKLOADS[args.workload]["metric"], "value": head["value"],
                "unit": head["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None,
+               "dtype": "f32 via 3xbf16 split MFMA (each fp32 operand = exact sum of 3 bf16 planes, 6 "
+                        "products, fp32 accumulate; fp32 storage)",
+               "data": "synthetic",
                "rccl_ranks": D.rccl_ranks(), "config": head["config"],
                "roofline": head["roofline"]}
         if world == 1 and not args.no_cpu_baseline:

@@ -275,9 +275,14 @@ int msmd_rulebook_tile_prefix(const int32_t* nbr /* [K,ld] */, int kernel_volume
                               int n_rows, int rows_per_tile,
                               int32_t* prefix /* [n_tiles + 1] */, msmd_stream_t stream);
 
-/* wgrad with the same operand splitting (both operands are read as fp32 and
- * split in registers); c_in, c_out >= 64 and multiples of 4.  Workspace as
- * msmd_spconv_wgrad_workspace_bytes. */
+/* wgrad with the same operand splitting (both operands are read as fp32 and split
+ * into bf16 planes on the way to the matrix cores); c_in, c_out >= 64 and multiples of 4.
+ * Widths that are multiples of 16 take the whole-block kernel (csrc/spconv_wgrad_block.hip:
+ * one workgroup owns up to 128 x 128 channels of an offset, producer waves fetch and split
+ * each pair's rows once, consumer waves only multiply); the others 64 x 64 slabs.
+ * replaces: sparse_conv_ext.indice_conv_backward_fp32's filter-gradient half
+ *           (mmdet3d/ops/spconv/include/spconv/spconv_ops.h:363-456).
+ * Workspace as msmd_spconv_wgrad_workspace_bytes. */
 int msmd_spconv_wgrad_split_supported(int c_in, int c_out);
 
 int msmd_spconv_wgrad_split(const float* in_feat, int c_in, const float* d_out, int c_out,
@@ -287,38 +292,6 @@ int msmd_spconv_wgrad_split(const float* in_feat, int c_in, const float* d_out, 
                             float* d_weight /* [K,c_in,c_out] */,
                             int krsc_out /* != 0: d_weight is [c_out,K,c_in] */,
                             void* workspace, size_t workspace_bytes, msmd_stream_t stream);
-
-/* bf16 PLANE tensors: x[n,c] fp32 -> planes[n+1][planes][c] bf16, row n all zeros
- * ("no pair"); x == sum of its planes exactly for planes = 3 (the split of
- * msmd_spconv_fwd_split, done once per tensor instead of once per gathered row).
- * c % 8 == 0.  No reference counterpart (the reference's GEMMs run on cuBLAS /
- * tensor-core TF32); consumers: msmd_spconv_wgrad_planes. */
-size_t msmd_planes_bytes(int n_rows, int channels, int planes);
-
-int msmd_split_planes_f32(const float* x /* [n_rows,channels] */, int n_rows, int channels,
-                          int planes, void* out /* msmd_planes_bytes */, msmd_stream_t stream);
-
-/* wgrad reading plane tensors: dW[k] = sum_p in[i_p]^T (x) dout[o_p] with both operands
- * gathered by LDS-DMA as bf16 rows and fed to the MFMA through transposing LDS reads
- * (no per-row conversion work).  Same result as msmd_spconv_wgrad_split to the last
- * bits of the fp32 accumulation order; c_in, c_out >= 64 and multiples of 8.
- * replaces: sparse_conv_ext.indice_conv_backward_fp32's filter-gradient half
- *           (spconv_ops.h:363-456 :438).
- * indice_pairs must be sorted by output row within each offset (msmd_rulebook_pairs'
- * order): a workgroup takes the pairs of one 2048-row range of OUTPUT rows, so that the
- * 27 offsets of a range share their rows in one XCD's L2. */
-int msmd_spconv_wgrad_planes_supported(int c_in, int c_out);
-
-size_t msmd_spconv_wgrad_planes_workspace_bytes(int kernel_volume, int n_out, int c_in,
-                                                int c_out);
-
-int msmd_spconv_wgrad_planes(const void* in_planes /* [n_in+1,planes,c_in] bf16 */, int n_in,
-                             int c_in, const void* dout_planes /* [n_out+1,planes,c_out] */,
-                             int n_out, int c_out, const int32_t* indice_pairs /* [K,2,ld] */,
-                             const int32_t* indice_num /* [K] device */, int ld,
-                             int kernel_volume, int planes, float* d_weight,
-                             int krsc_out /* != 0: d_weight is [c_out,K,c_in] */,
-                             void* workspace, size_t workspace_bytes, msmd_stream_t stream);
 
 /* out[k][p] = nbr[k][order[p]] for p < n: the neighbour table in tile order. */
 int msmd_rulebook_permute_cols(const int32_t* nbr, int kernel_volume, int ld, int n,
@@ -680,18 +653,6 @@ int msmd_gaussian_focal_f32(const float* logits, const float* target, int64_t n,
                             float clip, float* grad /* [n] or NULL */,
                             float* sums /* [2] */, void* workspace,
                             size_t workspace_bytes, msmd_stream_t stream);
-
-/* ------------------------------------------------------------------------ *
- * Counts the host waits for (a5/a6/a17 callers): no reference counterpart -- the
- * reference reads such counts with .item() / torch::_unique's implicit sync.
- * Any `int32_t* n_out` / `count` output of this header may point into pinned host
- * memory mapped for the device (hipHostMalloc; msmd_host_device_pointer gives the
- * address to pass); msmd_host_wait_i32 then spins until the producing kernel has
- * replaced `sentinel` in that slot -- no device->host copy, no stream synchronisation.
- * Returns MSMD_ERR_LAUNCH when nothing arrives within timeout_us. */
-int msmd_host_device_pointer(void* host_ptr, void** device_ptr);
-int msmd_host_wait_i32(const int32_t* slot, int32_t sentinel, int64_t timeout_us,
-                       int32_t* value);
 
 #ifdef __cplusplus
 }

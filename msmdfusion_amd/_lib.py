@@ -44,8 +44,6 @@ SIGNATURES = {
     "msmd_voxel_mean": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "msmd_rulebook_subm_workspace_bytes": (_sz, [_i]),
     "msmd_rulebook_subm3d": (_i, [_vp, _i, _i, _ip, _ip, _vp, _vp, _sz, _vp]),
-    "msmd_host_device_pointer": (_i, [_vp, C.POINTER(C.c_void_p)]),
-    "msmd_host_wait_i32": (_i, [_vp, _i, _i64, _ip]),
     "msmd_rulebook_subm_bitmap_workspace_bytes": (_sz, [_i, _i, _ip]),
     "msmd_rulebook_subm3d_bitmap": (_i, [_vp, _i, _i, _ip, _ip, _vp, _vp, _sz, _vp]),
     "msmd_rulebook_conv_workspace_bytes": (_sz, [_i, _ip]),
@@ -77,12 +75,6 @@ SIGNATURES = {
     "msmd_spconv_fwd_split_tile_rows": (_i, [_i]),
     "msmd_spconv_wgrad_split_supported": (_i, [_i, _i]),
     "msmd_spconv_wgrad_split": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
-    "msmd_planes_bytes": (_sz, [_i, _i, _i]),
-    "msmd_split_planes_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "msmd_spconv_wgrad_planes_supported": (_i, [_i, _i]),
-    "msmd_spconv_wgrad_planes_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "msmd_spconv_wgrad_planes": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz,
-                                      _vp]),
     "msmd_rulebook_permute_cols": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "msmd_bn_workspace_bytes": (_sz, [_i, _i]),
     "msmd_bn_act_fwd_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -52,58 +52,6 @@ __device__ __forceinline__ bool wgrad_work(int nchunks, int kvol, int slabs, int
   return chunk < nchunks;
 }
 
-// ---- wgrad work units as ranges of OUTPUT ROWS (spconv_planes.hip, spconv_split.hip) ----
-// ranges[k][c] = first pair of offset k whose output row is >= c * rows (c = 0 .. nchunks);
-// the lists are sorted by output row (msmd_rulebook_pairs).
-static __global__ __launch_bounds__(256) void pair_ranges_kernel(const int32_t* __restrict__ pairs,
-                                                          const int32_t* __restrict__ num, int ld,
-                                                          int kvol, int rows, int nchunks,
-                                                          int32_t* __restrict__ ranges) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= kvol * (nchunks + 1)) return;
-  const int k = e / (nchunks + 1), c = e - k * (nchunks + 1);
-  const int32_t* po = pairs + ((size_t)k * 2 + 1) * ld;
-  const long target = (long)c * rows;
-  int lo = 0, hi = num[k];
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (po[mid] < target) lo = mid + 1; else hi = mid;
-  }
-  ranges[e] = lo;
-}
-
-// dw = sum over the non-empty chunks of the per-(k, chunk) partials, in chunk order
-// (fixed: deterministic); 8 loads in flight per thread.
-static __global__ __launch_bounds__(256) void reduce_ranges_kernel(const float* __restrict__ partial,
-                                                            const int32_t* __restrict__ ranges,
-                                                            int nchunks, int per_k, int cin,
-                                                            int cout, int kvol, int krsc,
-                                                            float* __restrict__ dw) {
-  const int k = blockIdx.y;
-  const int32_t* rg = ranges + (size_t)k * (nchunks + 1);
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < per_k; e += gridDim.x * 256) {
-    const float* src = partial + (size_t)k * nchunks * per_k + e;
-    float s = 0.f;
-    for (int c0 = 0; c0 < nchunks; c0 += 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int c = c0 + u;
-        v[u] = (c < nchunks && rg[c + 1] > rg[c]) ? src[(size_t)c * per_k] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    if (krsc) {  // d_weight is [c_out][K][c_in] (the module's parameter layout)
-      const int ci = e / cout, co = e - ci * cout;
-      dw[((size_t)co * kvol + k) * cin + ci] = s;
-    } else {
-      dw[(size_t)k * per_k + e] = s;
-    }
-  }
-}
-
-
 inline int launch_status() {
   int e = g_launch_err;
   g_launch_err = 0;

@@ -917,9 +917,7 @@ MSMD_EXPORT size_t msmd_spconv_wgrad_workspace_bytes(int kernel_volume, int ld, 
   int chunk = wgrad_chunk(c_in, c_out);
   if (kWgradSplitChunk < chunk) chunk = kWgradSplitChunk;   // serves msmd_spconv_wgrad_split too
   size_t nchunks = (size_t)ceil_div(ld > 0 ? ld : 1, chunk);
-  // + the per-(offset, chunk) pair ranges of the row-range work split (spconv_split.hip)
-  const size_t chunked = align_up(sizeof(float) * kernel_volume * nchunks * c_in * c_out) +
-                         align_up(sizeof(int32_t) * (size_t)kernel_volume * (nchunks + 1));
+  const size_t chunked = align_up(sizeof(float) * kernel_volume * nchunks * c_in * c_out);
   // the whole-block kernel's slots (spconv_wgrad_block.hip): one per workgroup + segment
   const size_t block = wgrad_block_workspace_bytes(kernel_volume, c_in, c_out);
   return chunked > block ? chunked : block;
@@ -997,8 +995,7 @@ MSMD_EXPORT int msmd_spconv_wgrad_f32(const float* in_feat, int c_in, const floa
 namespace msmd {
 int wgrad_split_partials(const float* in_feat, int c_in, const float* d_out, int c_out,
                          const int32_t* pairs, const int32_t* num, int ld, int kvol, int np,
-                         int nchunks, float* ws, int32_t* ranges, hipStream_t st);
-bool wgrad_split_used_ranges();   // whether the last call on this thread took the range path
+                         int nchunks, float* ws, hipStream_t st);
 }
 
 MSMD_EXPORT int msmd_spconv_wgrad_split_supported(int c_in, int c_out) {
@@ -1039,24 +1036,11 @@ MSMD_EXPORT int msmd_spconv_wgrad_split(const float* in_feat, int c_in, const fl
   if (workspace_bytes < sizeof(float) * (size_t)kernel_volume * nchunks * per_k ||
       ((uintptr_t)workspace & 255))
     return MSMD_ERR_WORKSPACE;
-  // work units = ranges of OUTPUT ROWS when the workspace has room for the range table
-  // (msmd_spconv_wgrad_workspace_bytes): all offsets of a chunk then gather the same rows
-  const size_t part_bytes = align_up(sizeof(float) * (size_t)kernel_volume * nchunks * per_k);
-  int32_t* ranges = nullptr;
-  static const int by_rows = env_int("MSMD_WGRAD_ROW_CHUNKS", 0);   // measured: no gain
-  if (by_rows && workspace_bytes >= part_bytes + sizeof(int32_t) * (size_t)kernel_volume * (nchunks + 1))
-    ranges = (int32_t*)((char*)workspace + part_bytes);
   int rc = wgrad_split_partials(in_feat, c_in, d_out, c_out, indice_pairs, indice_num, ld,
-                                kernel_volume, planes, nchunks, (float*)workspace, ranges, st);
+                                kernel_volume, planes, nchunks, (float*)workspace, st);
   if (rc != MSMD_OK) return rc;
   int rb = ceil_div(per_k, 256);
   if (rb > 64) rb = 64;
-  if (rc == MSMD_OK && ranges && wgrad_split_used_ranges()) {
-    MSMD_LAUNCH(reduce_ranges_kernel, dim3(rb, kernel_volume), dim3(256), 0, st,
-                (const float*)workspace, (const int32_t*)ranges, nchunks, per_k, c_in, c_out,
-                kernel_volume, krsc_out, d_weight);
-    return launch_status();
-  }
   MSMD_LAUNCH(wgrad_reduce_kernel, dim3(rb, kernel_volume), dim3(256), 0, st,
               (const float*)workspace, indice_num, nchunks, per_k, c_in, c_out, kernel_volume,
               krsc_out, chunk, d_weight);

@@ -1046,356 +1046,25 @@ __global__ __launch_bounds__(1024) void tile_prefix_kernel(int32_t* __restrict__
 }
 
 // ------------------------------------------------------------------ wgrad --
-// dW[k] = sum_p in[i_p,:]^T (x) dout[o_p,:] with the pair index as the MFMA's
-// contraction (32 pairs per v_mfma_f32_16x16x32_bf16).  Same decomposition as
-// spconv_wgrad_kernel (spconv.hip): workgroup = (2048-pair chunk, offset k,
-// 64x64 channel slab), its 4 waves take interleaved 32-pair steps, partials are
-// reduced by wgrad_reduce in fixed order.
+// dW[k] = sum_p in[i_p,:]^T (x) dout[o_p,:] with the pair index as the MFMA's contraction
+// (32 pairs per v_mfma_f32_16x16x32_bf16).  The whole-block kernel of
+// spconv_wgrad_block.hip takes every layer whose widths are multiples of 16; what is left
+// here is the 64 x 64 SLAB kernel for the other widths (multiples of 4): workgroup =
+// (2048-pair chunk, offset k, channel slab), its 4 waves take interleaved 32-pair steps,
+// partials are reduced by wgrad_reduce (spconv.hip) in fixed order.
 //
-// Operands: lane (i, g) covers pairs 8g .. 8g+7 of the step and, on each side,
-// channels 4i .. 4i+3 of the slab: ONE 16-byte load per pair per side.  The
-// MFMA wants 8 consecutive contraction slots of ONE channel per lane -- i.e. the
-// 8x4 block the lane just loaded, transposed -- and v_cvt_pk_bf16_f32 takes its
-// two inputs from two registers: converting (pair 2t, pair 2t+1) of channel a
-// together yields dword t of tile a's operand directly (tile a, row i <->
-// channel 4i + a, as in the fp32 kernel).  The transposition is free; the split
-// into planes costs 9 VALU ops per operand dword.
-template <int NP>
-__global__ __launch_bounds__(256, 2) void spconv_wgrad_split_kernel(
-    const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
-    const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
-    int kvol, float* __restrict__ partial /* [K][nchunks][cin][cout] */) {
-  constexpr int CHUNK = kWgradSplitChunk, S = 4;
-  using P = Products<NP>;
-  __shared__ __attribute__((aligned(16))) char lds_raw[2 * S * S * 64 * sizeof(f32x4)];
-  int* s_in = (int*)lds_raw;
-  int* s_out = s_in + CHUNK;
-  f32x4* red = (f32x4*)lds_raw;
-  static_assert(2 * CHUNK * sizeof(int) <= sizeof(lds_raw), "index arrays must fit");
-  const int NTs = (cout + 63) / 64;   // slabs may be partial: c_in, c_out % 4 == 0
-  int k, chunk, slab;
-  if (!wgrad_work(nchunks, kvol, ((cin + 63) / 64) * NTs, chunk, k, slab)) return;
-  const int Pk = num[k];
-  const int p_begin = chunk * CHUNK;
-  if (p_begin >= Pk) return;
-  const int cnt = (Pk - p_begin) < CHUNK ? (Pk - p_begin) : CHUNK;
-  const int sa = slab / NTs, sb = slab % NTs;
-  const int a0 = sa * 64, b0 = sb * 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 15, g = lane >> 4;
-  {
-    const int32_t* pin = pairs + ((size_t)k * 2 + 0) * ld + p_begin;
-    const int32_t* pout = pairs + ((size_t)k * 2 + 1) * ld + p_begin;
-    for (int e = threadIdx.x; e < CHUNK; e += 256) {   // pad with -1: "no pair"
-      s_in[e] = e < cnt ? pin[e] : -1;
-      s_out[e] = e < cnt ? pout[e] : -1;
-    }
-  }
-  __syncthreads();
-
-  f32x4 acc[S][S];
-#pragma unroll
-  for (int a = 0; a < S; ++a)
-#pragma unroll
-    for (int b = 0; b < S; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const float* pa = in + a0 + 4 * i;
-  const float* pb = dout + b0 + 4 * i;
-  const bool in_a = a0 + 4 * i < cin, in_b = b0 + 4 * i < cout;   // this lane's channels exist
-  f32x4 ra[8], rb[8];   // this lane's 8 pairs x 4 channels, both sides
-  auto fetch = [&](int step) {
-    const int e0 = 32 * step + 8 * g;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const i32x4 ia = *(const i32x4*)(s_in + e0 + 4 * h), ib = *(const i32x4*)(s_out + e0 + 4 * h);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        ra[4 * h + s] = (ia[s] >= 0 && in_a) ? *(const f32x4*)(pa + (size_t)ia[s] * cin)
-                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
-        rb[4 * h + s] = (ib[s] >= 0 && in_b) ? *(const f32x4*)(pb + (size_t)ib[s] * cout)
-                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-    }
-  };
-  // raw [8 pairs][4 channels] -> op[tile = channel][plane] (8 slots each)
-  auto split_side = [&](const f32x4 (&r)[8], u32x4 (&op)[S][NP]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int a = 0; a < S; ++a) {
-        const f32x4 lo4 = r[2 * t], hi4 = r[2 * t + 1];
-        f32x2 v = {lo4[a], hi4[a]};
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-          const bf16x2 hi = __builtin_convertvector(v, bf16x2);
-          op[a][pl][t] = __builtin_bit_cast(unsigned int, hi);
-          if (pl + 1 < NP) v = v - __builtin_convertvector(hi, f32x2);   // exact
-        }
-      }
-  };
-  const int n_steps = (cnt + 31) / 32;
-  if (wave < n_steps) fetch(wave);
-  for (int step = wave; step < n_steps; step += 4) {
-    u32x4 oa[S][NP], ob[S][NP];
-    split_side(ra, oa);
-    split_side(rb, ob);
-    if (step + 4 < n_steps) fetch(step + 4);   // in flight under the MFMAs below
-#pragma unroll
-    for (int t = 0; t < P::n; ++t)
-#pragma unroll
-      for (int a = 0; a < S; ++a)
-#pragma unroll
-        for (int b = 0; b < S; ++b)
-          acc[a][b] = mfma_bf16(oa[a][P::a[t]], ob[b][P::b[t]], acc[a][b]);
-  }
-  // cross-wave sum, fixed tree order (w0+w2) + (w1+w3): deterministic
-  __syncthreads();   // everyone is done with the index arrays (red aliases them)
-  if (wave >= 2) {
-#pragma unroll
-    for (int a = 0; a < S; ++a)
-#pragma unroll
-      for (int b = 0; b < S; ++b) red[((wave - 2) * S * S + a * S + b) * 64 + lane] = acc[a][b];
-  }
-  __syncthreads();
-  if (wave < 2) {
-#pragma unroll
-    for (int a = 0; a < S; ++a)
-#pragma unroll
-      for (int b = 0; b < S; ++b) acc[a][b] += red[(wave * S * S + a * S + b) * 64 + lane];
-  }
-  __syncthreads();
-  if (wave == 1) {
-#pragma unroll
-    for (int a = 0; a < S; ++a)
-#pragma unroll
-      for (int b = 0; b < S; ++b) red[(a * S + b) * 64 + lane] = acc[a][b];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float* dst = partial + ((size_t)k * nchunks + chunk) * cin * cout;
-    const int cb = b0 + 4 * i;
-#pragma unroll
-    for (int a = 0; a < S; ++a) {
-      f32x4 v[S];
-#pragma unroll
-      for (int b = 0; b < S; ++b) v[b] = acc[a][b] + red[(a * S + b) * 64 + lane];
-      // D of tile (a,b): lane (col n = i, g) reg r -> ci = a0 + 4(4g+r) + a, co = b0 + 4n + b
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ci = a0 + 4 * (4 * g + r) + a;
-        if (ci < cin && cb < cout)
-          *(f32x4*)(dst + (size_t)ci * cout + cb) = (f32x4){v[0][r], v[1][r], v[2][r], v[3][r]};
-      }
-    }
-  }
-}
-
-
-// The same kernel with a lean instruction stream (round 2).  The version above spends, per
-// 32-pair step and wave, 96 MFMAs against ~1000 other instructions: 58 branches and 440
-// register moves around its predicated 64-bit-address loads (zero rows for "no pair"),
-// 120 address operations, packed-fp32 residual subtractions.  Here the rows come through a
-// raw buffer descriptor with 32-bit byte offsets -- an absent pair or channel is an
-// out-of-range offset, which loads zeros without a branch, a move or any traffic -- and the
-// residuals are scalar subtractions (a v_pk_add_f32 beside MFMAs costs more than the two
-// v_sub_f32 it replaces, MI355X_MICROARCH.md).  Same operands, same products, same sums:
-// bit-identical partials.  Needs rows * channels * 4 < 4 GiB on both sides (32-bit offsets);
-// larger tensors take the pointer version.
-template <int NP, int GA>   // GA = 64-channel groups of c_in per slab (slab = 64*GA x 64)
-__global__ __launch_bounds__(256, GA == 1 ? 2 : 1) void spconv_wgrad_split_buf_kernel(
-    const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
-    const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
-    int kvol, float* __restrict__ partial /* [K][nchunks][cin][cout] */,
-    const int32_t* __restrict__ ranges /* [K][nchunks+1] or null: chunks of pair positions */,
-    int dbg /* ablations, wrong results: 1 rows folded onto 4096, 2 no loads, 4 no MFMAs;
-               8 = no priority raise around the MFMA burst (results unchanged) */) {
-  const bool prio = !(dbg & 8);
-  constexpr int CHUNK = kWgradSplitChunk, S = 4, TA = S * GA;
-  using P = Products<NP>;
-  __shared__ __attribute__((aligned(16))) char lds_raw[2 * TA * S * 64 * sizeof(f32x4)];
-  unsigned* s_in = (unsigned*)lds_raw;       // BYTE OFFSETS of the rows (or the OOB offset)
-  unsigned* s_out = s_in + CHUNK;
-  f32x4* red = (f32x4*)lds_raw;
-  static_assert(2 * CHUNK * sizeof(int) <= sizeof(lds_raw), "index arrays must fit");
-  const int NTs = (cout + 63) / 64;
-  int k, chunk, slab;
-  if (!wgrad_work(nchunks, kvol, ((cin + 64 * GA - 1) / (64 * GA)) * NTs, chunk, k, slab)) return;
-  int p_begin, cnt;
-  if (ranges) {     // the pairs of offset k whose OUTPUT row lies in chunk's row range
-    p_begin = ranges[(size_t)k * (nchunks + 1) + chunk];
-    cnt = ranges[(size_t)k * (nchunks + 1) + chunk + 1] - p_begin;   // <= CHUNK rows
-    if (cnt <= 0) return;                                            // (the reduction skips it)
-  } else {
-    const int Pk = num[k];
-    p_begin = chunk * CHUNK;
-    if (p_begin >= Pk) return;
-    cnt = (Pk - p_begin) < CHUNK ? (Pk - p_begin) : CHUNK;
-  }
-  const int sa = slab / NTs, sb = slab % NTs;
-  const int a0 = sa * 64 * GA, b0 = sb * 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 15, g = lane >> 4;
-  {
-    const int32_t* pin = pairs + ((size_t)k * 2 + 0) * ld + p_begin;
-    const int32_t* pout = pairs + ((size_t)k * 2 + 1) * ld + p_begin;
-    const unsigned rowa = (unsigned)cin * 4u, rowb = (unsigned)cout * 4u;
-    for (int e = threadIdx.x; e < CHUNK; e += 256) {   // past the end: "no pair"
-      int ia = e < cnt ? pin[e] : -1, ib = e < cnt ? pout[e] : -1;
-      if (dbg & 1) { ia = ia < 0 ? ia : (ia & 4095); ib = ib < 0 ? ib : (ib & 4095); }
-      if (dbg & 2) { ia = -1; ib = -1; }
-      s_in[e] = ia >= 0 ? (unsigned)ia * rowa : kOobOffset;
-      s_out[e] = ib >= 0 ? (unsigned)ib * rowb : kOobOffset;
-    }
-  }
-  __syncthreads();
-  const __amdgpu_buffer_rsrc_t rs_a =
-      __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)kOobOffset, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b =
-      __builtin_amdgcn_make_buffer_rsrc((void*)dout, 0, (int)kOobOffset, 0x00020000);
-  // this lane's channel offsets inside a row; lanes whose channels do not exist (partial
-  // slab) read out of range too (the sentinel is applied AFTER the add, so it cannot wrap
-  // back into range)
-  unsigned cola[GA];
-  bool in_a[GA];
-#pragma unroll
-  for (int ga = 0; ga < GA; ++ga) {
-    cola[ga] = (unsigned)(a0 + 64 * ga + 4 * i) * 4u;
-    in_a[ga] = a0 + 64 * ga + 4 * i < cin;
-  }
-  const unsigned colb = (unsigned)(b0 + 4 * i) * 4u;
-  const bool in_b = b0 + 4 * i < cout;
-
-  f32x4 acc[TA][S];
-#pragma unroll
-  for (int a = 0; a < TA; ++a)
-#pragma unroll
-    for (int b = 0; b < S; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  u32x4 ra[GA][8], rb[8];   // this lane's 8 pairs x 4 channels per group (fp32 bits)
-  auto fetch = [&](int step) {
-    const int e0 = 32 * step + 8 * g;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const u32x4 oa4 = *(const u32x4*)(s_in + e0 + 4 * h), ob4 = *(const u32x4*)(s_out + e0 + 4 * h);
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-#pragma unroll
-        for (int ga = 0; ga < GA; ++ga) {
-          const unsigned fa =
-              (oa4[s2] == kOobOffset || !in_a[ga]) ? kOobOffset : oa4[s2] + cola[ga];
-          ra[ga][4 * h + s2] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)fa, 0, 0);
-        }
-        const unsigned fb = (ob4[s2] == kOobOffset || !in_b) ? kOobOffset : ob4[s2] + colb;
-        rb[4 * h + s2] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)fb, 0, 0);
-      }
-    }
-  };
-  // raw [8 pairs][4 channels] -> op[tile = channel][plane] (8 slots each); the planes of
-  // (pair 2t, pair 2t+1) of one channel are dword t of that channel's operand
-  auto split_side = [&](const u32x4 (&r)[8], u32x4 (*op)[NP]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int a = 0; a < S; ++a) {
-        float v0 = __uint_as_float(r[2 * t][a]), v1 = __uint_as_float(r[2 * t + 1][a]);
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-          unsigned hi;    // (asm: the builtin conversion first copies its inputs into a pair)
-          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
-          op[a][pl][t] = hi;
-          if (pl + 1 < NP) {          // exact residuals; scalar on purpose (one v_pk_add_f32
-            v0 = v0 - __uint_as_float(hi << 16);          // measured slower than these two:
-            v1 = v1 - __uint_as_float(hi & 0xffff0000u);  // 404 against 370 us at 128x128)
-          }
-        }
-      }
-  };
-  const int n_steps = (cnt + 31) / 32;
-  if (wave < n_steps) fetch(wave);
-  for (int step = wave; step < n_steps; step += 4) {
-    u32x4 oa[TA][NP], ob[S][NP];
-#pragma unroll
-    for (int ga = 0; ga < GA; ++ga) split_side(ra[ga], oa + S * ga);
-    split_side(rb, ob);
-    if (step + 4 < n_steps) fetch(step + 4);   // in flight under the MFMAs below
-    if (dbg & 4) {   // keep the operands alive without multiplying
-#pragma unroll
-      for (int a = 0; a < TA; ++a)
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) asm volatile("" ::"v"(oa[a][pl]));
-#pragma unroll
-      for (int b = 0; b < S; ++b)
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) asm volatile("" ::"v"(ob[b][pl]));
-      continue;
-    }
-    // The conversion phase (VALU only) and this phase (MFMA only) of ONE wave cannot
-    // overlap, but the SIMD's other wave is free to convert while this one multiplies -- if
-    // the two are out of phase.  Raised priority for the MFMA burst makes that the stable
-    // state: the multiplying wave issues at full rate, the converting one takes the 12 of 16
-    // cycles each MFMA leaves the issue port idle.
-    if (prio) __builtin_amdgcn_s_setprio(2);
-#pragma unroll
-    for (int t = 0; t < P::n; ++t)
-#pragma unroll
-      for (int a = 0; a < TA; ++a)
-#pragma unroll
-        for (int b = 0; b < S; ++b)
-          acc[a][b] = mfma_bf16(oa[a][P::a[t]], ob[b][P::b[t]], acc[a][b]);
-    if (prio) __builtin_amdgcn_s_setprio(0);
-  }
-  // cross-wave sum, fixed tree order (w0+w2) + (w1+w3): deterministic
-  __syncthreads();   // everyone is done with the index arrays (red aliases them)
-  if (wave >= 2) {
-#pragma unroll
-    for (int a = 0; a < TA; ++a)
-#pragma unroll
-      for (int b = 0; b < S; ++b) red[((wave - 2) * TA * S + a * S + b) * 64 + lane] = acc[a][b];
-  }
-  __syncthreads();
-  if (wave < 2) {
-#pragma unroll
-    for (int a = 0; a < TA; ++a)
-#pragma unroll
-      for (int b = 0; b < S; ++b) acc[a][b] += red[(wave * TA * S + a * S + b) * 64 + lane];
-  }
-  __syncthreads();
-  if (wave == 1) {
-#pragma unroll
-    for (int a = 0; a < TA; ++a)
-#pragma unroll
-      for (int b = 0; b < S; ++b) red[(a * S + b) * 64 + lane] = acc[a][b];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float* dst = partial + ((size_t)k * nchunks + chunk) * cin * cout;
-    const int cb = b0 + 4 * i;
-#pragma unroll
-    for (int a = 0; a < TA; ++a) {
-      f32x4 v[S];
-#pragma unroll
-      for (int b = 0; b < S; ++b) v[b] = acc[a][b] + red[(a * S + b) * 64 + lane];
-      // tile a = 4*ga + ch: row 4g+r of the tile <-> channel a0 + 64*ga + 4*(4g+r) + ch
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ci = a0 + 64 * (a / S) + 4 * (4 * g + r) + (a % S);
-        if (ci < cin && cb < cout)
-          *(f32x4*)(dst + (size_t)ci * cout + cb) = (f32x4){v[0][r], v[1][r], v[2][r], v[3][r]};
-      }
-    }
-  }
-}
-
-
-// The lean kernel with slabs as wide as the layer needs (round 2, late).  Above, a lane
-// always carries 4 channels of its side, so a slab is 64 x 64 and an 80- or 96-wide layer
-// (the LC fusion blocks: 80, 96, 128, 192) runs 2 x 2 slabs of which three are mostly
-// zeros -- 64 MFMA tiles for 25 (80 x 80) or 36 (96 x 96) tiles of work, and the conversion
-// work likewise.  Here the lanes of a REMAINDER slab carry W = 1 (16 channels left) or W = 2
-// (32 left) channels each (b32 / b64 loads: the 16 lanes of a pair still read one contiguous
-// 64 / 128-byte piece), which makes the slab W tiles wide on that side: 80 x 80 = slabs of
-// 16 + 4 + 4 + 1 tiles.  Same operands, same products, same per-slab sums as the kernel
-// above: bit-identical partials.  One launch; the slab shape is uniform per workgroup.
+// Operands: lane (i, g) covers pairs 8g .. 8g+7 of the step and, on each side, W consecutive
+// channels of the slab: ONE load per pair per side through a raw buffer descriptor with
+// 32-bit byte offsets staged in LDS (an absent pair or channel is an out-of-range offset:
+// zeros, no branch, no traffic).  The MFMA wants 8 consecutive contraction slots of ONE
+// channel per lane -- the block the lane just loaded, transposed -- and v_cvt_pk_bf16_f32
+// takes its two inputs from two registers: converting (pair 2t, pair 2t+1) of channel a
+// together yields dword t of tile a's operand directly (tile a, row i <-> channel W i + a).
+// Slabs are as wide as the layer's remainder needs: a remainder of 16 or 32 channels is 1
+// or 2 tiles wide on that side (80 x 80 = 16 + 4 + 4 + 1 tiles instead of 4 x 16).
+// History (all measured, all removed in round 3): the pointer-addressed
+// first version, 128 x 64 slabs, a 128 x 128 slab with the conversion shared through LDS by
+// all four waves, and pre-split bf16 plane tensors gathered by LDS-DMA.
 template <int NP, int WA, int WB>
 __device__ __forceinline__ void wgrad_var_body(
     const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
@@ -1598,180 +1267,6 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad_split_var_kernel(
 }
 
 
-// wgrad, 128 x 128 slabs with the operand conversion SHARED through LDS (round 2).
-// Ablating the lean kernel above (MSMD_WGRAD_DBG) shows its conversion phase alone is 52 %
-// of its time and adds to -- does not overlap with -- the MFMA phase: with 64 x 64 slabs
-// every wave converts 64 + 64 channels for 96 MFMAs, and each row of a 128-wide layer is
-// converted 2 x 27 times.  Here a workgroup owns a 128 x 128 slab and ALL four waves work on
-// the same 32-pair step: wave w gathers and converts ONE 64-channel unit (w = 0,1: the two
-// halves of c_in, w = 2,3: of c_out) and writes it to LDS in MFMA operand order (the lane's
-// own 16-byte operand pieces: lane-linear, conflict-free, no transposition); every wave
-// then reads the A unit and the B unit of its 64 x 64 quadrant.  Conversion work per MFMA
-// halves, and because it is independent of the current step's MFMAs it is interleaved with
-// them in program order (one MFMA, two conversion ops in its shadow): the conversion of step
-// s+1 and its LDS writes run under the MFMAs of step s.  Two barriers per step; two
-// workgroups per CU (64 KiB LDS each) fill each other's gaps.  Quadrants are disjoint: no
-// cross-wave reduction; partials and the final reduction as before.
-template <int NP>
-__global__ __launch_bounds__(256, 2) void spconv_wgrad_split_shared_kernel(
-    const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
-    const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int ld, int nchunks,
-    int kvol, float* __restrict__ partial /* [K][nchunks][cin][cout] */, int dbg) {
-  constexpr int CHUNK = kWgradSplitChunk, S = 4;
-  using P = Products<NP>;
-  __shared__ __attribute__((aligned(16))) char lds_raw[2 * CHUNK * sizeof(int) +
-                                                       4 * S * NP * 64 * sizeof(u32x4)];
-  unsigned* s_in = (unsigned*)lds_raw;       // BYTE OFFSETS of the rows (or the OOB offset)
-  unsigned* s_out = s_in + CHUNK;
-  u32x4* xch = (u32x4*)(lds_raw + 2 * CHUNK * sizeof(int));   // [unit][tile][plane][lane]
-  const int NB = (cout + 127) / 128;
-  int k, chunk, slab;
-  if (!wgrad_work(nchunks, kvol, ((cin + 127) / 128) * NB, chunk, k, slab)) return;
-  const int Pk = num[k];
-  const int p_begin = chunk * CHUNK;
-  if (p_begin >= Pk) return;
-  const int cnt = (Pk - p_begin) < CHUNK ? (Pk - p_begin) : CHUNK;
-  const int a0 = (slab / NB) * 128, b0 = (slab % NB) * 128;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i = lane & 15, g = lane >> 4;
-  {
-    const int32_t* pin = pairs + ((size_t)k * 2 + 0) * ld + p_begin;
-    const int32_t* pout = pairs + ((size_t)k * 2 + 1) * ld + p_begin;
-    const unsigned rowa = (unsigned)cin * 4u, rowb = (unsigned)cout * 4u;
-    for (int e = threadIdx.x; e < CHUNK; e += 256) {   // past the end: "no pair"
-      int ia = e < cnt ? pin[e] : -1, ib = e < cnt ? pout[e] : -1;
-      if (dbg & 1) { ia = ia < 0 ? ia : (ia & 4095); ib = ib < 0 ? ib : (ib & 4095); }
-      if (dbg & 2) { ia = -1; ib = -1; }
-      s_in[e] = ia >= 0 ? (unsigned)ia * rowa : kOobOffset;
-      s_out[e] = ib >= 0 ? (unsigned)ib * rowb : kOobOffset;
-    }
-  }
-  __syncthreads();
-  // converter role: unit = wave (0,1: halves of c_in; 2,3: halves of c_out)
-  const int side = wave >> 1, half = wave & 1;
-  const unsigned* s_off = side ? s_out : s_in;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(side ? dout : in), 0, (int)kOobOffset, 0x00020000);
-  const int c0 = (side ? b0 : a0) + 64 * half + 4 * i;
-  const bool in_c = c0 < (side ? cout : cin);
-  const unsigned col = (unsigned)c0 * 4u;
-  u32x4* xw = xch + (size_t)wave * S * NP * 64 + lane;
-  // multiplier role: quadrant (qa, qb)
-  const int qa = wave & 1, qb = wave >> 1;
-  const u32x4* xa = xch + (size_t)qa * S * NP * 64 + lane;
-  const u32x4* xb = xch + (size_t)(2 + qb) * S * NP * 64 + lane;
-  // an all-padding quadrant (partial last slab) has nothing to multiply
-  const bool live = a0 + 64 * qa < cin && b0 + 64 * qb < cout;
-  const bool mul = live && !(dbg & 4);
-
-  f32x4 acc[S][S];
-#pragma unroll
-  for (int a = 0; a < S; ++a)
-#pragma unroll
-    for (int b = 0; b < S; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  auto fetch = [&](u32x4 (&r)[8], int step) {
-    const int e0 = 32 * step + 8 * g;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const u32x4 o4 = *(const u32x4*)(s_off + e0 + 4 * h);
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        const unsigned f = (o4[s2] == kOobOffset || !in_c) ? kOobOffset : o4[s2] + col;
-        r[4 * h + s2] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)f, 0, 0);
-      }
-    }
-  };
-  // raw [8 pairs][4 channels] -> the unit's operands, written to LDS as they are produced
-  // (channel a = tile a; (pair 2t, 2t+1) = dword t; 16 bytes per (tile, plane))
-  auto convert_write = [&](const u32x4 (&r)[8]) {
-#pragma unroll
-    for (int a = 0; a < S; ++a) {
-      u32x4 op[NP];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float v0 = __uint_as_float(r[2 * t][a]), v1 = __uint_as_float(r[2 * t + 1][a]);
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-          unsigned hi;
-          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
-          op[pl][t] = hi;
-          if (pl + 1 < NP) {          // exact residuals, scalar on purpose
-            v0 = v0 - __uint_as_float(hi << 16);
-            v1 = v1 - __uint_as_float(hi & 0xffff0000u);
-          }
-        }
-      }
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) xw[(a * NP + pl) * 64] = op[pl];
-    }
-  };
-  u32x4 oa[S][NP], ob[S][NP];
-  auto read_ops = [&]() {
-#pragma unroll
-    for (int a = 0; a < S; ++a)
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) {
-        oa[a][pl] = xa[(a * NP + pl) * 64];
-        ob[a][pl] = xb[(a * NP + pl) * 64];
-      }
-  };
-  const int n_steps = (cnt + 31) / 32;
-  u32x4 raw0[8], raw1[8];
-  // prologue: step 0 converted and published; steps 1 and 2 in flight
-  fetch(raw0, 0);
-  if (1 < n_steps) fetch(raw1, 1);
-  convert_write(raw0);
-  if (2 < n_steps) fetch(raw0, 2);
-  __syncthreads();
-  read_ops();
-  // one step: MFMAs of step s from (oa, ob), under them the conversion of step s+1 (from
-  // `cur`) into LDS; then the load of step s+3 into the buffer just consumed
-  auto step_body = [&](int s, u32x4 (&cur)[8]) {
-    __syncthreads();              // everyone holds step s in registers: LDS may be rewritten
-    const bool more = s + 1 < n_steps;
-    auto multiply = [&]() {
-#pragma unroll
-      for (int t = 0; t < P::n; ++t)
-#pragma unroll
-        for (int a = 0; a < S; ++a)
-#pragma unroll
-          for (int b = 0; b < S; ++b)
-            acc[a][b] = mfma_bf16(oa[a][P::a[t]], ob[b][P::b[t]], acc[a][b]);
-    };
-    // (Interleaving the two in program order -- one MFMA, two conversion ops, via
-    // sched_group_barrier in a common basic block -- was tried: the forced order
-    // stretches the live ranges to 464 spilled registers.  Left to the hardware: the other
-    // workgroup's wave on this SIMD converts while this one multiplies.)
-    if (more) convert_write(cur);
-    if (mul) multiply();
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 3 < n_steps) fetch(cur, s + 3);
-    __syncthreads();              // step s+1 is published
-    if (more) read_ops();
-  };
-  for (int s = 0; s < n_steps; s += 2) {
-    step_body(s, raw1);
-    if (s + 1 < n_steps) step_body(s + 1, raw0);
-  }
-  if (live) {
-    float* dst = partial + ((size_t)k * nchunks + chunk) * cin * cout;
-    const int cb = b0 + 64 * qb + 4 * i;
-#pragma unroll
-    for (int a = 0; a < S; ++a) {
-      // D of tile (a,b): lane (col n = i, g) reg r -> ci = 4(4g+r) + a, co = 4n + b
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ci = a0 + 64 * qa + 4 * (4 * g + r) + a;
-        if (ci < cin && cb < cout)
-          *(f32x4*)(dst + (size_t)ci * cout + cb) =
-              (f32x4){acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
-      }
-    }
-  }
-}
-
 }  // namespace
 }  // namespace msmd
 
@@ -1890,80 +1385,23 @@ MSMD_EXPORT int msmd_rulebook_permute_cols(const int32_t* nbr, int kvol, int ld,
 // caller finishes with that entry point's reduction (see msmd_spconv_wgrad_split
 // in spconv.hip).
 namespace msmd {
-static thread_local bool g_wgrad_ranges = false;
-bool wgrad_split_used_ranges() { return g_wgrad_ranges; }
 int wgrad_split_partials(const float* in_feat, int c_in, const float* d_out, int c_out,
                          const int32_t* pairs, const int32_t* num, int ld, int kvol, int np,
-                         int nchunks, float* ws, int32_t* ranges, hipStream_t st) {
-  dim3 grid(wgrad_grid(nchunks, kvol, ((c_in + 63) / 64) * ((c_out + 63) / 64)));
-  // 32-bit row offsets (buffer loads) whenever both operands stay below 4 GiB
-  static const int buf_env = env_int2("MSMD_WGRAD_BUF", 1);
-  const bool buf = buf_env && (double)ld * 4.0 * (c_in > c_out ? c_in : c_out) < (double)kOobOffset;
-#define WG_LAUNCH(KERNEL, NPV)                                                                \
-  MSMD_LAUNCH(KERNEL<NPV>, grid, dim3(256), 0, st, in_feat, c_in, d_out, c_out, pairs, num, ld, \
-              nchunks, kvol, ws)
-  // 128 x 64 slabs (one wave per SIMD, accumulators in AGPRs) where c_in allows: the
-  // gathered bytes per MFMA drop by a quarter, and the gather rate is what bounds the kernel
-  static const int wide_env = env_int2("MSMD_WGRAD_WIDE", 0);   // measured slower, see DESIGN 8.2
+                         int nchunks, float* ws, hipStream_t st) {
+  // 32-bit row offsets (buffer loads): both operands must stay below 4 GiB
+  if (!((double)ld * 4.0 * (c_in > c_out ? c_in : c_out) < (double)kOobOffset))
+    return MSMD_ERR_RANGE;
   static const int wdbg = env_int2("MSMD_WGRAD_DBG", 0);
-  const bool wide = buf && wide_env && c_in % 128 == 0;
-  if (wide) grid = dim3(wgrad_grid(nchunks, kvol, (c_in / 128) * ((c_out + 63) / 64)));
-#define WGB_LAUNCH(NPV)                                                                        \
-  do {                                                                                         \
-    if (wide)                                                                                  \
-      MSMD_LAUNCH((spconv_wgrad_split_buf_kernel<NPV, 2>), grid, dim3(256), 0, st, in_feat,    \
-                  c_in, d_out, c_out, pairs, num, ld, nchunks, kvol, ws, (const int32_t*)ranges, wdbg); \
-    else                                                                                       \
-      MSMD_LAUNCH((spconv_wgrad_split_buf_kernel<NPV, 1>), grid, dim3(256), 0, st, in_feat,    \
-                  c_in, d_out, c_out, pairs, num, ld, nchunks, kvol, ws, (const int32_t*)ranges, wdbg); \
-  } while (0)
-  // 128 x 128 slabs with the conversion shared through LDS: both widths multiples of 128
-  static const int shared_env = env_int2("MSMD_WGRAD_SHARED", 0);   // 359 vs 369 us: not worth it
-  if (buf && shared_env && c_in % 128 == 0 && c_out % 128 == 0) {
-    g_wgrad_ranges = false;
-    const dim3 gs(wgrad_grid(nchunks, kvol, (c_in / 128) * (c_out / 128)));
-    if (np == 3)
-      MSMD_LAUNCH(spconv_wgrad_split_shared_kernel<3>, gs, dim3(256), 0, st, in_feat, c_in,
-                  d_out, c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
-    else if (np == 2)
-      MSMD_LAUNCH(spconv_wgrad_split_shared_kernel<2>, gs, dim3(256), 0, st, in_feat, c_in,
-                  d_out, c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
-    else
-      MSMD_LAUNCH(spconv_wgrad_split_shared_kernel<1>, gs, dim3(256), 0, st, in_feat, c_in,
-                  d_out, c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
-    return launch_status();
-  }
-  // slabs as wide as the layer needs (80 = 64 + 16, 96 = 64 + 32): default
-  static const int var_env = env_int2("MSMD_WGRAD_VAR", 1);
-  if (buf && var_env && !wide && !ranges) {
-    g_wgrad_ranges = false;
-    const dim3 gv(wgrad_grid(nchunks, kvol, wgrad_var_slabs(c_in) * wgrad_var_slabs(c_out)));
-    if (np == 3)
-      MSMD_LAUNCH(spconv_wgrad_split_var_kernel<3>, gv, dim3(256), 0, st, in_feat, c_in, d_out,
-                  c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
-    else if (np == 2)
-      MSMD_LAUNCH(spconv_wgrad_split_var_kernel<2>, gv, dim3(256), 0, st, in_feat, c_in, d_out,
-                  c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
-    else
-      MSMD_LAUNCH(spconv_wgrad_split_var_kernel<1>, gv, dim3(256), 0, st, in_feat, c_in, d_out,
-                  c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
-    return launch_status();
-  }
-  g_wgrad_ranges = buf && ranges;
-  if (buf) {
-    if (ranges)
-      MSMD_LAUNCH(pair_ranges_kernel, dim3(ceil_div((long)kvol * (nchunks + 1), 256)), dim3(256),
-                  0, st, pairs, num, ld, kvol, kWgradSplitChunk, nchunks, ranges);
-    if (np == 3) WGB_LAUNCH(3);
-    else if (np == 2) WGB_LAUNCH(2);
-    else WGB_LAUNCH(1);
-  } else {
-    if (np == 3) WG_LAUNCH(spconv_wgrad_split_kernel, 3);
-    else if (np == 2) WG_LAUNCH(spconv_wgrad_split_kernel, 2);
-    else WG_LAUNCH(spconv_wgrad_split_kernel, 1);
-  }
-#undef WG_LAUNCH
-#undef WGB_LAUNCH
+  const dim3 gv(wgrad_grid(nchunks, kvol, wgrad_var_slabs(c_in) * wgrad_var_slabs(c_out)));
+  if (np == 3)
+    MSMD_LAUNCH(spconv_wgrad_split_var_kernel<3>, gv, dim3(256), 0, st, in_feat, c_in, d_out,
+                c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
+  else if (np == 2)
+    MSMD_LAUNCH(spconv_wgrad_split_var_kernel<2>, gv, dim3(256), 0, st, in_feat, c_in, d_out,
+                c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
+  else
+    MSMD_LAUNCH(spconv_wgrad_split_var_kernel<1>, gv, dim3(256), 0, st, in_feat, c_in, d_out,
+                c_out, pairs, num, ld, nchunks, kvol, ws, wdbg);
   return launch_status();
 }
 }  // namespace msmd

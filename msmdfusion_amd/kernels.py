@@ -78,61 +78,18 @@ def _ws(nbytes, device):
     return buf
 
 
-# ---- counts the host waits for: written by the kernel into pinned host memory ----------
-# (measured: 134.2-134.3 samples/s with the pinned slots, 134.4 with .item() -- the 0.28 ms a
-# read costs next to the feature pass is the counting kernels' turn on a busy GPU, not the
-# runtime's copy + synchronise; kept as an option, off)
-_HOST_COUNTS = os.environ.get("MSMD_HOST_COUNTS", "0") == "1"
-_COUNT_SENTINEL = -0x7f7f7f7f
-
-
-class _CountSlots(threading.local):
-    """A ring of int32 slots in pinned, device-mapped host memory, one ring per host thread
-    (the step's thread and the index prefetcher's never share a slot)."""
-    SLOTS = 256
-
-    def __init__(self):
-        self.buf = None
-        self.next = 0
-
-    def take(self):
-        if self.buf is None:
-            self.buf = torch.empty((self.SLOTS,), dtype=torch.int32).pin_memory()
-            self.host = self.buf.data_ptr()
-            dev = C.c_void_p()
-            check(lib.msmd_host_device_pointer(C.c_void_p(self.host), C.byref(dev)),
-                  "msmd_host_device_pointer")
-            self.dev = dev.value
-        i = self.next
-        self.next = (i + 1) % self.SLOTS
-        self.buf[i] = _COUNT_SENTINEL
-        return i
-
-
-_COUNT_SLOTS = _CountSlots()
-
-
 class _Count:
-    """Where a counting kernel puts its total, and how the host gets it: a pinned slot the
-    host spins on (MSMD_HOST_COUNTS=1), or a device int read with .item() (default)."""
+    """Where a counting kernel puts its total and how the host gets it: a device int read
+    with .item().  (Round 2 also tried pinned, device-mapped host slots the host spins on:
+    134.2-134.3 against 134.4 samples/s -- what a read costs next to the feature pass is the
+    counting kernels' turn on a busy GPU, not the copy; removed.)"""
 
     def __init__(self, device):
-        if _HOST_COUNTS:
-            self.slot = _COUNT_SLOTS.take()
-            self.ptr = C.c_void_p(_COUNT_SLOTS.dev + 4 * self.slot)
-            self.tensor = None
-        else:
-            self.tensor = torch.empty((1,), dtype=torch.int32, device=device)
-            self.ptr = _p(self.tensor)
+        self.tensor = torch.empty((1,), dtype=torch.int32, device=device)
+        self.ptr = _p(self.tensor)
 
     def read(self):
-        if self.tensor is not None:
-            return int(self.tensor.item())
-        out = C.c_int(0)
-        check(lib.msmd_host_wait_i32(C.c_void_p(_COUNT_SLOTS.host + 4 * self.slot),
-                                     _COUNT_SENTINEL, 20_000_000, C.byref(out)),
-              "msmd_host_wait_i32")
-        return int(out.value)
+        return int(self.tensor.item())
 
 
 def _expand3(v):
@@ -670,45 +627,6 @@ def conv_wgrad_split(feat, d_out, pairs, num, planes=3, krsc_shape=None):
                                       int(planes), _p(dw), int(krsc_shape is not None), _p(ws),
                                       nbytes, _stream()), "msmd_spconv_wgrad_split")
     _prof_end("spconv_wgrad_split", ev, num=num, c_in=c_in, c_out=c_out)
-    return dw
-
-
-# ---------------------------------------------- bf16 plane tensors (split once per tensor)
-def split_planes(x, planes=3):
-    """x [n,c] fp32 -> bf16 planes [n+1, planes, c] (row n = zeros); x == planes.sum(1)
-    exactly for planes = 3.  c % 8 == 0."""
-    _need_cuda(x)
-    xx = x.contiguous().float()
-    n, c = xx.shape
-    out = torch.empty((n + 1, int(planes), c), dtype=torch.bfloat16, device=xx.device)
-    check(lib.msmd_split_planes_f32(_p(xx), n, c, int(planes), _p(out), _stream()),
-          "msmd_split_planes_f32")
-    return out
-
-
-def wgrad_planes_supported(c_in, c_out):
-    return bool(lib.msmd_spconv_wgrad_planes_supported(int(c_in), int(c_out)))
-
-
-def conv_wgrad_planes(in_planes, dout_planes, pairs, num, krsc_shape=None):
-    """conv_wgrad from plane tensors (split_planes) of the features and of grad_out."""
-    _need_cuda(in_planes, dout_planes, pairs, num)
-    assert in_planes.dtype == dout_planes.dtype == torch.bfloat16
-    assert in_planes.is_contiguous() and dout_planes.is_contiguous()
-    assert in_planes.shape[1] == dout_planes.shape[1]
-    kvol, _, ld = pairs.shape
-    n_in, np_, c_in = in_planes.shape[0] - 1, in_planes.shape[1], in_planes.shape[2]
-    n_out, c_out = dout_planes.shape[0] - 1, dout_planes.shape[2]
-    dw = torch.empty((kvol, c_in, c_out) if krsc_shape is None else tuple(krsc_shape),
-                     dtype=torch.float32, device=in_planes.device)
-    nbytes = lib.msmd_spconv_wgrad_planes_workspace_bytes(kvol, n_out, c_in, c_out)
-    ws = _ws(nbytes, in_planes.device)
-    ev = _prof_begin()
-    check(lib.msmd_spconv_wgrad_planes(_p(in_planes), n_in, c_in, _p(dout_planes), n_out, c_out,
-                                       _p(pairs), _p(num), ld, kvol, np_, _p(dw),
-                                       int(krsc_shape is not None), _p(ws), nbytes, _stream()),
-          "msmd_spconv_wgrad_planes")
-    _prof_end("spconv_wgrad_planes", ev, num=num, c_in=c_in, c_out=c_out)
     return dw
 
 

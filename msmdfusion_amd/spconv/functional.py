@@ -75,33 +75,6 @@ def _conv_f32(x, weight, krsc, transpose, nbr, n_out, weight_flip=False, row_ord
     return torch.cat(outs, 1)
 
 
-def planes_of(t, np_):
-    """bf16 plane tensor of a [n,c] fp32 tensor (K.split_planes), remembered on the
-    tensor object while its contents stay the same (`_version`): a producer that
-    already wrote the planes (the fused BN kernels) attaches them the same way."""
-    hit = getattr(t, "_msmd_planes", None)
-    if hit is not None and hit[0] == t._version and hit[1].shape[1] == np_ \
-            and hit[1].shape[0] == t.shape[0] + 1:
-        return hit[1]
-    planes = K.split_planes(t, np_)
-    try:
-        t._msmd_planes = (t._version, planes)
-    except (AttributeError, RuntimeError):
-        pass
-    return planes
-
-
-def _wgrad_mode():
-    """MSMD_WGRAD: 'split' (default) -- fp32 operands gathered into registers and split
-    there for every gathered row (csrc/spconv_split.hip); 'planes' -- operands split once
-    per tensor into bf16 plane tensors, gathered by LDS-DMA and transposed by the LDS read
-    (csrc/spconv_planes.hip).  The plane kernel removes all operand VALU work, but on
-    MI355X it measured no faster (128x128, 1.2 M pairs: 354-430 us against 380): with one
-    8-wave workgroup per CU its phases (DMA issue, LDS reads, MFMAs) run in lockstep
-    behind the stage barrier instead of overlapping (DESIGN.md 3.3 has the ablations)."""
-    return os.environ.get("MSMD_WGRAD", "split")
-
-
 _SIDE_STREAMS = {}
 
 
@@ -202,12 +175,6 @@ class _SparseConvFunction(Function):
             pairs, num = rb.pairs()     # (cached; built on this stream if not yet)
 
             def run_wgrad():
-                if conv_planes() in (1, 2, 3) and _wgrad_mode() == "planes" \
-                        and K.wgrad_planes_supported(c_in, c_out):
-                    np_ = conv_planes()
-                    return K.conv_wgrad_planes(planes_of(features, np_), planes_of(grad_out, np_),
-                                               pairs, num,
-                                               krsc_shape=weight.shape if krsc else None)
                 if conv_planes() in (1, 2, 3) and K.wgrad_split_supported(c_in, c_out):
                     return K.conv_wgrad_split(features, grad_out, pairs, num, conv_planes(),
                                               krsc_shape=weight.shape if krsc else None)

@@ -18,8 +18,10 @@ description of what ran.  They are timing harnesses: parity lives in tests/.
 
 Skipped in both (elementwise, < 1 % of the CPU time): BatchNorm, ReLU, the
 residual adds and the optimizer; in lc_sample also the backward of the four
-gate Linears.  The real reference loop (torch::mm per offset + index_add) is
-slower than this OpenMP restatement, so the figure flatters the CPU.
+gate Linears.  reference_conv_leg() times the conv part alone through the
+reference's own compiled loop (oracle/_ref: gather / torch::mm / scatter-add) beside
+this port on the same layers -- on the build container's cores torch::mm's BLAS makes
+the reference loop ~4x faster than the port's plain OpenMP GEMM on the wide layers.
 """
 import time
 
@@ -167,3 +169,50 @@ def lc_sample(seed):
     return dict(seconds=time.perf_counter() - t0, gmac_fwd=(macs_enc + macs) / 1e9,
                 gmac_fwd_fusion=macs / 1e9, points=pts.shape[0], voxels=nvox,
                 virtual_points=virt.shape[0], virtual_voxels=n2_total)
+
+
+def reference_conv_leg(seed=0, budget_s=6.0):
+    """The conv part of the path through the REFERENCE's own compiled CPU code
+    (oracle/_ref/libmsmd_ref.so: spconv's SparseGatherFunctor / SparseScatterAddFunctor around
+    torch::mm, the loop of spconv_ops.h:260-456) beside the OpenMP port on the SAME layers:
+    SubM 3x3x3 forward + backward (dgrad + wgrad) on the LiDAR voxels of one synthetic sample
+    at the encoder's widths, widest layers first until ~budget_s of reference time is spent.
+    -> dict with both GMAC/s figures, or None when the reference build is not on this box."""
+    if not O.have_ref():
+        return None
+    import torch
+    pts = S.lidar_sweep(seed)
+    v, c, n = O.hard_voxelize(pts, S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 120000)
+    idx = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+    shape = list(S.SPARSE_SHAPE)
+    rng = np.random.RandomState(seed)
+    layers, t_ref, t_port, macs = [], 0.0, 0.0, 0
+    # stage s: the voxel set after s stride-2 convs, SubM at the stage's width
+    for s, width in enumerate((16, 32, 64, 128)):
+        if s:
+            idx, _, _, shape = O.get_indice_pairs(idx, 1, shape, 3, 2, DOWN_PADS[s - 1], 1, False)
+            shape = list(shape)
+        oi, pr, nm, _ = O.get_indice_pairs(idx, 1, shape, 3, 1, 1, 1, True)
+        layers.append((width, idx.shape[0], pr, nm))
+    for width, rows, pr, nm in reversed(layers):
+        f = rng.randn(rows, width).astype(np.float32)
+        w = rng.randn(27, width, width).astype(np.float32) * 0.05
+        g = rng.randn(rows, width).astype(np.float32)
+        for use_ref in (False, True):
+            t0 = time.perf_counter()
+            O.indice_conv_fwd(f, w, pr, nm, rows, subm=True, use_ref=use_ref)
+            O.indice_conv_bwd(f, w, g, pr, nm, subm=True, use_ref=use_ref)
+            dt = time.perf_counter() - t0
+            if use_ref:
+                t_ref += dt
+            else:
+                t_port += dt
+        macs += 3 * int(nm.sum()) * width * width          # fwd + dgrad + wgrad
+        if t_ref > budget_s:
+            break
+    return dict(reference_gmac_per_s=round(macs / 1e9 / t_ref, 2),
+                port_gmac_per_s=round(macs / 1e9 / t_port, 2),
+                reference_seconds=round(t_ref, 2), port_seconds=round(t_port, 2),
+                torch_threads=torch.get_num_threads(),
+                layers="SubM 3x3x3 fwd+dgrad+wgrad on one synthetic sample's LiDAR voxel sets, "
+                       "widths 128, 64, 32, 16 (widest first, until the budget is spent)")

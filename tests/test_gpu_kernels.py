@@ -417,79 +417,6 @@ def test_split_wgrad(dev, cin, cout, planes):
     np.testing.assert_allclose(dw2.cpu().numpy(), edw2, rtol=tol, atol=5 * tol)
 
 
-def test_split_planes_exact(dev):
-    """msmd_split_planes_f32: x == plane0 + plane1 + plane2 exactly (three bf16 values
-    carry an fp32's 24 bits), each plane the round-to-nearest bf16 of the residual, the
-    extra last row all zeros."""
-    from msmdfusion_amd import kernels as K
-    rng = np.random.RandomState(0)
-    x = (rng.randn(777, 96) * np.exp(rng.randn(777, 96) * 4)).astype(np.float32)
-    x[0, :8] = [0.0, -0.0, 1.0, -1.0, 3.0e38, 1e-30, 65504.0, 1.17549435e-38]
-    xd = t(x, dev)
-    for planes in (3, 2, 1):
-        p = K.split_planes(xd, planes)
-        assert p.shape == (778, planes, 96) and p.dtype == torch.bfloat16
-        assert not p[777].float().abs().any()
-        r = xd.clone()
-        for k in range(planes):
-            assert torch.equal(p[:777, k], r.bfloat16())
-            r = r - p[:777, k].float()
-        if planes == 3:
-            assert not r.abs().any()          # exact reconstruction
-            assert torch.equal(p[:777].float().sum(1), xd) or \
-                torch.equal((p[:777, 0].float() + p[:777, 1].float()) + p[:777, 2].float(), xd)
-
-
-@pytest.mark.parametrize("planes", [3, 2, 1])
-@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 128), (128, 64), (128, 128), (192, 64),
-                                      (80, 80), (80, 96), (96, 128), (192, 192), (72, 104)])
-def test_planes_wgrad(dev, cin, cout, planes):
-    """msmd_spconv_wgrad_planes (bf16 plane tensors gathered by LDS-DMA, transposing LDS
-    reads) against the oracle: SubM and strided pair lists, ragged chunk tails, partial
-    channel slabs, [K,Cin,Cout] and KRSC outputs; planes=3 as close to the oracle as the
-    fp32 MFMA kernel, and deterministic."""
-    from msmdfusion_amd import kernels as K
-    assert K.wgrad_planes_supported(cin, cout) and not K.wgrad_planes_supported(32, 64)
-    assert not K.wgrad_planes_supported(68, 64)
-    shape = [11, 64, 64]
-    idx = S.random_voxel_indices(2500, 2, shape, seed=cin + cout)
-    n = idx.shape[0]
-    rng = np.random.RandomState(cin + 7 * cout)
-    f = rng.randn(n, cin).astype(np.float32)
-    g = rng.randn(n, cout).astype(np.float32)
-    w = np.zeros((27, cin, cout), np.float32)
-    oi, pr, nm, _ = O.get_indice_pairs(idx, 2, shape, 3, 1, 1, 1, True)
-    _, edw = O.indice_conv_bwd(f, w, g, pr, nm, subm=True)
-    tol = {3: TOL, 2: 2 * TOL, 1: 3e-2}[planes]
-    nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
-    pairs, num = K.rulebook_pairs(nbr)
-    fp, gp = K.split_planes(t(f, dev), planes), K.split_planes(t(g, dev), planes)
-    dw = K.conv_wgrad_planes(fp, gp, pairs, num)
-    scale = float(np.abs(edw).max())
-    assert np.abs(dw.cpu().numpy() - edw).max() <= 5 * tol * max(scale, 1.0) if planes == 1 else True
-    if planes > 1:
-        np.testing.assert_allclose(dw.cpu().numpy(), edw, rtol=tol, atol=5 * tol)
-    dwk = K.conv_wgrad_planes(fp, gp, pairs, num, krsc_shape=(cout, 3, 3, 3, cin))
-    assert torch.equal(dwk.view(cout, 27, cin).permute(1, 2, 0), dw)
-    assert torch.equal(dw, K.conv_wgrad_planes(fp, gp, pairs, num))
-    if planes == 3:
-        # (one accumulator chain per wave over a whole row range: a few more fp32
-        # roundings than the fp32 kernel's 4-way interleave, same order of magnitude)
-        d32 = K.conv_wgrad(t(f, dev), t(g, dev), pairs, num).cpu().numpy()
-        assert np.abs(dw.cpu().numpy() - edw).max() <= 4 * np.abs(d32 - edw).max() + 2e-6 * scale
-    # strided conv: compact lists of very different lengths, ld > pairs, n_out != n_in
-    oi, pr, nm, osz = O.get_indice_pairs(idx, 2, shape, 3, 2, 1, 1, False)
-    m = oi.shape[0]
-    g2 = rng.randn(m, cout).astype(np.float32)
-    _, edw2 = O.indice_conv_bwd(f, w, g2, pr, nm)
-    _, _, perm = O.canonical_rulebook(oi, pr, nm, osz)
-    _, nbr_fwd, _, _ = K.rulebook_conv(t(idx, dev), 2, shape, 3, 2, 1)
-    pairs2, num2 = K.rulebook_pairs(nbr_fwd, ld=max(n, m))
-    dw2 = K.conv_wgrad_planes(fp, K.split_planes(t(g2[perm], dev), planes), pairs2, num2)
-    if planes > 1:
-        np.testing.assert_allclose(dw2.cpu().numpy(), edw2, rtol=tol, atol=5 * tol)
-
-
 def test_split_conv_bf16_operands(dev):
     """planes=1 (MSMD_CONV_PLANES=1): plain bf16 operands, fp32 accumulate -- the
     arithmetic of configs[2]'s "bf16".  Equal to an fp64 evaluation on operands

@@ -19,16 +19,7 @@ for w in $WHAT; do
       timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
       tail -c 600 $OUT/bench_default.json; tail -3 $OUT/bench_default.err ;;
     prof)
-      (cd /tmp && export TMPDIR=/tmp
-       for wl in lc transfusion_l; do
-         P=$OUT/prof_$wl; mkdir -p $P
-         timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o s -- \
-           python $R/bench.py --workload $wl --no-also --no-cpu-baseline --no-profile > $P/bench.log 2>&1
-         rm -f $P/*kernel_trace.csv $P/*/*kernel_trace.csv
-         f=$(find $P -name "*kernel_stats.csv" | head -1)
-         tail -1 $P/bench.log | cut -c1-160
-         [ -n "$f" ] && python $R/tools/prof_summary.py $f $([ $wl = lc ] && echo 42 || echo 36) 40 > $P/summary.txt
-       done) ;;
+      for wl in lc transfusion_l; do bash $R/tools/prof_bench.sh $TAG $wl; done ;;
     rb)   # integer kernels at nominal and stress size (profiles/rNN_rulebook_voxelize_roofline.jsonl)
       timeout 300 python tools/rulebook_bench.py 2>/dev/null > $OUT/rulebook_voxelize_roofline.jsonl
       cut -c1-200 $OUT/rulebook_voxelize_roofline.jsonl
