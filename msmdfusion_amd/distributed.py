@@ -144,21 +144,44 @@ class TrainStep:
     def __init__(self, net, params, optimizer, loss_fn, prefetcher=None, max_norm=10.0):
         self.net, self.params, self.optimizer = net, list(params), optimizer
         self.loss_fn, self.prefetcher, self.max_norm = loss_fn, prefetcher, max_norm
-        self._pending = []
+        self._pending = []      # (batch, ticket), oldest first: a ticket stays with ITS batch
+
+    def _submit(self, batch):
+        self._pending.append((batch, self.prefetcher.submit(*batch)))
 
     def prime(self, batch):
         """Queue the index work of the first batch (call once before the loop)."""
         if self.prefetcher is not None:
-            self._pending.append(self.prefetcher.submit(*batch))
+            self._submit(batch)
 
     def __call__(self, batch, next_batch=None):
+        """One step on `batch`.  next_batch: the batch of the next step, or a list of the
+        next steps' batches in order (a prefetcher of depth d keeps up to d of them in
+        flight); None = the next step reuses `batch` (bench.py's constant synthetic batch).
+        The prepared batch handed to the forward pass is always the one submitted for THIS
+        batch object -- a queue that is out of step with the caller raises instead of
+        silently pairing one batch's voxels with another's images and targets."""
         pf = self.prefetcher
         ticket = None
         if pf is not None:
-            while len(self._pending) < getattr(pf, "depth", 1):     # keep `depth` in flight
-                self.prime(batch)
-            self._pending.append(pf.submit(*(batch if next_batch is None else next_batch)))
-            ticket = self._pending.pop(0)
+            if not self._pending:
+                self._submit(batch)
+            if self._pending[0][0] is not batch:
+                raise RuntimeError(
+                    "TrainStep: the oldest prepared batch was submitted for a different batch "
+                    "object than the one being stepped (pass upcoming batches as next_batch, "
+                    "in order)")
+            depth = getattr(pf, "depth", 1)
+            upcoming = [batch] * depth if next_batch is None else (
+                list(next_batch) if isinstance(next_batch, list) else [next_batch])
+            # pending[1 + i] must be upcoming[i]: submit the ones not queued yet
+            for i, nb in enumerate(upcoming[:depth]):
+                if len(self._pending) - 1 > i:
+                    if self._pending[1 + i][0] is not nb:
+                        raise RuntimeError("TrainStep: next_batch changed after it was submitted")
+                    continue
+                self._submit(nb)
+            _, ticket = self._pending.pop(0)
             out = self.net(*batch, prepared=pf.take(ticket))
         else:
             out = self.net(*batch)

@@ -1071,17 +1071,30 @@ def rows_where(mask, count):
     count = int(count)
     if count == 0:
         return torch.empty((0,), dtype=torch.long, device=mask.device)
-    global _NONZERO_STATIC
-    if _NONZERO_STATIC:
-        try:
-            return torch.nonzero_static(mask, size=count).flatten()
-        except (NotImplementedError, RuntimeError):
-            _NONZERO_STATIC = False
+    if _nonzero_static_ok(mask.device):
+        return torch.nonzero_static(mask, size=count).flatten()
     # stable sort of the inverted mask: the selected rows come first, in order
     return torch.sort((~mask).to(torch.uint8), stable=True)[1][:count]
 
 
-_NONZERO_STATIC = hasattr(torch, "nonzero_static")
+_NONZERO_STATIC = {}      # device type -> whether torch.nonzero_static works there
+
+
+def _nonzero_static_ok(device):
+    """Probed ONCE per device type on a tiny tensor: the hot path never swallows a
+    RuntimeError (an asynchronous HIP error surfacing at that call would be hidden and the
+    slow fallback taken for the rest of the process)."""
+    ok = _NONZERO_STATIC.get(device.type)
+    if ok is None:
+        ok = False
+        if hasattr(torch, "nonzero_static"):
+            try:
+                probe = torch.tensor([True, False, True], device=device)
+                ok = torch.nonzero_static(probe, size=2).flatten().tolist() == [0, 2]
+            except (NotImplementedError, RuntimeError):
+                ok = False
+        _NONZERO_STATIC[device.type] = ok
+    return ok
 
 
 # ------------------------------------------------------------------ GMA-Conv helpers

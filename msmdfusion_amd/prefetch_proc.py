@@ -17,6 +17,7 @@ no cross-process event; a consumed batch's buffers are kept referenced until the
 consumer's stream has passed its last reader (retire(), as in IndexPrefetcher).
 """
 import collections
+import queue
 import io
 import pickle
 
@@ -128,7 +129,9 @@ class ProcessPrefetcher:
             try:
                 skeleton, table, buffers = self.queue.get(timeout=5.0)
                 break
-            except Exception:            # queue.Empty: is the worker still there?
+            except queue.Empty:          # nothing yet: is the worker still there?
+                # (only Empty: an IPC-rebuild or unpickling error raised by get() has
+                # consumed the item and must surface, not be retried forever)
                 if not self.proc.is_alive():
                     raise RuntimeError("index worker process died (exit code %s)"
                                        % self.proc.exitcode)

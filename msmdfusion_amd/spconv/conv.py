@@ -117,6 +117,13 @@ class SparseConvolution(SparseModule):
         kv = int(np.prod(self.kernel_size))
         return self.weight.reshape(self.out_channels, kv, self.in_channels).permute(1, 2, 0)
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        # copy_ into a Parameter bumps its version, but loaders that write through `.data`
+        # do not: the packed images of frozen weights are rebuilt after any load
+        from . import functional as Fsp
+        Fsp.invalidate_packed_weights()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def forward(self, input: SparseConvTensor):
         assert isinstance(input, SparseConvTensor)
         assert input.features.shape[1] == self.in_channels, "channel size mismatch"

@@ -116,15 +116,29 @@ _FROZEN_PACKS = {}
 
 def _pack_split_cached(weight, np_, krsc):
     """pack_weight_split of a weight that does not train (the LC recipe freezes the LiDAR
-    encoder, tools/train.py:185-219): packed once per (tensor, version), not once per
-    step -- 21 launches and their host time per step on the LC path."""
-    key = (weight.data_ptr(), weight._version, np_, krsc, tuple(weight.shape))
+    encoder, tools/train.py:185-219): packed once, not once per step -- 21 launches and
+    their host time per step on the LC path.  An entry belongs to ONE live tensor object (a
+    weak reference: a new Parameter that inherits a dead one's id and storage address
+    misses, and a dead one's entry is evicted) and to its `_version` (in-place ops).
+    Writes through `.data` do not bump the version: SparseConvolution drops the cache when a
+    state dict is loaded into it, and code that re-initialises a frozen weight through
+    `.data` after a forward calls invalidate_packed_weights() itself."""
+    import weakref
     hit = _FROZEN_PACKS.get(id(weight))
-    if hit is None or hit[0] != key:
-        hit = _FROZEN_PACKS[id(weight)] = (key, K.pack_weight_split(weight, np_, krsc=krsc))
-        if len(_FROZEN_PACKS) > 512:
-            _FROZEN_PACKS.pop(next(iter(_FROZEN_PACKS)))
-    return hit[1]
+    key = (weight.data_ptr(), weight._version, np_, krsc, tuple(weight.shape))
+    if hit is not None and hit[0]() is weight and hit[1] == key:
+        return hit[2]
+    packed = K.pack_weight_split(weight, np_, krsc=krsc)
+    wid = id(weight)
+    ref = weakref.ref(weight, lambda _r, wid=wid: _FROZEN_PACKS.pop(wid, None))
+    _FROZEN_PACKS[wid] = (ref, key, packed)
+    return packed
+
+
+def invalidate_packed_weights():
+    """Forget every cached packed image of a frozen weight (call after writing weights
+    through `.data` / load_state_dict; SparseConvolution's load hook does)."""
+    _FROZEN_PACKS.clear()
 
 
 def _conv_forward(features, weight, rb, krsc, want_dgrad):
@@ -254,7 +268,10 @@ def bn_act(x, bn, relu=False, residual=None):
     rv = bn.running_var if pass_running else None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
+    # (any of the four: a BatchNorm with frozen weight but trainable bias still needs its
+    # bias gradient, as torch's own BatchNorm produces)
     if not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad
+                                         or bn.bias.requires_grad
                                          or (residual is not None and residual.requires_grad))):
         return K.bn_act_forward(x, residual, bn.weight, bn.bias, rm, rv, use_batch_stats,
                                 bn.momentum, bn.eps, relu)[0]

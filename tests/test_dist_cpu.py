@@ -173,3 +173,52 @@ def test_single_process_helpers_are_noops():
     assert D.wrap_data_parallel(m) is m
     assert D.global_max(3.5) == 3.5
     assert D.shard_sample_ids(0, 1, 4) == [0, 1, 2, 3]
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_train_step_pairs_each_batch_with_its_own_prepared_batch(depth):
+    """A prefetcher that keeps `depth` batches in flight must still hand the forward pass
+    the index work of THE batch being stepped (round-2 advisory: with depth 2 the queue
+    was filled with copies of the current batch and step i ran on batch i-1's voxels).
+    Distinct batches, the upcoming ones passed as a list: every step's `prepared` equals
+    prepare(that step's batch); a caller that skips a batch gets an error, not garbage."""
+    sys.path.insert(0, ROOT)
+    from msmdfusion_amd import distributed as D
+    from msmdfusion_amd.prefetch import IndexPrefetcher
+    torch.manual_seed(0)
+    model = _TinyPath()
+    seen = []
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.m = model
+
+        def forward(self, x, prepared=None):
+            seen.append((x, prepared))
+            return self.m(x, prepared=prepared)
+    net = Net()
+    params = list(model.parameters())
+    opt = torch.optim.SGD(params, lr=1e-3)
+    pf = IndexPrefetcher(model.prepare, "cpu", threaded=True, depth=depth)
+    assert pf.depth == depth
+    step = D.TrainStep(net, params, opt, lambda y: y.pow(2).mean(), pf, max_norm=None)
+    data = _batches(0, 7)
+    step.prime(data[0])
+    for i, b in enumerate(data):
+        step(b, next_batch=data[i + 1:i + 1 + depth])
+    assert len(seen) == len(data)
+    for (x, prepared), b in zip(seen, data):
+        assert x is b[0] and torch.equal(prepared, model.prepare(b[0]))
+    # out of step with the queue: refused
+    step2 = D.TrainStep(net, params, opt, lambda y: y.pow(2).mean(), pf, max_norm=None)
+    step2.prime(data[0])
+    with pytest.raises(RuntimeError, match="different batch"):
+        step2(data[1])
+    # the constant-batch form bench.py uses
+    step3 = D.TrainStep(net, params, opt, lambda y: y.pow(2).mean(), pf, max_norm=None)
+    step3.prime(data[2])
+    for _ in range(4):
+        step3(data[2])
+    assert all(x is data[2][0] for x, _ in seen[-4:])
