@@ -57,6 +57,11 @@ PINNED_CPUS = pin_host_threads() if (__name__ == "__main__" or
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
+# more busy host threads than the cgroup pays CPUs for (8 ranks on a 16-CPU box): waits
+# block instead of spinning (device flag: before the first HIP call of the process)
+from msmdfusion_amd.hostcpu import set_blocking_sync_if_oversubscribed  # noqa: E402
+BLOCKING_SYNC = set_blocking_sync_if_oversubscribed() if __name__ == "__main__" else False
+
 PEAK_BF16_MFMA_TFLOPS = 2516.6   # 256 CUs x 4096 flop/clk x 2.4 GHz, dense
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
@@ -481,7 +486,9 @@ def main():
                "dtype": "f32 via 3xbf16 split MFMA (each fp32 operand = exact sum of 3 bf16 planes, 6 "
                         "products, fp32 accumulate; fp32 storage)",
                "data": "synthetic",
-               "rccl_ranks": D.rccl_ranks(), "config": head["config"],
+               "rccl_ranks": D.rccl_ranks(),
+               "host": {"pinned_cpus": PINNED_CPUS, "blocking_sync": bool(BLOCKING_SYNC)},
+               "config": head["config"],
                "roofline": head["roofline"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)

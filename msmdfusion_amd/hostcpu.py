@@ -59,7 +59,10 @@ def base_cpus():
 
 
 def quota_cpus():
-    """CPUs' worth of time the cgroup grants (cpu.max quota / period), or None."""
+    """CPUs' worth of time the cgroup grants (cpu.max quota / period), or None.
+    MSMD_CPU_QUOTA overrides it (tests; boxes whose limit is not in cpu.max)."""
+    if os.environ.get("MSMD_CPU_QUOTA"):
+        return max(1, int(os.environ["MSMD_CPU_QUOTA"]))
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if quota != "max":
@@ -78,9 +81,58 @@ def within_quota(cpus=None):
     return cpus if q is None or q >= len(cpus) else cpus[:q]
 
 
-def pin_host_threads(local_rank=None, cpus_per_rank=4):
+def local_world_size():
+    """Ranks of this job on this node (torch.distributed.run exports LOCAL_WORLD_SIZE)."""
+    for k in ("LOCAL_WORLD_SIZE", "WORLD_SIZE"):
+        if os.environ.get(k):
+            return max(1, int(os.environ[k]))
+    return 1
+
+
+def plan_rank_cpus(local_rank, local_world, base=None, max_per_rank=4):
+    """The CPUs of rank `local_rank` of `local_world` ranks on this node: disjoint groups of
+    equal size cut from the first `quota` CPUs of the job's mask -- all ranks together never
+    ask for more CPU time than the cgroup grants (8 ranks x 4 CPUs on a 16-CPU quota was the
+    throttling hazard of round 2: DESIGN.md 8.5), and a rank's RCCL proxy and HIP helper
+    threads, created after the pin, inherit its group."""
+    allowed = within_quota(base)
+    per = max(1, min(int(max_per_rank), len(allowed) // max(1, int(local_world))))
+    return rank_cpus(local_rank, per, allowed)
+
+
+def host_is_oversubscribed(local_world=None, threads_per_rank=None):
+    """True when the ranks' busy host threads (step + index prefetcher each, + RCCL's proxy
+    thread in a multi-rank job) outnumber the CPUs the cgroup pays for: waits must then
+    BLOCK (hipDeviceScheduleBlockingSync) instead of spinning, or the spinners eat the quota
+    the working threads need."""
+    q = quota_cpus()
+    n = local_world_size() if local_world is None else int(local_world)
+    if threads_per_rank is None:
+        threads_per_rank = 2 + (1 if n > 1 else 0)
+    return q is not None and n * threads_per_rank > q
+
+
+def set_blocking_sync_if_oversubscribed(local_world=None):
+    """Call after `import torch` and BEFORE the first HIP call of the process (device flags
+    are fixed when the context is created).  -> whether blocking waits were selected."""
+    if os.environ.get("MSMD_BLOCKING_SYNC", "auto") == "0":
+        return False
+    if os.environ.get("MSMD_BLOCKING_SYNC") != "1" and not host_is_oversubscribed(local_world):
+        return False
+    import ctypes
+    try:
+        hip = ctypes.CDLL(None)
+        fn = hip.hipSetDeviceFlags
+    except (OSError, AttributeError):
+        return False
+    return fn(ctypes.c_uint(0x4)) == 0        # hipDeviceScheduleBlockingSync
+
+
+def pin_host_threads(local_rank=None, cpus_per_rank=None):
     """Restrict the calling thread (and every thread it creates from now on) to this rank's
-    CPUs.  MSMD_PIN=0 disables it, MSMD_PIN_CPUS='a-b,c' names the CPUs outright.
+    CPUs: a group of up to 4, sized so that all local ranks fit the cgroup's quota
+    (plan_rank_cpus); cpus_per_rank forces a size.  MSMD_PIN=0 disables it,
+    MSMD_PIN_CPUS='a-b,c' names the CPUs outright.
     -> the CPU list in effect, or None when pinning is off / unsupported."""
     if os.environ.get("MSMD_PIN", "1") != "1" or not hasattr(os, "sched_setaffinity"):
         return None
@@ -89,8 +141,10 @@ def pin_host_threads(local_rank=None, cpus_per_rank=4):
     base = base_cpus()
     if os.environ.get("MSMD_PIN_CPUS"):
         cpus = parse_cpu_list(os.environ["MSMD_PIN_CPUS"])
-    else:
+    elif cpus_per_rank is not None:
         cpus = rank_cpus(local_rank, cpus_per_rank, base)
+    else:
+        cpus = plan_rank_cpus(local_rank, local_world_size(), base)
     try:
         os.sched_setaffinity(0, cpus)
     except OSError:

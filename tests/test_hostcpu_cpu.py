@@ -48,3 +48,28 @@ def test_pinning_in_a_child_process_and_its_children():
          "from msmdfusion_amd import hostcpu as H; print(H.pin_host_threads())"],
         env=dict(env, MSMD_PIN="0"))
     assert off.decode().strip() == "None"
+
+
+def test_eight_ranks_fit_a_sixteen_cpu_quota(monkeypatch):
+    """SCALE runs 8 ranks on a box whose cgroup pays for 16 CPUs: the ranks' CPU groups are
+    disjoint, equal, and together inside the quota (round 2 gave every rank 4 = 32 CPUs);
+    with two busy threads per rank the host counts as oversubscribed only beyond the quota."""
+    base = list(range(0, 64)) + list(range(128, 192))
+    monkeypatch.setenv("MSMD_CPU_QUOTA", "16")
+    groups = [H.plan_rank_cpus(r, 8, base) for r in range(8)]
+    assert all(len(g) == 2 for g in groups)
+    flat = [c for g in groups for c in g]
+    assert len(set(flat)) == 16 and set(flat) == set(base[:16])
+    assert [H.plan_rank_cpus(r, 4, base) for r in range(4)] == \
+        [base[4 * r:4 * r + 4] for r in range(4)]
+    assert H.plan_rank_cpus(0, 1, base) == base[:4]
+    assert H.plan_rank_cpus(5, 32, base) == [base[5]]            # never less than one CPU
+    # 3 busy threads per rank in a multi-rank job (step, index prefetcher, RCCL proxy)
+    assert not H.host_is_oversubscribed(1) and not H.host_is_oversubscribed(5)
+    assert H.host_is_oversubscribed(6) and H.host_is_oversubscribed(8)
+    monkeypatch.setenv("MSMD_CPU_QUOTA", "8")
+    assert H.host_is_oversubscribed(4) and not H.host_is_oversubscribed(2)
+    assert [len(H.plan_rank_cpus(r, 8, base)) for r in range(8)] == [1] * 8
+    monkeypatch.delenv("MSMD_CPU_QUOTA")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert H.local_world_size() == 8
