@@ -126,90 +126,79 @@ def parse():
     return ap.parse_args()
 
 
+def _sparse_only(model_cfg):
+    """The config's `model` dict without the dense tail and head: the sparse hot path."""
+    return {k: v for k, v in model_cfg.items()
+            if k not in ("pts_backbone", "pts_neck", "pts_bbox_head")}
+
+
 class Backbone(torch.nn.Module):
-    """pts_voxel_layer + pts_voxel_encoder + pts_middle_encoder of
-    TransFusionDetector.extract_pts_feat (mmdet3d/models/detectors/transfusion.py:61-74)."""
+    """configs[1]: TransFusionDetector (msmdfusion_amd/detector.py) built from
+    configs/transfusion_nusc_voxel_L.py's model dict up to the BEV map --
+    pts_voxel_layer + pts_voxel_encoder + pts_middle_encoder of extract_pts_feat
+    (mmdet3d/models/detectors/transfusion.py:61-74)."""
 
     def __init__(self):
         super().__init__()
-        from msmdfusion_amd import synthetic as S
-        from msmdfusion_amd.registry import build_middle_encoder
-        from msmdfusion_amd.voxelize import Voxelization
-        import msmdfusion_amd.sparse_encoder  # noqa: F401  (registers SparseEncoder)
-        self.voxel_layer = Voxelization(S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, S.MAX_NUM_POINTS,
-                                        S.MAX_VOXELS)
-        self.middle_encoder = build_middle_encoder(ENCODER_CFG)
-
-    @torch.no_grad()
-    def voxelize(self, points):
-        """transfusion.py:76-101 with the VFE fused into the gather."""
-        feats, coors = [], []
-        for b, (mean, c, _) in enumerate(self.voxel_layer.forward_batch(points, fused_mean=True)):
-            feats.append(mean)
-            coors.append(F.pad(c, (1, 0), mode="constant", value=b))
-        return torch.cat(feats, 0), torch.cat(coors, 0)
+        from msmdfusion_amd.detector import build_detector
+        self.det = build_detector(_sparse_only(TRANSFUSION_L["model"]))
+        self.voxel_layer, self.middle_encoder = self.det.pts_voxel_layer, self.det.pts_middle_encoder
 
     def prepare(self, points):
-        """The index-only part of a step (needs no weights, no previous step):
-        voxelization + every rulebook / tiling order / pair list of the encoder."""
-        feats, coors = self.voxelize(points)
-        planned, _ = self.middle_encoder.plan(coors, len(points))
-        return feats, coors, planned
+        return self.det.prepare(points)
 
     def forward(self, points, prepared=None):
-        feats, coors, planned = prepared if prepared is not None else self.prepare(points)
-        bev, _ = self.middle_encoder(feats, coors, len(points), planned=planned)
-        return bev
+        return self.det.extract_sparse_feat(points, prepared=prepared)
 
 
 class FusionBackbone(torch.nn.Module):
-    """MSMDFusionDetector.extract_pts_feat's sparse section
-    (mmdet3d/models/detectors/MSMDFusion.py:421-443) with the LC config
-    (configs/MSMDFusion_nusc_voxel_LC.py:141-190): LiDAR encoder frozen
+    """configs[2]: MSMDFusionDetector built from configs/MSMDFusion_nusc_voxel_LC.py's model
+    dict, its sparse section (MSMDFusion.py:421-443): LiDAR encoder frozen
     (freeze_lidar_components, tools/train.py:185-219), fusion stack trained."""
 
-    def __init__(self):
+    def __init__(self, tail=False, head=False):
         super().__init__()
-        from msmdfusion_amd import synthetic as S
-        from msmdfusion_amd.distributed import freeze_unused_fusion_blocks
-        from msmdfusion_amd.fusion import SparseFusionPath
-        from msmdfusion_amd.registry import build_middle_encoder
-        from msmdfusion_amd.voxelize import Voxelization
-        vox = Voxelization(S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, S.MAX_NUM_POINTS, S.MAX_VOXELS)
-        enc = build_middle_encoder(ENCODER_CFG)
-        mm = build_middle_encoder(MSMDFUSION_LC["model"]["multimodal_middle_encoder"])
-        for p in enc.parameters():
-            p.requires_grad = False
-        for m in enc.modules():
-            if isinstance(m, torch.nn.BatchNorm1d):
-                m.track_running_stats = False
-        freeze_unused_fusion_blocks(mm)     # built, never called: no find_unused_parameters
-        self.path = SparseFusionPath(vox, enc, mm)
+        from msmdfusion_amd.detector import build_detector, freeze_lidar_components
+        cfg = dict(MSMDFUSION_LC["model"]) if tail else _sparse_only(MSMDFUSION_LC["model"])
+        if head:
+            from msmdfusion_amd.configs import _PTS_BBOX_HEAD, _TEST_CFG_PTS, _TRAIN_CFG_PTS
+            cfg.update(pts_bbox_head=dict(_PTS_BBOX_HEAD), train_cfg=dict(pts=dict(_TRAIN_CFG_PTS)),
+                       test_cfg=dict(pts=dict(_TEST_CFG_PTS)))
+        self.det = build_detector(cfg)
+        if MSMDFUSION_LC["freeze_lidar_components"]:
+            freeze_lidar_components(self.det)
+        if not tail:     # the image-side glue and SPP block take no part in the sparse section
+            for m in (self.det.conv1x1_blocks, self.det.score_net, self.det.bev_fusion):
+                for p in m.parameters():
+                    p.requires_grad = False
+        else:            # reached only through @no_grad voxelization (the LC config's
+            for m in (self.det.conv1x1_blocks, self.det.score_net):   # unused parameters)
+                for p in m.parameters():
+                    p.requires_grad = False
+        self.path = self.det._path      # (tests and tools reach the sparse section here)
 
     def prepare(self, points, virtual):
         """Index-only part of a step, for the prefetcher (its own stream, a step ahead)."""
         # the FPS / nearest-voxel chain (9 + 2 ms, two workgroups wide) goes to the path's own
         # side stream: on the prefetcher's stream the NEXT batch's host reads would queue
         # behind it and the prepare chain (25 ms) would set the step time
-        return self.path.prepare(points, [virtual] * 4, nn_side_stream=True)
+        return self.det.prepare(points, virtual, nn_side_stream=True)
 
     def forward(self, points, virtual, prepared=None):
         # cat([x, x_mm], 1) -- bev_fusion's input (MSMDFusion.py:440) -- as ONE
         # channels-last map both sparse tensors scatter into (no dense()+view+cat)
-        return self.path(points, [virtual] * 4, prepared=prepared, joint_bev=True)
+        return self.det.extract_sparse_feat(points, virtual, prepared=prepared)
 
 
 class FusionTailBackbone(FusionBackbone):
     """FusionBackbone + the dense BEV tail (extract_pts_feat to its end,
     MSMDFusion.py:440-447): bev_fusion, pts_backbone, pts_neck, trained."""
 
-    def __init__(self):
-        super().__init__()
-        from msmdfusion_amd.configs import build_bev_tail
-        self.tail = build_bev_tail(MSMDFUSION_LC)
+    def __init__(self, head=False):
+        super().__init__(tail=True, head=head)
 
     def forward(self, points, virtual, prepared=None):
-        return self.tail(super().forward(points, virtual, prepared=prepared))[0]
+        return self.det.extract_pts_feat(points, virtual_points=virtual, prepared=prepared)[0]
 
 
 class FusionDetector(FusionTailBackbone):
@@ -218,11 +207,10 @@ class FusionDetector(FusionTailBackbone):
     returns the summed losses of the batch's (synthetic, fixed) ground truth."""
 
     def __init__(self, sample_ids=(), boxes_per_sample=40):
-        super().__init__()
+        super().__init__(head=True)
         import numpy as np
-        from msmdfusion_amd.configs import build_head
         from msmdfusion_amd.head_loss import LiDARBoxes
-        self.head = build_head(MSMDFUSION_LC, rows=True)
+        self.head = self.det.pts_bbox_head
         self.gt_boxes, self.gt_labels = [], []
         for i in sample_ids:                       # nuScenes-like sizes inside the range
             rs = np.random.RandomState(1000 + i)
@@ -243,8 +231,8 @@ class FusionDetector(FusionTailBackbone):
         return out
 
     def forward(self, points, virtual, prepared=None):
-        feats = FusionTailBackbone.forward(self, points, virtual, prepared=prepared)
-        losses = self.head.loss(self.gt_boxes, self.gt_labels, self.head(feats))
+        losses = self.det.forward_train(points=points, virtual_points=virtual, prepared=prepared,
+                                        gt_bboxes_3d=self.gt_boxes, gt_labels_3d=self.gt_labels)
         return sum(v for k, v in losses.items() if "loss" in k)
 
 

@@ -128,6 +128,14 @@ def launch_ranks(n, script, argv, port=None):
     return subprocess.call(cmd, env=env)
 
 
+def _same_batch(a, b):
+    """The same batch: the same object, or tuples / lists of the same objects."""
+    if a is b:
+        return True
+    return (isinstance(a, (tuple, list)) and isinstance(b, (tuple, list)) and len(a) == len(b)
+            and all(x is y for x, y in zip(a, b)))
+
+
 class TrainStep:
     """One optimisation step of the data-parallel recipe, the way bench.py and
     training run it on every rank:
@@ -166,7 +174,7 @@ class TrainStep:
         if pf is not None:
             if not self._pending:
                 self._submit(batch)
-            if self._pending[0][0] is not batch:
+            if not _same_batch(self._pending[0][0], batch):
                 raise RuntimeError(
                     "TrainStep: the oldest prepared batch was submitted for a different batch "
                     "object than the one being stepped (pass upcoming batches as next_batch, "
@@ -177,7 +185,7 @@ class TrainStep:
             # pending[1 + i] must be upcoming[i]: submit the ones not queued yet
             for i, nb in enumerate(upcoming[:depth]):
                 if len(self._pending) - 1 > i:
-                    if self._pending[1 + i][0] is not nb:
+                    if not _same_batch(self._pending[1 + i][0], nb):
                         raise RuntimeError("TrainStep: next_batch changed after it was submitted")
                     continue
                 self._submit(nb)

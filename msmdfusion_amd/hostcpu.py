@@ -120,10 +120,23 @@ def set_blocking_sync_if_oversubscribed(local_world=None):
     if os.environ.get("MSMD_BLOCKING_SYNC") != "1" and not host_is_oversubscribed(local_world):
         return False
     import ctypes
+    import glob
+    fn = None
+    # torch's own copy of the runtime (loaded RTLD_LOCAL: not visible through CDLL(None))
+    cands = [None]
     try:
-        hip = ctypes.CDLL(None)
-        fn = hip.hipSetDeviceFlags
-    except (OSError, AttributeError):
+        import torch
+        cands = sorted(glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib",
+                                              "libamdhip64.so*"))) + cands
+    except ImportError:
+        pass
+    for path in cands:
+        try:
+            fn = ctypes.CDLL(path).hipSetDeviceFlags
+            break
+        except (OSError, AttributeError):
+            continue
+    if fn is None:
         return False
     return fn(ctypes.c_uint(0x4)) == 0        # hipDeviceScheduleBlockingSync
 

@@ -55,6 +55,7 @@ MIDDLE_ENCODERS = Registry("middle_encoder")
 VOXEL_ENCODERS = Registry("voxel_encoder")
 BACKBONES = Registry("backbone")
 NECKS = Registry("neck")
+DETECTORS = Registry("detector")
 
 CONV_LAYERS.register_module("Conv1d", module=nn.Conv1d)
 CONV_LAYERS.register_module("Conv2d", module=nn.Conv2d)
@@ -109,6 +110,12 @@ def build_backbone(cfg):
     """mmdet3d.models.builder.build_backbone for the BEV tail (SECOND)."""
     _register_hot_path()
     return BACKBONES.build(cfg)
+
+
+def build_detector(cfg, train_cfg=None, test_cfg=None, **injected):
+    """mmdet3d.models.build_detector (msmdfusion_amd/detector.py registers the classes)."""
+    from . import detector
+    return detector.build_detector(cfg, train_cfg=train_cfg, test_cfg=test_cfg, **injected)
 
 
 def build_neck(cfg):
