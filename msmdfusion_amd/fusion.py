@@ -62,14 +62,60 @@ def modality_split_indices(idx3, idx2, batch_size, spatial_shape):
     return idx3_5, idx2_5, pair3.long(), pair2.long()
 
 
-def voxel_modality_split(voxel_3D, voxel_2D, batch_size):
+def _split_float_keys(idx3, idx2, batch_size):
+    """voxel_modality_split with the REFERENCE's float32 keys (MSMDFusion.py:271-272:
+    `z*1e6 + y*1e3 + x` on an int tensor promotes to float32, each step rounded) and its
+    two-pointer merge (type_assign, :27-45), sample by sample, bit for bit: keys alias once
+    z >= 17 (2^24 < 17e6) or x >= 1000, and voxels that merely share a rounded key are
+    marked "mixed" -- what a checkpoint trained with the reference has seen.  Compatibility
+    mode: torch ops and one host read, not the hot path.  Equal keys inside a set keep row
+    order (stable sort; torch.sort's tie order in the reference is unspecified)."""
+    dev = idx3.device
+    mix3 = torch.zeros((idx3.shape[0],), dtype=torch.int32, device=dev)
+    mix2 = torch.zeros((idx2.shape[0],), dtype=torch.int32, device=dev)
+    ids = torch.arange(batch_size, device=dev, dtype=idx3.dtype)
+    counts = torch.stack([(idx3[:, :1] == ids).sum(0), (idx2[:, :1] == ids).sum(0)]).tolist()
+    p3, p2, o3, o2 = [], [], 0, 0
+
+    def keys(zyx):
+        k = zyx[:, 0].float() * 1e6
+        k = k + zyx[:, 1].float() * 1e3
+        return k + zyx[:, 2].float()
+    for b in range(batch_size):
+        n3, n2 = counts[0][b], counts[1][b]
+        a, ia = torch.sort(keys(idx3[o3:o3 + n3, 1:]), stable=True)
+        c, ic = torch.sort(keys(idx2[o2:o2 + n2, 1:]), stable=True)
+        # the merge pairs the r-th occurrence of a key in one list with the r-th in the other
+        lo_c = torch.searchsorted(c, a, right=False)
+        cnt_c = torch.searchsorted(c, a, right=True) - lo_c
+        occ_a = torch.arange(n3, device=dev) - torch.searchsorted(a, a, right=False)
+        hit = occ_a < cnt_c
+        rows3 = ia[hit]
+        rows2 = ic[(lo_c + occ_a)[hit]]
+        mix3[o3 + rows3] = 1
+        mix2[o2 + rows2] = 1
+        p3.append(rows3 + o3)      # cumulative offsets (the reference adds the LAST sample's
+        p2.append(rows2 + o2)      # count only: SURVEY Appendix B.4)
+        o3 += n3
+        o2 += n2
+    return mix3, mix2, torch.cat(p3), torch.cat(p2)
+
+
+def voxel_modality_split(voxel_3D, voxel_2D, batch_size, float_keys=False):
     """MSMDFusion.py:251-325: mark voxels present in both modalities.
     indices become 5 columns (batch, mix_flag, z, y, x); syn_mix_3D / syn_mix_2D
     list the matched rows of each tensor, aligned, in ascending (b,z,y,x) order.
-    Exact integer keys on the GPU (the reference's float32 keys + numba merge
-    alias for z >= 17 or x >= 1000: SURVEY Appendix B.3, deliberate fix)."""
+    Default: exact integer keys on the GPU (the reference's float32 keys + numba merge
+    alias for z >= 17 or x >= 1000: SURVEY Appendix B.3, deliberate fix).
+    float_keys=True reproduces the reference's aliasing matches bit for bit (for running
+    a checkpoint trained with the reference at matched behaviour)."""
     idx3, idx2 = voxel_3D.indices, voxel_2D.indices
     assert idx3.shape[1] == 4 and idx2.shape[1] == 4
+    if float_keys:
+        mix3, mix2, pair3, pair2 = _split_float_keys(idx3, idx2, batch_size)
+        voxel_3D.indices = torch.cat([idx3[:, :1], mix3[:, None], idx3[:, 1:]], 1).contiguous()
+        voxel_2D.indices = torch.cat([idx2[:, :1], mix2[:, None], idx2[:, 1:]], 1).contiguous()
+        return voxel_3D, voxel_2D, pair3.long(), pair2.long()
     shape = [max(a, b) for a, b in zip(voxel_3D.spatial_shape, voxel_2D.spatial_shape)]
     voxel_3D.indices, voxel_2D.indices, pair3, pair2 = modality_split_indices(
         idx3, idx2, batch_size, shape)

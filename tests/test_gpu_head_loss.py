@@ -218,3 +218,34 @@ def test_lc_sized_loss_against_the_host_logic_on_the_oracle(dev):
     np.testing.assert_allclose(got_t[7].cpu().numpy(), want_t[7].numpy(), rtol=1.2e-7, atol=0)
     for k in want_l:
         np.testing.assert_allclose(float(got_l[k]), float(want_l[k]), rtol=1e-4, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [False, True])
+def test_forward_single_on_the_gpu_matches_the_reference(rows):
+    """TransFusionHead.forward_single on the GPU -- the torch / MIOpen form and the row-kernel
+    form (shared_conv and heat-map convs on the sparse-conv kernels) -- against the outputs of
+    the REFERENCE's own forward_single (tests/golden/head_vectors.npz,
+    transfusion_head.py:755-1027), the same vectors tests/test_head_cpu.py pins the CPU path
+    with.  (Round 2 compared the row form with torch on the same GPU only.)"""
+    import test_head_cpu as T
+    from msmdfusion_amd import synthetic as S
+    from msmdfusion_amd.head import TransFusionHead
+    dev = torch.device("cuda:0")
+    gold = np.load(T.GOLD)
+    head = S.seeded_parameters(TransFusionHead(rows=rows, **T.CFG), seed=21).eval().to(dev)
+    x = torch.from_numpy(np.random.RandomState(22).standard_normal((2, 32, 20, 20))
+                         .astype(np.float32)).to(dev)
+    with torch.no_grad():
+        res = head(x)
+    (pred,) = res[0]
+    np.testing.assert_array_equal(head.query_labels.cpu().numpy(), gold["query_labels"])
+    for k, v in pred.items():
+        np.testing.assert_allclose(v.cpu().numpy(), gold["fs_" + k], rtol=2e-4, atol=5e-5,
+                                   err_msg="%s rows=%s" % (k, rows))
+    for i, d in enumerate(head.get_bboxes(res)):
+        np.testing.assert_array_equal(d["labels"].cpu().numpy(), gold["dec_%d_labels" % i])
+        np.testing.assert_allclose(d["scores"].cpu().numpy(), gold["dec_%d_scores" % i],
+                                   rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(d["bboxes"].cpu().numpy(), gold["dec_%d_bboxes" % i],
+                                   rtol=2e-4, atol=2e-4)

@@ -295,13 +295,19 @@ def test_split_conv_subm(dev, cin, cout, planes):
     oi, pr, nm, _ = O.get_indice_pairs(idx, 2, shape, 3, 1, 1, 1, True)
     exp = O.indice_conv_fwd(f, w, pr, nm, n, subm=True)
     edin, _ = O.indice_conv_bwd(f, w, g, pr, nm, subm=True)
+    # three planes: north_star's 1e-4 element by element.  Two planes (three products, the
+    # opt-in mode): 2e-4 element by element -- entries that are small through cancellation
+    # see the dropped 2^-16 terms -- and, against the LARGEST output, what DESIGN.md 3.1
+    # claims for it: <= 2e-5 (measured 4.3e-6; three planes 2.2e-6)
     tol = TOL if planes == 3 else 2 * TOL
+    rel = 6e-6 if planes == 3 else 2e-5
 
     nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
     wd, fd = t(w, dev), t(f, dev)
     ws = K.pack_weight_split(wd, planes)
     out = K.conv_forward_split(fd, ws, nbr, n, cout, planes)
     np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=tol, atol=tol)
+    assert np.abs(out.cpu().numpy() - exp).max() <= rel * np.abs(exp).max(), planes
     # one scheduling unit per tile: any tiling order gives bit-identical results (the
     # table travels in tile order).  With split tiles (the default) a heavy tile's sum
     # is (lower offsets) + (upper offsets): equal to rounding, and deterministic
@@ -394,11 +400,13 @@ def test_split_wgrad(dev, cin, cout, planes):
     w = np.zeros((27, cin, cout), np.float32)
     oi, pr, nm, _ = O.get_indice_pairs(idx, 2, shape, 3, 1, 1, 1, True)
     _, edw = O.indice_conv_bwd(f, w, g, pr, nm, subm=True)
-    tol = TOL if planes == 3 else 2 * TOL
+    tol = TOL if planes == 3 else 2 * TOL      # (see test_split_conv_subm)
     nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
     pairs, num = K.rulebook_pairs(nbr)
     dw = K.conv_wgrad_split(t(f, dev), t(g, dev), pairs, num, planes)
     np.testing.assert_allclose(dw.cpu().numpy(), edw, rtol=tol, atol=5 * tol)
+    # relative to the largest entry: ~1e-6 with three planes, ~5e-6 with two
+    assert np.abs(dw.cpu().numpy() - edw).max() <= (6e-6 if planes == 3 else 2e-5) * np.abs(edw).max()
     dwk = K.conv_wgrad_split(t(f, dev), t(g, dev), pairs, num, planes,
                              krsc_shape=(cout, 3, 3, 3, cin))
     assert torch.equal(dwk.view(cout, 27, cin).permute(1, 2, 0), dw)

@@ -326,6 +326,47 @@ def test_stress_voxelize_and_rulebooks(dev, stress_cloud):
     assert np.array_equal(_np(nbr_b), exp_b)
 
 
+def test_stress_batch_of_four_bitmap_index_and_virtual_cloud(dev):
+    """configs[4] as BASELINE.json states it: a BATCH of four 10-sweep clouds (~290 k points
+    each -> ~720 k voxels at 0.05 m, the regime tools/rulebook_bench.py measures) through the
+    batched voxelization and the occupancy-bitmap SubM index, bit-exact against the oracle
+    (sample by sample: neither step crosses samples); and a 200 k-point 64-channel
+    virtual-point cloud at 0.05 m through voxelization + mean VFE."""
+    from msmdfusion_amd import kernels as K
+    vs, shape = [0.05, 0.05, 0.2], [41, 2160, 2160]
+    clouds = [S.lidar_sweep(i, sweeps=10) for i in range(4)]
+    res = K.hard_voxelize_batch([t(p, dev) for p in clouds], vs, S.POINT_CLOUD_RANGE, 10, 1200000,
+                                want_voxels=False, want_mean=True)
+    idx_parts, exp_tables, base = [], [], 0
+    for b, (pts, (_, c, n, mean)) in enumerate(zip(clouds, res)):
+        ev, ec, en = O.hard_voxelize(pts, vs, S.POINT_CLOUD_RANGE, 10, 1200000)
+        assert np.array_equal(_np(c), ec) and np.array_equal(_np(n), en)
+        np.testing.assert_array_equal(_np(mean), O.voxel_mean(ev, en))
+        one = np.concatenate([np.zeros((ec.shape[0], 1), np.int32), ec], 1)
+        oi, pr, nm, osz = O.get_indice_pairs(one, 1, shape, 3, 1, 1, 1, True)
+        _, can, _ = O.canonical_rulebook(oi, pr, nm, osz, keep_rows=True)
+        tab = O.nbr_table_from_pairs(can, one.shape[0])
+        exp_tables.append(np.where(tab >= 0, tab + base, -1))
+        idx_parts.append(np.concatenate([np.full((ec.shape[0], 1), b, np.int32), ec], 1))
+        base += ec.shape[0]
+    idx = np.concatenate(idx_parts)
+    assert idx.shape[0] > 600000
+    d_idx = t(idx, dev)
+    want = np.concatenate(exp_tables, 1)
+    for method in ("bitmap", "hash"):
+        nbr = K.rulebook_subm(d_idx, 4, shape, 3, method=method)
+        assert np.array_equal(_np(nbr), want), method
+    assert np.array_equal(_np(K.rulebook_subm(d_idx, 4, shape, 3)), want)     # auto = bitmap here
+    # 64-channel virtual points at the stress voxel size (the fusion path's other input)
+    virt = S.virtual_points(0, n=200000)
+    ev, ec, en = O.hard_voxelize(virt, vs, S.POINT_CLOUD_RANGE, 10, 400000)
+    _, c, n, mean = K.hard_voxelize(t(virt, dev), vs, S.POINT_CLOUD_RANGE, 10, 400000,
+                                    want_voxels=False, want_mean=True)
+    assert np.array_equal(_np(c), ec) and np.array_equal(_np(n), en)
+    np.testing.assert_array_equal(_np(mean), O.voxel_mean(ev, en))
+    assert mean.shape[1] == 64 and ec.shape[0] > 20000
+
+
 def test_large_feature_fallback_branch(dev, monkeypatch):
     """functional._use_split sends features beyond the split kernel's 32-bit gather
     offsets (>= 4 GiB) to the fp32 kernels; the C ABI refuses them (MSMD_ERR_RANGE)
