@@ -54,6 +54,11 @@ __device__ __forceinline__ int block_range_sum(const int* __restrict__ a, int lo
   int t = 0;
 #pragma unroll
   for (int i = 0; i < BLOCK / 64; ++i) t += smem[i];
+  // ... and the next user of smem (block_excl_scan writes it without a barrier in front) must
+  // not overtake a wave still reading here.  Without this barrier a block now and then took
+  // a wrong carry: garbage positions in pair lists / row ranks, only under load (round 3:
+  // memory faults in one bench leg out of ~6 -- found by bisecting, tools/scratch/r3_bisect.sh)
+  __syncthreads();
   return t;
 }
 

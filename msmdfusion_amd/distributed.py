@@ -162,6 +162,19 @@ class TrainStep:
         if self.prefetcher is not None:
             self._submit(batch)
 
+    def drain(self):
+        """Wait for the index work still queued (the batch submitted ahead of the last step)
+        and drop it.  Call before running the module OUTSIDE this step -- an evaluation pass,
+        a sanity forward: its inline prepare() would otherwise run next to the worker's on
+        the same neighbour-search streams and scratch buffers, which one thread at a time
+        may drive."""
+        pf = self.prefetcher
+        while self._pending:
+            _, ticket = self._pending.pop(0)
+            if pf is not None:
+                pf.take(ticket)
+                pf.retire(ticket)
+
     def __call__(self, batch, next_batch=None):
         """One step on `batch`.  next_batch: the batch of the next step, or a list of the
         next steps' batches in order (a prefetcher of depth d keeps up to d of them in

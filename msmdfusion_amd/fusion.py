@@ -6,6 +6,7 @@ hot path proper; virtual points arrive here as ready [N,64] tensors
 (image_glue.get_foreground2D builds them; bev.BevTail consumes the result).
 """
 import os
+import threading
 
 import torch
 from torch import nn
@@ -122,6 +123,9 @@ def voxel_modality_split(voxel_3D, voxel_2D, batch_size, float_keys=False):
     return voxel_3D, voxel_2D, pair3, pair2
 
 
+_NN_STREAMS_LOCK = threading.Lock()     # see prepare(): the shared neighbour-search streams
+
+
 class SparseFusionPath(nn.Module):
     """extract_pts_feat's sparse section (MSMDFusion.py:421-443) behind one
     module: LiDAR clouds + per-stage virtual points -> (x[B,256,180,180],
@@ -214,17 +218,23 @@ class SparseFusionPath(nn.Module):
         # nearest voxel -> ball query -> assignment, and the four chains are independent.
         # On one stream they took 11.7 ms back to back -- longer than the feature pass
         # they hide under, i.e. the LC step time; side by side the longest one (7.5 ms) counts.
-        for i in range(4):
-            side = self._side_stream(feats.device, i) if nn_side_stream else main
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                mm.plan_stage_nn(plans[i], counts[i], B, self.fps_num_list[i],
-                                 self.radius_list[i], self.max_cluster_samples_list[i],
-                                 self.dist_thresh_list[i])
-                if nn_side_stream:
-                    plans[i]["nn3"].record_stream(main)
-                    plans[i]["ready"] = torch.cuda.Event()
-                    plans[i]["ready"].record(side)
+        # The search streams are process-wide (slots 8..11) and their scratch is per stream:
+        # ONE thread at a time may drive them.  Two prepare() calls can overlap -- a prefetcher
+        # of depth 2, or a forward pass run inline while the worker prepares the next batch
+        # (round 3: bench.py's sanity step did, and once in ~10 runs read another batch's
+        # neighbour indices) -- so the enqueue of the four chains is a critical section.
+        with _NN_STREAMS_LOCK:
+            for i in range(4):
+                side = self._side_stream(feats.device, i) if nn_side_stream else main
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    mm.plan_stage_nn(plans[i], counts[i], B, self.fps_num_list[i],
+                                     self.radius_list[i], self.max_cluster_samples_list[i],
+                                     self.dist_thresh_list[i])
+                    if nn_side_stream:
+                        plans[i]["nn3"].record_stream(main)
+                        plans[i]["ready"] = torch.cuda.Event()
+                        plans[i]["ready"].record(side)
         return dict(feats=feats, coors=coors, planned=planned, stages=stages, v2=v2,
                     idx3_5=idx3_5, s3=s3, s2=s2, plans=plans)
 

@@ -222,3 +222,11 @@ def test_train_step_pairs_each_batch_with_its_own_prepared_batch(depth):
     for _ in range(4):
         step3(data[2])
     assert all(x is data[2][0] for x, _ in seen[-4:])
+    # the step after the last one was submitted ahead: drain() waits for it and drops it, so
+    # a forward pass outside the step (evaluation, a sanity check) never runs its prepare()
+    # next to the worker's
+    assert len(step3._pending) == min(depth, 1) or len(step3._pending) == depth
+    step3.drain()
+    assert step3._pending == []
+    step3(data[2])      # and the step structure refills its queue by itself
+    assert seen[-1][0] is data[2][0]

@@ -363,6 +363,56 @@ def test_index_prefetch_matches_inline_lc(dev):
 
 
 @pytest.mark.gpu
+def test_inline_forward_next_to_a_running_prepare(dev):
+    """Two prepare() calls may overlap -- a prefetcher of depth 2, or a forward pass run inline
+    (evaluation, bench.py's sanity step) while the worker prepares the next batch.  The four
+    neighbour-search streams and their scratch are process-wide, so their enqueue is a
+    critical section (fusion._NN_STREAMS_LOCK): without it the inline pass now and then read
+    the other batch's neighbour indices (round 3: one bench run in ~10 ended with gradients
+    missing on the stage 1-3 3-D convs).  Here: the inline result must equal the sequential
+    one while a worker thread prepares OTHER batches in a loop."""
+    import threading
+    import bench
+    torch.manual_seed(0)
+    model = bench.FusionBackbone().to(dev).train()
+    mm = model.path.multimodal_middle_encoder
+    fixed = {c: torch.rand(1, c) for c in mm.in_channels_3D}
+    mm.dummy_embedding_fn = lambda c, device: fixed[c].to(device)
+    batches = [([torch.from_numpy(S.lidar_sweep(2 * i + j)).to(dev) for j in range(2)],
+                [torch.from_numpy(S.virtual_points(2 * i + j)).to(dev) for j in range(2)])
+               for i in range(3)]
+    with torch.no_grad():
+        want = model(*batches[0]).clone()
+    torch.cuda.synchronize()
+    stop = threading.Event()
+    errors = []
+
+    def worker():
+        try:
+            torch.cuda.set_device(dev)
+            side = torch.cuda.Stream(device=dev)
+            with torch.no_grad(), torch.cuda.stream(side):
+                i = 1
+                while not stop.is_set():
+                    model.prepare(*batches[i])
+                    i = 3 - i
+            side.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    th = threading.Thread(target=worker)
+    th.start()
+    try:
+        for _ in range(8):
+            with torch.no_grad():
+                got = model(*batches[0])
+            assert torch.equal(got, want)
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+
+
+@pytest.mark.gpu
 def test_prefetched_step_through_ddp(dev):
     """bench.py's N>1 step on one rank: the prepared batch travels through
     DistributedDataParallel's forward as a keyword argument (RCCL backend, world

@@ -1,18 +1,21 @@
-# copy the judged summaries from gpurun_out/ (written by tools/prof_bench.sh, tools/pmc_collect.sh
-# and the plain bench runs) into profiles/
+# copy the judged summaries of one gpurun round (tools/gpu_round.sh <tag> ...) from gpurun_out/<tag>/
+# into profiles/ under this round's prefix:   bash tools/refresh_profiles.sh r03a r03
 set -e
 cd "$(dirname "$0")/.."
-cp gpurun_out/prof_final/s_kernel_stats.csv profiles/r01_transfusion_l_kernel_stats.csv
-cp gpurun_out/prof_final_lc/s_kernel_stats.csv profiles/r01_lc_kernel_stats.csv
-cp gpurun_out/pmc/pmc_summary.json profiles/r01_pmc_summary.json
-[ -s gpurun_out/rulebook_bench.jsonl ] && grep "^{" gpurun_out/rulebook_bench.jsonl > profiles/r01_rulebook_voxelize_roofline.jsonl
-grep "^{" gpurun_out/bench_default.json | tail -1 > profiles/r01_bench_default.json
-grep "^{" gpurun_out/bench_lc.json | tail -1 > profiles/r01_bench_lc.json
-grep "^{" gpurun_out/prof_final/bench.log | tail -1 > profiles/r01_transfusion_l_bench_under_rocprof.json
-python - <<'PY'
-import json
-for f in ('profiles/r01_bench_default.json', 'profiles/r01_bench_lc.json'):
-    d = json.loads(open(f).read()); r = d.get('roofline') or {}
-    print(f, d['value'], d['ms_per_step'], r.get('kernel'), r.get('achieved'), r.get('frac'),
-          r.get('traffic'), r.get('mfma_pipe_busy_frac_pmc'), r.get('avg_launch_us'))
-PY
+TAG=${1:?gpurun_out tag}; R=${2:?profiles prefix, e.g. r03}
+G=gpurun_out/$TAG
+for wl in lc transfusion_l; do
+  P=$G/prof_$wl
+  [ -d $P ] || continue
+  cp $P/kernel_stats.csv profiles/${R}_${wl}_kernel_stats.csv
+  cp $P/summary.txt profiles/${R}_${wl}_kernel_summary.txt
+  cp $P/stream_summary.txt profiles/${R}_${wl}_stream_summary.txt
+  grep "^{" $P/bench.json | tail -1 > profiles/${R}_${wl}_bench_under_rocprof.json
+done
+[ -s $G/bench_default.json ] && grep "^{" $G/bench_default.json | tail -1 > profiles/${R}_bench_default.json
+[ -s $G/rulebook_voxelize_roofline.jsonl ] && grep "^{" $G/rulebook_voxelize_roofline.jsonl > profiles/${R}_rulebook_voxelize_roofline.jsonl
+[ -s $G/fps.txt ] && cp $G/fps.txt profiles/${R}_fps.txt
+for wl in lc transfusion_l; do
+  [ -s $G/pmc_$wl/pmc_summary.json ] && cp $G/pmc_$wl/pmc_summary.json profiles/${R}_pmc_summary_$wl.json
+done
+ls -la profiles | grep " ${R}_"
