@@ -270,6 +270,44 @@ def test_strided_conv_fwd_bwd(dev, ks, st, pd, cin, cout):
     np.testing.assert_allclose(dw.cpu().numpy(), edw, rtol=TOL, atol=TOL * 5)
 
 
+def test_scans_do_not_depend_on_what_else_runs(dev):
+    """The scan-based index kernels (pair-list compaction, strided rulebook ranks, sparse_add
+    maps) give the same tables while another stream keeps the chip busy with persistent conv
+    kernels.  Round 3: block_range_sum left its LDS scratch unguarded and a block now and then
+    took a wrong carry -- only when its waves were descheduled in between, i.e. under load.
+    (An invariance check, not a reproducer: the library without the barrier passes this too;
+    what exposed it was the training step itself, one bench leg in ~6 --
+    tools/scratch/seq_repro.py repeats legs in one process.)"""
+    from msmdfusion_amd import kernels as K
+    shape = [21, 160, 160]
+    idx = t(S.random_voxel_indices(60000, 2, shape, seed=5), dev)
+    nbr = K.rulebook_subm(idx, 2, shape, 3)
+    n = nbr.shape[1]
+    want_pairs, want_num = K.rulebook_pairs(nbr)
+    want_conv = K.rulebook_conv(idx, 2, shape, 3, 2, 1)
+    idx_b = t(S.random_voxel_indices(50000, 2, shape, seed=6), dev)
+    want_add = K.sparse_add_index(idx, idx_b, 2, shape)
+    order = K.rulebook_tiling(nbr, want_table=False)[0]
+    tab = K.permute_cols(nbr, order)
+    pre = K.tile_prefix(tab, K.split_tile_rows(64))
+    f = torch.randn(n, 64, device=dev)
+    g = torch.randn(n, 64, device=dev)
+    ws = K.pack_weight_split(torch.randn(27, 64, 64, device=dev) * 0.05, 3)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for _ in range(120):
+        with torch.cuda.stream(side):    # one whole-CU workgroup per CU, 144 KB of LDS each
+            K.conv_wgrad_split(f, g, want_pairs, want_num, 3)
+            K.conv_forward_split(f, ws, tab, n, 64, 3, row_order=order, tile_prefix=pre)
+        pairs, num = K.rulebook_pairs(nbr)
+        assert torch.equal(num, want_num) and torch.equal(pairs, want_pairs)
+        got = K.rulebook_conv(idx, 2, shape, 3, 2, 1)
+        assert all(torch.equal(a, b) for a, b in zip(got[:3], want_conv[:3]))
+        add = K.sparse_add_index(idx, idx_b, 2, shape)
+        assert all(torch.equal(a, b) for a, b in zip(add, want_add))
+    torch.cuda.synchronize()
+
+
 # --------------------------------------------- split-bf16 ("fp32-equivalent") convolution
 SPLIT_CHANNELS = [(32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (96, 96), (64, 32),
                   (128, 64), (128, 96),

@@ -1,6 +1,9 @@
 cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$GRAFT_REPO_ROOT
-L="2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:transfusion_l 2:lc_b4 2:lc_b4 2:lc_b4 2:lc_b4 2:lc_b4 2:lc_b4"
-timeout 600 python -X faulthandler tools/scratch/seq_repro.py $L 2>&1 | grep -v "amdgpu.ids\|steps_total" > /tmp/out.txt
-echo "legs completed of 22: $(grep -c '^2:[a-z_0-9]* [0-9]' /tmp/out.txt)"
-grep -v '^2:[a-z_0-9]* [0-9]' /tmp/out.txt | head -5 | cut -c1-200
+echo "== fixed library"
+timeout 300 python -m pytest tests/test_gpu_kernels.py -x -q -k "scans_do_not_depend" 2>&1 | tail -3
+cp msmdfusion_amd/libmsmd_hip.so /tmp/good.so
+cp msmdfusion_amd/libmsmd_hip_bug.so msmdfusion_amd/libmsmd_hip.so
+echo "== library without the barrier"
+timeout 300 python -m pytest tests/test_gpu_kernels.py -x -q -k "scans_do_not_depend" 2>&1 | tail -6 | cut -c1-200
+cp /tmp/good.so msmdfusion_amd/libmsmd_hip.so
