@@ -555,7 +555,8 @@ def pmc_traffic(kernel_name, workload):
     else:   # wgrad: whichever instantiation of the split kernel ran most (the lean
         #     buffer-load variant is spconv_wgrad_split_buf_kernel<planes, groups>)
         stem = kernel_name.replace("_kernel", "")
-        cands = [k for k in kernels if k.startswith(stem)]
+        # (round 3: widths that are multiples of 16 run spconv_wgrad_block_kernel<planes>)
+        cands = [k for k in kernels if k.startswith(stem) or k.startswith("spconv_wgrad_block")]
         key = max(cands, key=lambda k: kernels[k].get("launches_sampled", 0)) if cands else None
     e = kernels.get(key, {})
     return e.get("hbm_bytes_per_launch"), e.get("mfma_pipe_busy_frac"), os.path.relpath(path, ROOT)
