@@ -203,25 +203,15 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
   }
 }
 
-// Tuning knobs (defaults chosen from on-device sweeps, tools/conv_sweep.py);
-// MSMD_FWD_SLOTS / MSMD_FWD_R override them for experiments.
+// Tuning constants chosen from on-device sweeps (tools/scratch/conv_sweep.py; the environment
+// overrides of rounds 1-2 -- MSMD_FWD_SLOTS / _R / _PIPE / _KC, MSMD_PIPE_MIN_NT,
+// MSMD_NARROW_ORDER, MSMD_WGRAD_MULTISLAB -- are gone: measured, decided).
 inline int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
-inline int fwd_slots_per_cu() {
-  static const int v = env_int("MSMD_FWD_SLOTS", 3);
-  return v;
-}
-inline int fwd_rows_variant() {  // 0 = per-NT default, 1 / 2 = force R
-  static const int v = env_int("MSMD_FWD_R", 0);
-  return v;
-}
-
-inline int fwd_pipe_enabled() {
-  static const int v = env_int("MSMD_FWD_PIPE", 1);
-  return v;
-}
+inline int fwd_slots_per_cu() { return 3; }
+inline int fwd_rows_variant() { return 0; }   // 0 = per-NT default
 
 // ---------------------------------------------------- pipelined forward ----
 // Same math and tiling as spconv_fwd_kernel, restructured so that no memory
@@ -440,13 +430,6 @@ int dispatch_fwd_pipe(const float* in, int cin, const float* wp, const int32_t* 
                       int n_out, int kvol, int flip, const int32_t* order, int* tile_counter,
                       float* out, int cout, hipStream_t st) {
   const int T = cin / 16;
-  static const int kc_force = env_int("MSMD_FWD_KC", 0);
-  if (kc_force == 1 || (kc_force == 2 && T % 2 != 0))
-    return launch_fwd_pipe<NT, R, 1>(in, cin, wp, nbr, ld, n_out, kvol, flip, order, tile_counter,
-                                     out, cout, st);
-  if (kc_force == 2)
-    return launch_fwd_pipe<NT, R, 2>(in, cin, wp, nbr, ld, n_out, kvol, flip, order,
-                                     tile_counter, out, cout, st);
   if (NT <= 8 && T % 4 == 0)
     return launch_fwd_pipe<NT, R, 4>(in, cin, wp, nbr, ld, n_out, kvol, flip, order,
                                      tile_counter, out, cout, st);
@@ -462,9 +445,7 @@ int launch_fwd(const float* in, int cin, const float* wp, const int32_t* nbr, in
                int kvol, int flip, const int32_t* order, int* tile_counter, float* out, int cout,
                hipStream_t st) {
   // narrow layers too (c_in % 16 == 0): 16->16 34 -> 21 us, strided 16->32 65 -> 47, bit-identical
-  static const int pipe_min_nt = env_int("MSMD_PIPE_MIN_NT", 1);
-  if (fwd_pipe_enabled() && (cin & 15) == 0 && (cout & 3) == 0 && kvol <= kMaxK &&
-      NT >= pipe_min_nt)
+  if ((cin & 15) == 0 && (cout & 3) == 0 && kvol <= kMaxK)
     return dispatch_fwd_pipe<NT, R>(in, cin, wp, nbr, ld, n_out, kvol, flip, order, tile_counter,
                                     out, cout, st);
   const int rows_per_block = 4 * R * 16;
@@ -888,9 +869,9 @@ MSMD_EXPORT int msmd_spconv_fwd_f32(const float* in_feat, int n_in, int c_in,
   if (!packed_weight || !nbr || !out_feat || (n_in > 0 && !in_feat)) return MSMD_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int NT = (c_out + 15) / 16;
-  // sorted order + persistent scheduler on them: 16->16 21 -> 36 us (scattered rows), off
-  static const int narrow_order = env_int("MSMD_NARROW_ORDER", 0);
-  if (NT < 4 && !narrow_order) {  // (was: narrow layers in natural row order, static grid)
+  // (sorted order + persistent scheduler on the narrow layers: 16->16 21 -> 36 us --
+  // scattered rows; they run in natural row order on a static grid)
+  if (NT < 4) {
     row_order = nullptr;
     tile_counter = nullptr;
   }
@@ -930,14 +911,10 @@ void launch_wgrad(int chunk, dim3 grid, hipStream_t st, const float* in_feat, in
                   int nchunks, float* ws) {
   // vector loads need every row 4*S-byte aligned on both sides
   const bool vec = c_in % SA == 0 && c_out % SB == 0;
-  // slabs per workgroup: 4 when the slab grid allows it (and 2x2 of them share
-  // rows), else 2 along c_out, else 1
-  // (measured on the 128x128 layers: 4 slabs per workgroup = 4x longer, 4x fewer
-  // workgroups -- 671 us against 516 us for one slab each; kept for experiments)
-  const int n_slabs = (int)grid.z, nb = ceil_div(c_out, 16 * SB);
-  static const int multi = env_int("MSMD_WGRAD_MULTISLAB", 0);
-  const int spw = !multi ? 1 : ((n_slabs % 4 == 0 && nb % 2 == 0) ? 4 : (nb % 2 == 0 ? 2 : 1));
-  const int kvol = (int)grid.y, groups = n_slabs / spw;
+  // one slab per workgroup (measured on the 128x128 layers: 4 slabs per workgroup sharing
+  // rows = 4x longer, 4x fewer workgroups -- 671 us against 516 us; removed)
+  const int n_slabs = (int)grid.z;
+  const int kvol = (int)grid.y, groups = n_slabs;
   const dim3 grid1(wgrad_grid(nchunks, kvol, groups));
 #define MSMD_GOW(C_, V_, W_)                                                                  \
   MSMD_LAUNCH((spconv_wgrad_kernel<SA, SB, C_, V_, W_>), grid1, dim3(256), 0, st, in_feat,    \
@@ -945,11 +922,11 @@ void launch_wgrad(int chunk, dim3 grid, hipStream_t st, const float* in_feat, in
 #define MSMD_GOV(C_, W_)                                                                      \
   if (vec) MSMD_GOW(C_, true, W_); else MSMD_GOW(C_, false, W_)
   if (chunk == 512) {
-    if (spw == 4) { MSMD_GOV(512, 1); } else if (spw == 2) { MSMD_GOV(512, 2); } else { MSMD_GOV(512, 4); }
+    MSMD_GOV(512, 4);
   } else if (chunk == 1024) {
-    if (spw == 4) { MSMD_GOV(1024, 1); } else if (spw == 2) { MSMD_GOV(1024, 2); } else { MSMD_GOV(1024, 4); }
+    MSMD_GOV(1024, 4);
   } else {
-    if (spw == 4) { MSMD_GOV(2048, 1); } else if (spw == 2) { MSMD_GOV(2048, 2); } else { MSMD_GOV(2048, 4); }
+    MSMD_GOV(2048, 4);
   }
 #undef MSMD_GOV
 #undef MSMD_GOW

@@ -269,10 +269,7 @@ constexpr int kSkMinRanks = 64;  // stream-K: smallest segment (cost units) wort
 // the whole chip is doing at that moment (everybody starts in dense tiles), not the tile.
 // 12 keeps the term as a tie-breaker.
 constexpr int kSkC1Default = 12;
-inline int sk_c1() {   // MSMD_SK_C1 overrides (experiments)
-  static const int v = [] { const char* e = getenv("MSMD_SK_C1"); return e ? atoi(e) : kSkC1Default; }();
-  return v;
-}
+inline int sk_c1() { return kSkC1Default; }
 
 // ------------------------------------------------------- forward / dgrad --
 // One workgroup = 4 waves x 32 output rows (two 16-row MFMA groups per wave) x
@@ -348,10 +345,6 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
   constexpr int R = 2, kRows = WV * R * 16, kRowShift = WV == 4 ? 7 : 8;
   constexpr int kUnitU = NP * NT * 64;  // 16-byte units of one unit's weights (in LDS)
   constexpr int kWU = UB * kUnitU;
-#ifndef MSMD_FWD_EMBED
-#define MSMD_FWD_EMBED 0   // measured: 256 vs 258 us on 128->128 -- no gain, see MSMD_ITEM1
-#endif
-  constexpr bool kEmbedIssue = MSMD_FWD_EMBED != 0;   // see MSMD_ITEM1
   constexpr int kGr = R * 2;            // gather loads per unit per lane
   constexpr int kPw = (NP * NT + WV - 1) / WV;  // weight DMA ops per unit per wave
   constexpr int kWp = UB * kPw;           // ... per item per wave
@@ -554,7 +547,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
     // next unit's rows raw_n -> b_n, a quarter (4 channels of one row group) per
     // fragment step, interleaved with the MFMAs.
     // `during(st)`: memory-op issue work the caller wants done UNDER this unit's MFMAs
-    // (called once per fragment step, between two MFMA groups; see MSMD_ITEM1)
+    // (called once per fragment step, between two MFMA groups)
     auto compute = [&](int it, int u, const u32x4 (&b)[R][NP], int valid,
                        const u32x4 (&raw_n)[R][2], u32x4 (&b_n)[R][NP], auto&& during) {
       if (!__any(valid >= 0) || (dbg & 4)) {
@@ -683,65 +676,19 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
     if (UB > 2) { MSMD_SLOT_UNIT(IT, 2, (PH)*UB + 2) }                                 \
     if (UB > 3) { MSMD_SLOT_UNIT(IT, 3, (PH)*UB + 3) }                                 \
   }
-    // UB == 1 (one unit per item: the 96-128-channel layers).  Measured per item there
-    // (PROF build): top wait 785, barrier 206, weight-DMA issue 496, gather issue + index
-    // fetch 534, wait for rows 242, MFMAs + conversion 2047, glue 291 cycles -- the two
-    // issue phases are a quarter of the item and run BEFORE the MFMAs.  Nothing forces
-    // that: the weight buffer written is the OTHER one, the raw slot gathered into was
-    // vacated a unit ago, and the rows this unit converts were drained at the item top.  So
-    // here they are issued between the MFMA groups of the unit (fragment steps 0 and 1..),
-    // and the only wait left is the drain at the top (which covers what `wait_rows` waited
-    // for).  RESULT: correct (all split-conv tests), and no faster -- 256 against 258 us on the
-    // 128->128 layer in the same call: the issue cycles moved under the MFMAs stretch the
-    // MFMA stream by as much.  Compiled out by default (make EXTRA=-DMSMD_FWD_EMBED=1).
-#define MSMD_UNIT1(IT, RAW_C, V_C, CV_C, RAW_N, V_N, CV_N)                                  \
-  {                                                                                          \
-    const int v_cur = V_C;                                                                   \
-    wait_rows<0>(RAW_N);   /* (drained at the top; this ties the registers to that wait) */  \
-    compute((IT), 0, CV_C, v_cur, RAW_N, CV_N, [&](int st) {                                 \
-      if (st == 0) {                                                                         \
-        issue_g(RAW_C, V_C);                                                                 \
-        load_src();                                                                          \
-      } else if (st == 1) {                                                                  \
-        issue_w((IT) + 1);                                                                   \
-      }                                                                                      \
-    });                                                                                      \
-    KP_MARK(5);                                                                              \
-  }
-#define MSMD_ITEM1(IT, PH)                                                                  \
-  {                                                                                          \
-    if ((IT) == 1 && tid == 0) {                                                             \
-      ctl[2] = nxt_v;                                                                        \
-      ctl[tb ^ 1] = 0;                                                                       \
-      if (!sk && nxt_v == last_ticket) *tile_counter = 0;                                    \
-    }                                                                                        \
-    KP_MARK(6);                                                                              \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
-    KP_MARK(0);                                                                              \
-    __builtin_amdgcn_s_barrier();                                                            \
-    KP_MARK(1);                                                                              \
-    if ((IT) == 1) {                                                                         \
-      nxt = __builtin_amdgcn_readfirstlane(ctl[2]);                                          \
-      if (nxt < tile_lim) stage_table(nxt, tb ^ 1);                                          \
-      staged = true;                                                                         \
-    }                                                                                        \
-    if ((PH) == 0) MSMD_UNIT1(IT, raw0, vr0, cv0, raw1, vr1, cv1)                            \
-    else MSMD_UNIT1(IT, raw1, vr1, cv1, raw0, vr0, cv0)                                      \
-  }
+    // (Tried for UB == 1, the 96-128-channel layers, where a PROF build showed per item:
+    // top wait 785, barrier 206, weight-DMA issue 496, gather issue + index fetch 534, wait
+    // for rows 242, MFMAs + conversion 2047, glue 291 cycles: issuing the weight DMA and the
+    // gathers BETWEEN the MFMA groups of the unit instead of in front of them.  Correct, and
+    // no faster -- 256 against 258 us on the 128->128 layer in the same call: the issue cycles
+    // moved under the MFMAs stretch the MFMA stream by as much.  Removed in round 3.)
     KP_BEGIN();
 #ifdef MSMD_KERNEL_PROF
     const unsigned long long kt0 = wall_clock64();
 #endif
-    if constexpr (UB == 1 && NS >= 2 && kEmbedIssue) {
-      for (int it = 0; it < n_items; it += 2) {
-        MSMD_ITEM1(it, 0);
-        if (it + 1 < n_items) MSMD_ITEM1(it + 1, 1);
-      }
-    } else {
-      for (int it = 0; it < n_items; it += 2) {
-        MSMD_ITEM(it, 0);
-        if (it + 1 < n_items) MSMD_ITEM(it + 1, 1);
-      }
+    for (int it = 0; it < n_items; it += 2) {
+      MSMD_ITEM(it, 0);
+      if (it + 1 < n_items) MSMD_ITEM(it + 1, 1);
     }
 #ifdef MSMD_KERNEL_PROF
     if (lane == 0 && wave == 1 && blockIdx.x < 8) atomicAdd(&g_kprof[7], (unsigned long long)n_items);
@@ -856,10 +803,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
   }
 }
 
-int split_slots_per_cu() {
-  static const int v = env_int2("MSMD_SPLIT_SLOTS", 2);
-  return v;
-}
+int split_slots_per_cu() { return 2; }
 
 template <int NT, int UB, int NP, int WV>
 int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
@@ -868,10 +812,9 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
                      void* scratch, int* flags, const int32_t* tile_start, int sk_grid,
                      hipStream_t st) {
   // stream-K: a tile visit's fixed cost in units (offset x k-block) of this instantiation,
-  // charged per tile in ranks of ceil(cin / 32) units each (MSMD_SK_OVH overrides)
-  static const int ovh_env = env_int2("MSMD_SK_OVH", -1);
+  // charged per tile in ranks of ceil(cin / 32) units each
   // (swept 0..48 on the bench layers: 8 is within 2 % of the best for every width)
-  const int ovh_units = ovh_env >= 0 ? ovh_env : 8;
+  const int ovh_units = 8;
   const int kbt = (cin + 31) / 32;
   const int sk_c0 = ((ovh_units + kbt - 1) / kbt) * (sk_c1() + 2);   // in cost units
   constexpr int kRows = WV * 32;
@@ -895,16 +838,14 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
 }
 
 // Waves per workgroup / rows per tile of the split kernel (see the kernel): 4 x 128 rows,
-// two workgroups per CU.  MSMD_FWD_WAVES=8 selects the 8-wave / 256-row instantiations
-// (one workgroup per CU, one weight stream per CU, two units per weight buffer for the wide
-// layers): measured within +-5 % of the 4-wave ones on the 128-/192-channel layers (260 vs
-// 259-268 us on 128->128) and 25 % slower on the 80-channel ones -- the two waves of a SIMD
-// then belong to the same workgroup and stall at its barriers together.  Kept as an
-// experiment knob.
+// two workgroups per CU.  (The 8-wave / 256-row instantiations of round 2 -- one workgroup
+// and one weight stream per CU -- measured within +-5 % on the 128-/192-channel layers and
+// 25 % slower on the 80-channel ones: the two waves of a SIMD then belong to one workgroup
+// and stall at its barriers together.  Removed in round 3; the kernel keeps its WV
+// parameter.)
 int fwd_waves(int cout) {
   (void)cout;
-  static const int force = env_int2("MSMD_FWD_WAVES", 0);
-  return force == 8 ? 8 : 4;
+  return 4;
 }
 // stream-K: workgroups (= segments = exchange slots) of a launch over `row_tiles` tiles,
 // and the exchange buffer: one pass's accumulators of one tile per workgroup
@@ -919,7 +860,7 @@ size_t fwd_sk_ws_bytes(int n_out, int kvol, int cout) {
   int per = (nt_total + n_pass - 1) / n_pass;
   per = per > 6 ? 8 : per > 4 ? 6 : per > 2 ? 4 : 2;      // the instantiation's NT
   size_t need = 0;
-  for (int waves = 4; waves <= 8; waves += 4) {            // whichever the dispatch picks
+  for (int waves = 4; waves <= 4; waves += 4) {
     const int rows = waves * 32;
     const size_t b = (size_t)sk_grid_size(ceil_div(n_out > 0 ? n_out : 0, rows), kvol, waves) *
                      rows * 16 * per * sizeof(float);
@@ -961,23 +902,10 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
   rc = launch_fwd_split<NT_, UB_, NP, WV_>(in, n_in, cin, wp, nbr, ld, n_out, kvol, flip, order, \
                                            tile_counter, o, cout, width, nt_total, mt0, ws,      \
                                            flags, tile_start, sk_grid, st)
-    static const int ub8 = env_int2("MSMD_FWD_UB8", 2);   // units per item of the 8-wave kernels
-    if (waves == 8 && ub8 == 2 && tiles > 4) {
-      // two units per weight buffer: 2 x 48 KiB + 57 KiB of tables = 153 KiB, one barrier
-      // and one queue drain per 192 MFMAs of a wave instead of per 96
-      if (tiles > 6) { MSMD_GO(8, 2, 8); }
-      else { MSMD_GO(6, 2, 8); }
-    } else if (waves == 8) {
-      if (tiles > 6) { MSMD_GO(8, 1, 8); }
-      else if (tiles > 4) { MSMD_GO(6, 1, 8); }
-      else if (tiles > 2) { MSMD_GO(4, 2, 8); }
-      else { MSMD_GO(2, 4, 8); }
-    } else {
-      if (tiles > 6) { MSMD_GO(8, 1, 4); }
-      else if (tiles > 4) { MSMD_GO(6, 1, 4); }
-      else if (tiles > 2) { MSMD_GO(4, 2, 4); }
-      else { MSMD_GO(2, 4, 4); }
-    }
+    if (tiles > 6) { MSMD_GO(8, 1, 4); }
+    else if (tiles > 4) { MSMD_GO(6, 1, 4); }
+    else if (tiles > 2) { MSMD_GO(4, 2, 4); }
+    else { MSMD_GO(2, 4, 4); }
 #undef MSMD_GO
     if (rc != MSMD_OK) return rc;
   }

@@ -31,18 +31,16 @@ namespace {
 __global__ __launch_bounds__(256) void finish_kernel(const int32_t* __restrict__ nbr, int kvol,
                                                      int n, const int32_t* __restrict__ sorted,
                                                      const int32_t* __restrict__ tile_seq,
-                                                     int full, int rows, int zigzag,
+                                                     int full, int rows,
                                                      int32_t* __restrict__ order,
                                                      int32_t* __restrict__ tiled) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
   const int t = p / rows;
-  // zigzag (MSMD_TILE_ZIGZAG=1, experiment): position 2i takes the i-th heaviest tile, 2i+1
-  // the i-th lightest, so that every stream-K segment holds dense and light-mask tiles
-  // alike.  Measured no gain (266 vs 263 us on 128->128) and it costs the dynamic tile
-  // scheduler its heaviest-first order (418 vs 385 us): off.
-  const int ts = !zigzag ? t : (t & 1) ? full - 1 - (t >> 1) : (t >> 1);
-  const int src = t < full ? tile_seq[ts] * rows + (p - t * rows) : p;
+  // (tried: a zigzag sequence -- position 2i the i-th heaviest tile, 2i+1 the i-th lightest
+  // -- so that every stream-K segment holds dense and light-mask tiles alike: no gain, 266
+  // against 263 us on 128->128, and the dynamic scheduler lost its heaviest-first order)
+  const int src = t < full ? tile_seq[t] * rows + (p - t * rows) : p;
   const int row = sorted[src];
   order[p] = row;
   if (tiled)
@@ -122,9 +120,8 @@ MSMD_EXPORT int msmd_rulebook_tiling(const int32_t* nbr, int kernel_volume, int 
                                            full, 0, 6, st) != hipSuccess)   // cost <= 31
       return MSMD_ERR_LAUNCH;
   }
-  static const int zigzag = [] { const char* e = getenv("MSMD_TILE_ZIGZAG"); return e ? atoi(e) : 0; }();
   MSMD_LAUNCH(finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, nbr, kernel_volume, n,
-              w.sorted, w.tile_seq, full > 1 && lpt ? full : 0, rows_per_tile, zigzag, order, tiled);
+              w.sorted, w.tile_seq, full > 1 && lpt ? full : 0, rows_per_tile, order, tiled);
   return launch_status();
 }
 
