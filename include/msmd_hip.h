@@ -529,6 +529,25 @@ int msmd_gma_assemble_bwd_f32(const float* d_out, int n_o3, int c3, int n3, int 
                               msmd_stream_t stream);
 size_t msmd_gma_assemble_bwd_workspace_floats(int c2);
 
+/* a16  the stage's gate tables: gate_control / cross_gate_control =
+ * nn.Sequential(nn.Linear(c3, 64), nn.ReLU()) applied to the rows of the 3-D voxels
+ * replaces: torch's Linear + ReLU (hipBLASLt GEMM + elementwise) at
+ *           sparse_multimodal_encoder_painting.py:83-96 (definition), :398-417 (use)
+ * y[n + n_tail, c_out] = relu?(cat(x, x_tail) w^T + b), w = nn.Linear's [c_out, c_in]
+ * (x_tail: the dummy embedding row the reference concatenates, no copy of x needed);
+ * backward: dw = g^T x, db = column sums of g, g = dy where y > 0 -- per-block partials
+ * added in block order (deterministic).  c_out in {32, 64, 128}, c_in % 4 = 0
+ * (msmd_rows_linear_supported). */
+int msmd_rows_linear_supported(int c_in, int c_out);
+int msmd_rows_linear_fwd_f32(const float* x, int n, const float* x_tail, int n_tail, int c_in,
+                             const float* w, const float* b /* or NULL */, int c_out, int relu,
+                             float* y, msmd_stream_t stream);
+size_t msmd_rows_linear_bwd_workspace_bytes(int n_total, int c_in, int c_out);
+int msmd_rows_linear_bwd_f32(const float* x, int n, const float* x_tail, int n_tail, int c_in,
+                             const float* y, const float* dy, int c_out, int relu,
+                             float* dw /* [c_out,c_in] */, float* db /* [c_out] or NULL */,
+                             void* workspace, size_t workspace_bytes, msmd_stream_t stream);
+
 /* ------------------------------------------------------------------------ *
  * a14  voxel_modality_split: LiDAR voxels vs virtual-point voxels
  * replaces: MSMDFusionDetector.voxel_modality_split + numba type_assign

@@ -102,6 +102,11 @@ SIGNATURES = {
     "msmd_gma_assemble_bwd_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _vp]),
     "msmd_gma_assemble_bwd_workspace_floats": (_sz, [_i]),
+    "msmd_rows_linear_supported": (_i, [_i, _i]),
+    "msmd_rows_linear_fwd_f32": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "msmd_rows_linear_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "msmd_rows_linear_bwd_f32": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz,
+                                      _vp]),
     "msmd_modality_split_workspace_bytes": (_sz, [_i, _ip]),
     "msmd_modality_split": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "msmd_modality_split_stats": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,

@@ -189,6 +189,214 @@ bool fill_args(GmaArgs& A, const float* conv3, int n_o3, int c3, const float* cr
   return true;
 }
 
+
+// ---------------------------------------------------------------- gate linears --
+// gate_control / cross_gate_control: nn.Sequential(nn.Linear(c3, 64), nn.ReLU()) over the
+// rows of a stage's 3-D voxels (sparse_multimodal_encoder_painting.py:83-96, applied at
+// :398-417).  hipBLASLt's fp32 GEMM took 170-230 us per call on these skinny shapes
+// ([75k..150k] x [16..128] x 64: under 1 GFLOP, 57 MB of traffic) and the step makes 16 of
+// them; they are row-streaming passes: y = relu(x W^T + b) with W in LDS, and for backward
+// per-block partial sums of dW = g^T x, db = sum g (g = dy where y > 0), added in block
+// order (fixed: deterministic).  fp32 FMAs in k order; results differ from the GEMM's by
+// its different summation order only (~1e-7 relative).
+constexpr int kLinRowsPerBlock = 256;   // forward: rows per block (whole passes of 32..128)
+constexpr int kLinBwdRows = 256;        // backward: rows per partial block
+constexpr int kLinBwdTile = 32;         // ... staged in LDS this many at a time
+
+__global__ __launch_bounds__(256) void rows_linear_fwd_kernel(
+    const float* __restrict__ x, int n, const float* __restrict__ x_tail, int n_tail, int cin,
+    const float* __restrict__ w, const float* __restrict__ b, int cout, int relu,
+    float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float lin_smem[];
+  constexpr int RT = 4;                      // rows per thread: a W piece read from LDS serves 4
+  float* wt = lin_smem;                      // [cin][cout]: W transposed
+  const int xs_ld = cin + 4;                 // (+4: rows of a pass land in different banks)
+  float* xs = wt + cin * cout;               // [rows per pass][xs_ld]
+  const int cg = cout >> 2, rg = 256 / cg;   // column groups of 4, row groups per pass
+  const int rpp = rg * RT;                   // rows per pass
+  const int tid = threadIdx.x;
+  // (LDS writes in address order; w is a few KB and comes from L1/L2 either way)
+  for (int e = tid; e < cin * cout; e += 256) {
+    const int k = e / cout, co = e - k * cout;
+    wt[e] = w[co * cin + k];
+  }
+  const int g = tid % cg, r = tid / cg;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (b) bias = *(const f32x4*)(b + 4 * g);
+  const long total = (long)n + n_tail;
+  const long row0 = (long)blockIdx.x * kLinRowsPerBlock;
+  const int c4 = cin >> 2;
+  // a pass's x tile = rpp * c4 16-byte pieces, at most kLinFwdPre per thread (cin <= 4 cout);
+  // the next pass's pieces are loaded into registers while this one is multiplied
+  constexpr int kLinFwdPre = 4 * RT;
+  f32x4 pre[kLinFwdPre];
+  auto fetch = [&](int p0) {
+#pragma unroll
+    for (int u = 0; u < kLinFwdPre; ++u) {
+      const int e = tid + 256 * u;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < rpp * c4) {
+        const int rr = e / c4, k4 = e - rr * c4;
+        const long row = row0 + p0 + rr;
+        if (row < n) v = *(const f32x4*)(x + row * cin + 4 * k4);
+        else if (row < total) v = *(const f32x4*)(x_tail + (row - n) * cin + 4 * k4);
+      }
+      pre[u] = v;
+    }
+  };
+  fetch(0);
+  for (int p0 = 0; p0 < kLinRowsPerBlock; p0 += rpp) {
+    if (row0 + p0 >= total) break;
+    __syncthreads();   // wt filled (first pass) / the previous pass's xs consumed
+#pragma unroll
+    for (int u = 0; u < kLinFwdPre; ++u) {
+      const int e = tid + 256 * u;
+      if (e < rpp * c4) {
+        const int rr = e / c4, k4 = e - rr * c4;
+        *(f32x4*)(xs + rr * xs_ld + 4 * k4) = pre[u];
+      }
+    }
+    __syncthreads();
+    if (p0 + rpp < kLinRowsPerBlock) fetch(p0 + rpp);
+    f32x4 acc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = bias;
+    for (int k = 0; k < cin; k += 4) {
+      f32x4 xv[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) xv[t] = *(const f32x4*)(xs + (r + rg * t) * xs_ld + k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 wv = *(const f32x4*)(wt + (k + j) * cout + 4 * g);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] += xv[t][j] * wv;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const long row = row0 + p0 + r + rg * t;
+      if (row >= total) continue;
+      f32x4 a = acc[t];
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = a[j] > 0.f ? a[j] : 0.f;
+      }
+      *(f32x4*)(y + row * cout + 4 * g) = a;
+    }
+  }
+}
+
+// part[blk][cout * cin + cout]: this block's dW (as [cout][cin]) and db
+template <int CPT>
+__global__ __launch_bounds__(256) void rows_linear_bwd_partial_kernel(
+    const float* __restrict__ x, int n, const float* __restrict__ x_tail, int n_tail, int cin,
+    const float* __restrict__ y, const float* __restrict__ dy, int cout, int relu,
+    float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float lin_smem[];
+  const int xs_ld = cin + 4;
+  float* gs = lin_smem;                         // [tile][cout]
+  float* xs = gs + kLinBwdTile * cout;          // [tile][xs_ld]
+  const int tid = threadIdx.x;
+  const int co = tid % cout, grp = tid / cout;  // this thread: dW[co][grp * CPT .. + CPT)
+  float acc[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
+  float accb = 0.f;
+  const long total = (long)n + n_tail;
+  const long row0 = (long)blockIdx.x * kLinBwdRows;
+  const int c4 = cin >> 2, o4 = cout >> 2;
+  // the next tile's pieces travel in registers while this one is accumulated
+  constexpr int kPreG = kLinBwdTile * 32 / 256, kPreX = kLinBwdTile * 64 / 256;   // cout <= 128, cin <= 256
+  f32x4 pg[kPreG], px[kPreX];
+  auto fetch = [&](int p0) {
+#pragma unroll
+    for (int u = 0; u < kPreG; ++u) {
+      const int e = tid + 256 * u;
+      f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+      if (e < kLinBwdTile * o4) {
+        const int rr = e / o4, q = e - rr * o4;
+        const long row = row0 + p0 + rr;
+        if (row < total) {
+          gv = *(const f32x4*)(dy + row * cout + 4 * q);
+          if (relu) {
+            const f32x4 yv = *(const f32x4*)(y + row * cout + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+          }
+        }
+      }
+      pg[u] = gv;
+    }
+#pragma unroll
+    for (int u = 0; u < kPreX; ++u) {
+      const int e = tid + 256 * u;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < kLinBwdTile * c4) {
+        const int rr = e / c4, k4 = e - rr * c4;
+        const long row = row0 + p0 + rr;
+        if (row < n) v = *(const f32x4*)(x + row * cin + 4 * k4);
+        else if (row < total) v = *(const f32x4*)(x_tail + (row - n) * cin + 4 * k4);
+      }
+      px[u] = v;
+    }
+  };
+  fetch(0);
+  for (int p0 = 0; p0 < kLinBwdRows; p0 += kLinBwdTile) {
+    if (row0 + p0 >= total) break;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPreG; ++u) {
+      const int e = tid + 256 * u;
+      if (e < kLinBwdTile * o4) *(f32x4*)(gs + (e / o4) * cout + 4 * (e % o4)) = pg[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kPreX; ++u) {
+      const int e = tid + 256 * u;
+      if (e < kLinBwdTile * c4) *(f32x4*)(xs + (e / c4) * xs_ld + 4 * (e % c4)) = px[u];
+    }
+    __syncthreads();
+    if (p0 + kLinBwdTile < kLinBwdRows) fetch(p0 + kLinBwdTile);
+#pragma unroll 4
+    for (int rr = 0; rr < kLinBwdTile; ++rr) {
+      const float gv = gs[rr * cout + co];
+      const float* xr = xs + rr * xs_ld + grp * CPT;
+#pragma unroll
+      for (int j = 0; j < CPT; j += 4) {
+        const f32x4 xv = *(const f32x4*)(xr + j);
+        acc[j] += gv * xv[0];
+        acc[j + 1] += gv * xv[1];
+        acc[j + 2] += gv * xv[2];
+        acc[j + 3] += gv * xv[3];
+      }
+      accb += gv;
+    }
+  }
+  float* out = part + (size_t)blockIdx.x * ((size_t)cout * cin + cout);
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) out[(size_t)co * cin + grp * CPT + j] = acc[j];
+  if (grp == 0) out[(size_t)cout * cin + co] = accb;
+}
+
+// d[e] = sum over blocks of part[blk][e], in block order
+__global__ __launch_bounds__(256) void rows_linear_bwd_reduce_kernel(
+    const float* __restrict__ part, int nblk, int entries, int per_w, float* __restrict__ dw,
+    float* __restrict__ db) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= entries) return;
+  float s = 0.f;
+  int bk = 0;
+  for (; bk + 8 <= nblk; bk += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(bk + u) * entries + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; bk < nblk; ++bk) s += part[(size_t)bk * entries + e];
+  if (e < per_w) dw[e] = s;
+  else if (db) db[e - per_w] = s;
+}
+
 }  // namespace
 }  // namespace msmd
 
@@ -251,5 +459,80 @@ MSMD_EXPORT int msmd_gma_assemble_bwd_f32(const float* d_out, int n_o3, int c3, 
   if (n_o3 && !d_conv3) return MSMD_ERR_INVALID_ARG;
   MSMD_LAUNCH(gma_assemble_bwd_kernel, dim3(grid_for(rows * ((c3 + c2) >> 2))), dim3(256), 0, st,
               A, d_out, d_conv3, csr ? (float*)nullptr : d_cross_gate, d_gate);
+  return launch_status();
+}
+
+
+// y[(n + n_tail), cout] = relu?(cat(x, x_tail) @ w^T + b); w is nn.Linear's [cout, cin].
+MSMD_EXPORT int msmd_rows_linear_supported(int cin, int cout) {
+  // channel groups of 4; cout threads per row group; the backward's thread layout
+  return cin >= 4 && cin <= 256 && cin <= 4 * cout && (cin & 3) == 0 &&
+         (cout == 32 || cout == 64 || cout == 128) && cin % (256 / cout) == 0 &&
+         (cin / (256 / cout)) % 4 == 0 && cin / (256 / cout) <= 64;
+}
+
+MSMD_EXPORT int msmd_rows_linear_fwd_f32(const float* x, int n, const float* x_tail, int n_tail,
+                                         int cin, const float* w, const float* b, int cout,
+                                         int relu, float* y, msmd_stream_t stream) {
+  if (!msmd_rows_linear_supported(cin, cout)) return MSMD_ERR_UNSUPPORTED;
+  if (n < 0 || n_tail < 0 || !w || (n && !x) || (n_tail && !x_tail)) return MSMD_ERR_INVALID_ARG;
+  const long total = (long)n + n_tail;
+  if (total == 0) return MSMD_OK;
+  if (!y) return MSMD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int rpp = 4 * (256 / (cout >> 2));    // (RT rows per thread)
+  const size_t smem = sizeof(float) * ((size_t)cin * cout + (size_t)rpp * (cin + 4));
+  static size_t attr = 0;
+  if (smem > attr) {
+    (void)hipFuncSetAttribute((const void*)rows_linear_fwd_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = smem;
+  }
+  MSMD_LAUNCH(rows_linear_fwd_kernel, dim3(ceil_div(total, kLinRowsPerBlock)), dim3(256), smem, st,
+              x, n, x_tail, n_tail, cin, w, b, cout, relu, y);
+  return launch_status();
+}
+
+MSMD_EXPORT size_t msmd_rows_linear_bwd_workspace_bytes(int n_total, int cin, int cout) {
+  const size_t nblk = ceil_div(n_total > 0 ? n_total : 1, kLinBwdRows);
+  return align_up(sizeof(float) * nblk * ((size_t)cout * cin + cout));
+}
+
+// dw[cout, cin] = g^T cat(x, x_tail), db[cout] = column sums of g, g = dy (where y > 0 if relu)
+MSMD_EXPORT int msmd_rows_linear_bwd_f32(const float* x, int n, const float* x_tail, int n_tail,
+                                         int cin, const float* y, const float* dy, int cout,
+                                         int relu, float* dw, float* db, void* workspace,
+                                         size_t workspace_bytes, msmd_stream_t stream) {
+  if (!msmd_rows_linear_supported(cin, cout)) return MSMD_ERR_UNSUPPORTED;
+  if (n < 0 || n_tail < 0 || !dw || (n && !x) || (n_tail && !x_tail)) return MSMD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)n + n_tail;
+  const int per_w = cout * cin, entries = per_w + cout;
+  if (total == 0) {
+    (void)hipMemsetAsync(dw, 0, sizeof(float) * per_w, st);
+    if (db) (void)hipMemsetAsync(db, 0, sizeof(float) * cout, st);
+    return launch_status();
+  }
+  if (!dy || (relu && !y)) return MSMD_ERR_INVALID_ARG;
+  const int nblk = ceil_div(total, kLinBwdRows);
+  if (workspace_bytes < sizeof(float) * (size_t)nblk * entries || ((uintptr_t)workspace & 255))
+    return MSMD_ERR_WORKSPACE;
+  float* part = (float*)workspace;
+  const int cpt = cin / (256 / cout);
+  const size_t smem = sizeof(float) * ((size_t)kLinBwdTile * cout + (size_t)kLinBwdTile * (cin + 4));
+#define MSMD_LIN_BWD(C_)                                                                       \
+  MSMD_LAUNCH(rows_linear_bwd_partial_kernel<C_>, dim3(nblk), dim3(256), smem, st, x, n, x_tail, \
+              n_tail, cin, y, dy, cout, relu, part)
+  switch (cpt) {
+    case 4: MSMD_LIN_BWD(4); break;
+    case 8: MSMD_LIN_BWD(8); break;
+    case 16: MSMD_LIN_BWD(16); break;
+    case 32: MSMD_LIN_BWD(32); break;
+    case 64: MSMD_LIN_BWD(64); break;
+    default: return MSMD_ERR_UNSUPPORTED;
+  }
+#undef MSMD_LIN_BWD
+  MSMD_LAUNCH(rows_linear_bwd_reduce_kernel, dim3(ceil_div(entries, 256)), dim3(256), 0, st,
+              (const float*)part, nblk, entries, per_w, dw, db);
   return launch_status();
 }

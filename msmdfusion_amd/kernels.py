@@ -1158,3 +1158,62 @@ def nn_assign(group_idx, rep_nn, nq):
     check(lib.msmd_nn_assign(_p(g), _p(r), m, ns, int(nq), _p(out), _p(scratch), _stream()),
           "msmd_nn_assign")
     return out
+
+
+# ------------------------------------------------------------------ gate tables (a16)
+def rows_linear_supported(c_in, c_out):
+    return bool(lib.msmd_rows_linear_supported(int(c_in), int(c_out)))
+
+
+class _RowsLinear(torch.autograd.Function):
+    """relu?(cat(x, x_tail) @ w^T + b) over feature rows (csrc/gma.hip); the weight and bias
+    gradients come from per-block partial sums added in block order (deterministic); the
+    input gradient, when something upstream wants it, is one matmul."""
+
+    @staticmethod
+    def forward(ctx, x, x_tail, w, b, relu):
+        xx = x.contiguous().float()
+        n, c_in = xx.shape
+        tail = None if x_tail is None else x_tail.contiguous().float()
+        n_tail = 0 if tail is None else tail.shape[0]
+        ww = w.contiguous().float()
+        bb = None if b is None else b.contiguous().float()
+        c_out = ww.shape[0]
+        y = torch.empty((n + n_tail, c_out), dtype=torch.float32, device=xx.device)
+        check(lib.msmd_rows_linear_fwd_f32(_p(xx), n, _p(tail), n_tail, c_in, _p(ww), _p(bb), c_out,
+                                           int(bool(relu)), _p(y), _stream()),
+              "msmd_rows_linear_fwd_f32")
+        ctx.save_for_backward(xx, tail, ww, y)
+        ctx.relu, ctx.has_bias = bool(relu), b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xx, tail, ww, y = ctx.saved_tensors
+        g = dy.contiguous().float()
+        n, c_in = xx.shape
+        n_tail = 0 if tail is None else tail.shape[0]
+        c_out = ww.shape[0]
+        dx = dtail = dw = db = None
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            dw = torch.empty_like(ww)
+            db = torch.empty((c_out,), dtype=torch.float32, device=ww.device) if ctx.has_bias else None
+            nbytes = lib.msmd_rows_linear_bwd_workspace_bytes(n + n_tail, c_in, c_out)
+            ws = _ws(nbytes, ww.device)
+            check(lib.msmd_rows_linear_bwd_f32(_p(xx), n, _p(tail), n_tail, c_in, _p(y), _p(g),
+                                               c_out, int(ctx.relu), _p(dw), _p(db), _p(ws), nbytes,
+                                               _stream()), "msmd_rows_linear_bwd_f32")
+        if ctx.needs_input_grad[0] or (tail is not None and ctx.needs_input_grad[1]):
+            gm = g * (y > 0) if ctx.relu else g
+            if ctx.needs_input_grad[0]:
+                dx = gm[:n] @ ww
+            if tail is not None and ctx.needs_input_grad[1]:
+                dtail = gm[n:] @ ww
+        return dx, dtail, dw, db, None
+
+
+def rows_linear(x, weight, bias=None, relu=False, x_tail=None):
+    """nn.Linear (+ ReLU) over feature rows, optionally with extra rows appended (x_tail)
+    without materialising the concatenation."""
+    _need_cuda(x, weight)
+    return _RowsLinear.apply(x, x_tail, weight, bias, relu)

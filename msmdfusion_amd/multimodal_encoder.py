@@ -275,6 +275,19 @@ class SparseMultiModalEncoderPaint(nn.Module):
         return total.plan(convs(getattr(self.downscale_blocks, stage)), need_grad)
 
     # ---- one GMA-Conv stage (:325-430) -----------------------------------------
+    @staticmethod
+    def _gate_table(seq, rows, tail=None):
+        """gate_control / cross_gate_control (Linear + ReLU) over feature rows; `tail`: rows
+        appended behind them (the dummy embedding).  On the GPU one row-streaming kernel each
+        way (kernels.rows_linear: hipBLASLt's fp32 GEMM took 170-230 us per call on these
+        skinny shapes, 16 calls per step); the module itself otherwise."""
+        lin = seq[0]
+        if (rows.is_cuda and rows.dtype == torch.float32 and len(seq) == 2
+                and isinstance(lin, nn.Linear) and isinstance(seq[1], nn.ReLU)
+                and K.rows_linear_supported(lin.in_features, lin.out_features)):
+            return K.rows_linear(rows, lin.weight, lin.bias, relu=True, x_tail=tail)
+        return seq(rows if tail is None else torch.cat([rows, tail], 0))
+
     def grouped_sparse_conv(self, voxel_3D, voxel_2D, syn_mix_3D, syn_mix_2D, stage_id, fps_num,
                             radius, max_cluster_samples, dist_thresh, plan=None):
         B = voxel_3D.batch_size
@@ -294,8 +307,8 @@ class SparseMultiModalEncoderPaint(nn.Module):
         # uncovered 2D voxels are gated by a random embedding (row -1 -> last row)
         dummy = plan["dummy"] if "dummy" in plan else \
             self.dummy_embedding_fn(c3, voxel_3D.features.device)
-        cross_gating = self.cross_gate_control[stage_id](
-            torch.cat([voxel_3D.features, dummy.to(voxel_3D.features.dtype)], 0))
+        cross_gating = self._gate_table(self.cross_gate_control[stage_id], voxel_3D.features,
+                                        dummy.to(voxel_3D.features.dtype))
         n3 = voxel_3D.features.shape[0]
         planned = "unified" in plan     # plan_stage_tensors ran: voxel sets + rulebooks exist
         f3_only = voxel_3D.features.index_select(0, only_3D_rows)
@@ -307,7 +320,7 @@ class SparseMultiModalEncoderPaint(nn.Module):
                 voxel_3D.spatial_shape, B)
         mixed_3D = voxel_3D.features.index_select(0, syn_mix_3D)
         assert syn_mix_3D.shape[0] == syn_mix_2D.shape[0]
-        gate = self.gate_control[stage_id](mixed_3D)
+        gate = self._gate_table(self.gate_control[stage_id], mixed_3D)
         stage = f"stage_{stage_id + 1}"
         # One launch for the rest (csrc/gma.hip) when the stage was planned ahead and neither
         # input tensor wants a gradient (frozen LiDAR encoder, raw virtual-point voxels: the

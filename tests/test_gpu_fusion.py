@@ -612,6 +612,50 @@ def test_gma_assemble_kernel_matches_torch_ops(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("c_in,c_out,n", [(16, 64, 5000), (32, 64, 70001), (64, 64, 1000),
+                                           (128, 64, 33333), (64, 128, 777), (32, 32, 3)])
+def test_rows_linear_matches_torch(dev, c_in, c_out, n):
+    """kernels.rows_linear (the gate tables: Linear + ReLU over voxel rows, the dummy row
+    appended without a concatenation) == torch's Linear + ReLU forward, and its weight / bias
+    / input gradients (fp32 sums in another order: 1e-5 of the largest entry)."""
+    from msmdfusion_amd import kernels as K
+    assert K.rows_linear_supported(c_in, c_out) and not K.rows_linear_supported(10, 64)
+    g = torch.Generator(device=dev).manual_seed(c_in + c_out + n)
+    x = torch.randn(n, c_in, device=dev, generator=g)
+    tail = torch.randn(1, c_in, device=dev, generator=g)
+    lin = torch.nn.Linear(c_in, c_out).to(dev)
+    dy = torch.randn(n + 1, c_out, device=dev, generator=g)
+    for use_tail, req_x in ((True, False), (False, True)):
+        xr = x.clone().requires_grad_(req_x)
+        xin = torch.cat([xr, tail], 0) if use_tail else xr
+        want = torch.relu(lin(xin))
+        lin.zero_grad(set_to_none=True)
+        want.backward(dy[:want.shape[0]])
+        gw, gb = lin.weight.grad.clone(), lin.bias.grad.clone()
+        gx = xr.grad.clone() if req_x else None
+        xr2 = x.clone().requires_grad_(req_x)
+        lin.zero_grad(set_to_none=True)
+        got = K.rows_linear(xr2, lin.weight, lin.bias, relu=True, x_tail=tail if use_tail else None)
+        assert got.shape == want.shape
+        assert (got - want).abs().max().item() <= 1e-5 * max(want.abs().max().item(), 1.0)
+        got.backward(dy[:got.shape[0]])
+        for a, b in ((lin.weight.grad, gw), (lin.bias.grad, gb)):
+            assert (a - b).abs().max().item() <= 1e-5 * max(b.abs().max().item(), 1.0)
+        if req_x:
+            assert (xr2.grad - gx).abs().max().item() <= 1e-5 * max(gx.abs().max().item(), 1.0)
+    # no ReLU, no bias; run to run identical (fixed summation order)
+    y0 = K.rows_linear(x, lin.weight, None, relu=False)
+    assert (y0 - x @ lin.weight.t()).abs().max().item() <= 1e-5 * y0.abs().max().item()
+    w2 = lin.weight.detach().clone().requires_grad_(True)
+    grads = []
+    for _ in range(2):
+        w2.grad = None
+        K.rows_linear(x, w2, lin.bias, relu=True).backward(dy[:n])
+        grads.append(w2.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.gpu
 def test_fused_stage_assembly_matches_the_op_chain(dev):
     """The LC path with the one-launch stage assembly == with the reference's op-by-op
     chain: identical BEV map; gate / conv gradients equal up to the order of float atomics."""
