@@ -270,6 +270,27 @@ def test_strided_conv_fwd_bwd(dev, ks, st, pd, cin, cout):
     np.testing.assert_allclose(dw.cpu().numpy(), edw, rtol=TOL, atol=TOL * 5)
 
 
+@pytest.mark.parametrize("n_vox", [1500, 4097, 130])
+def test_rulebook_plan_equals_its_parts(dev, n_vox):
+    """msmd_rulebook_plan (order + tiled table + 128-row stream-K prefix out of the tiling's
+    last kernel + pair lists, one call) == rulebook_tiling, permute_cols, tile_prefix and
+    rulebook_pairs called one by one (odd tile counts, a partial last tile, fewer rows than
+    one block)."""
+    from msmdfusion_amd import kernels as K
+    shape = [11, 64, 64]
+    idx = S.random_voxel_indices(n_vox, 2, shape, seed=n_vox)
+    nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
+    plan = K.rulebook_plan(nbr, tile_rows=(128,), want_pairs=True)
+    order, tiled = K.rulebook_tiling(nbr)
+    assert torch.equal(plan["order"], order) and torch.equal(plan["tiled"], tiled)
+    assert torch.equal(tiled, K.permute_cols(nbr, order))
+    assert torch.equal(plan["prefix"][128], K.tile_prefix(tiled, 128))
+    pairs, num = K.rulebook_pairs(nbr)
+    assert torch.equal(plan["pairs"][0], pairs) and torch.equal(plan["pairs"][1], num)
+    again = K.rulebook_plan(nbr, tile_rows=(128,))          # (the block counter re-arms itself)
+    assert torch.equal(again["prefix"][128], plan["prefix"][128])
+
+
 def test_scans_do_not_depend_on_what_else_runs(dev):
     """The scan-based index kernels (pair-list compaction, strided rulebook ranks, sparse_add
     maps) give the same tables while another stream keeps the chip busy with persistent conv
