@@ -555,8 +555,7 @@ def pmc_traffic(kernel_name, workload):
     else:   # wgrad: whichever instantiation of the split kernel ran most (the lean
         #     buffer-load variant is spconv_wgrad_split_buf_kernel<planes, groups>)
         stem = kernel_name.replace("_kernel", "")
-        # (round 3: widths that are multiples of 16 run spconv_wgrad_block_kernel<planes>)
-        cands = [k for k in kernels if k.startswith(stem) or k.startswith("spconv_wgrad_block")]
+        cands = [k for k in kernels if k.startswith(stem)]
         key = max(cands, key=lambda k: kernels[k].get("launches_sampled", 0)) if cands else None
     e = kernels.get(key, {})
     return e.get("hbm_bytes_per_launch"), e.get("mfma_pipe_busy_frac"), os.path.relpath(path, ROOT)
@@ -584,8 +583,12 @@ def roofline(prof, workload):
                         else "spconv_fwd_kernel<NT=%d>") % nt
         else:
             pairs = int(meta["num"].sum().item())
-            name = "spconv_wgrad_split_kernel" if kind == "spconv_wgrad_split" \
-                else "spconv_wgrad_kernel"
+            # (msmd_spconv_wgrad_split runs the whole-block kernel where both widths are
+            # multiples of 16 and >= 64 -- csrc/spconv_wgrad_block.hip -- else the slab kernel)
+            block = meta["c_in"] % 16 == 0 and meta["c_out"] % 16 == 0 and \
+                min(meta["c_in"], meta["c_out"]) >= 64 and os.environ.get("MSMD_WGRAD") != "var"
+            name = ("spconv_wgrad_block_kernel" if block else "spconv_wgrad_split_var_kernel") \
+                if kind == "spconv_wgrad_split" else "spconv_wgrad_kernel"
         if os.environ.get("MSMD_BENCH_LAYERS") == "1":     # per-launch lines (stderr)
             print("[layer] %-34s %4d->%-4d pairs %8d  %7.1f us  %6.1f TF" % (
                 name, meta["c_in"], meta["c_out"], pairs, ms * 1e3,
@@ -599,7 +602,7 @@ def roofline(prof, workload):
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
     traffic, mfma_busy, pmc_file = pmc_traffic(name, workload)
     peak, peak_note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA (v_mfma_f32_16x16x4_f32)"
-    if name.startswith("spconv_fwd_split") or name.startswith("spconv_wgrad_split"):
+    if name.startswith(("spconv_fwd_split", "spconv_wgrad_split", "spconv_wgrad_block")):
         from msmdfusion_amd.spconv.functional import conv_planes
         products = {3: 6, 2: 3, 1: 1}[conv_planes()]
         peak = round(PEAK_BF16_MFMA_TFLOPS / products, 1)
