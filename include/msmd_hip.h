@@ -262,6 +262,19 @@ int msmd_spconv_fwd_split(const float* in_feat /* [n_in,c_in] */, int n_in, int 
                                                         or NULL: dynamic tile scheduler */,
                           msmd_stream_t stream);
 
+/* The same call that also leaves, per 128-row tile of the output, the column sums and sums
+ * of squares of the rows it wrote: bn_partials[ceil(n_out / 128)][2][c_out] -- the statistics
+ * pass of the BatchNorm1d that follows a conv in make_sparse_convmodule / SparseBasicBlock
+ * (mmdet3d/ops/sparse_block.py:87-117,161-190) without reading the output again
+ * (msmd_bn_act_fwd_from_partials_f32 takes them).  bn_partials = NULL: msmd_spconv_fwd_split. */
+int msmd_spconv_fwd_split_stats(const float* in_feat, int n_in, int c_in,
+                                const void* packed_weight, const int32_t* nbr, int ld,
+                                int n_out, int kernel_volume, int weight_flip,
+                                const int32_t* row_order, int32_t* tile_counter, int sync_ints,
+                                float* out_feat, int c_out, int planes, void* workspace,
+                                size_t workspace_bytes, const int32_t* tile_prefix,
+                                float* bn_partials, msmd_stream_t stream);
+
 /* Rows per tile the split kernel uses for a layer of c_out output channels (128 or 256):
  * the rows_per_tile to compute its tile_prefix with. */
 int msmd_spconv_fwd_split_tile_rows(int c_out);
@@ -367,6 +380,16 @@ int msmd_bn_act_fwd_f32(const float* x /* [n,c] */, const float* residual /* or 
                         float momentum, float eps, int relu, float* y,
                         float* save_mean, float* save_invstd, void* workspace,
                         size_t workspace_bytes, msmd_stream_t stream);
+
+/* Training-mode forward whose statistics pass was done by the producer of x:
+ * partials[n_partials][2][c] = column sums / sums of squares of disjoint row blocks covering x
+ * (msmd_spconv_fwd_split_stats).  Same outputs and running-stat update as msmd_bn_act_fwd_f32. */
+int msmd_bn_act_fwd_from_partials_f32(const float* x, const float* residual, int n, int c,
+                                      const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float momentum,
+                                      float eps, int relu, float* y, float* save_mean,
+                                      float* save_invstd, const float* partials, int n_partials,
+                                      msmd_stream_t stream);
 
 int msmd_bn_act_bwd_f32(const float* x, const float* y /* fwd output, for the ReLU mask */,
                         const float* dy, int n, int c, const float* gamma,

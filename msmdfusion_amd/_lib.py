@@ -71,6 +71,7 @@ SIGNATURES = {
     "msmd_spconv_fwd_split_workspace_bytes": (_sz, [_i, _i]),
     "msmd_spconv_fwd_split": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i,
                                    _vp, _sz, _vp, _vp]),
+    "msmd_spconv_fwd_split_stats": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "msmd_rulebook_tile_prefix": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "msmd_spconv_fwd_split_tile_rows": (_i, [_i]),
     "msmd_spconv_wgrad_split_supported": (_i, [_i, _i]),
@@ -78,6 +79,8 @@ SIGNATURES = {
     "msmd_rulebook_permute_cols": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "msmd_bn_workspace_bytes": (_sz, [_i, _i]),
     "msmd_bn_act_fwd_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "msmd_bn_act_fwd_from_partials_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp,
+                                               _vp, _vp, _vp, _i, _vp]),
     "msmd_bn_act_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "msmd_dense_scatter_f32": (_i, [_vp, _vp, _i, _i, _i, _ip, _vp, _vp]),
     "msmd_dense_gather_f32": (_i, [_vp, _vp, _i, _i, _i, _ip, _vp, _vp]),

@@ -274,6 +274,29 @@ MSMD_EXPORT int msmd_bn_act_fwd_f32(const float* x, const float* residual, int n
   return launch_status();
 }
 
+// Training-mode forward with the statistics pass already done: `partials` =
+// [n_partials][2][c] column sums and sums of squares of disjoint row blocks of x that
+// together cover it (msmd_spconv_fwd_split_stats writes them from its accumulators).
+MSMD_EXPORT int msmd_bn_act_fwd_from_partials_f32(const float* x, const float* residual, int n,
+                                                  int c, const float* gamma, const float* beta,
+                                                  float* running_mean, float* running_var,
+                                                  float momentum, float eps, int relu, float* y,
+                                                  float* save_mean, float* save_invstd,
+                                                  const float* partials, int n_partials,
+                                                  msmd_stream_t stream) {
+  if (n < 0 || c < 4 || (c & 3) || c > 1024 || !gamma || !beta || !save_mean || !save_invstd)
+    return c > 0 && ((c & 3) || c > 1024) ? MSMD_ERR_UNSUPPORTED : MSMD_ERR_INVALID_ARG;
+  if (n == 0) return MSMD_OK;
+  if (!x || !y || !partials || n_partials < 1) return MSMD_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  MSMD_LAUNCH(bn_fwd_finalize, dim3(ceil_div(c, 16)), dim3(256), 0, st, partials, n_partials, n, c,
+              eps, momentum, running_mean, running_var, save_mean, save_invstd);
+  const long total4 = (long)n * (c >> 2);
+  MSMD_LAUNCH(bn_fwd_apply, dim3(stream_blocks(total4)), dim3(256), 0, st, x, residual, total4,
+              c >> 2, save_mean, save_invstd, gamma, beta, relu, y);
+  return launch_status();
+}
+
 MSMD_EXPORT int msmd_bn_act_bwd_f32(const float* x, const float* y, const float* dy, int n, int c,
                                     const float* gamma, const float* save_mean,
                                     const float* save_invstd, int training, int relu, float* dx,

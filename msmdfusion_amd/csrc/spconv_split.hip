@@ -308,7 +308,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
     const int32_t* __restrict__ order, int* __restrict__ tile_counter, float* __restrict__ out,
     int ldo, int cout, int nt_total, int mt0, f32x4* __restrict__ scratch,
     int* __restrict__ flags, const int32_t* __restrict__ tile_start, int sk_c0, int sk_c1v,
-    int dbg) {
+    int dbg, float* __restrict__ bn_part) {
   // Scheduling.  Without `tile_start`: persistent workgroups draw whole 128-row tiles from
   // a global counter (tiles arrive heaviest first: LPT list scheduling), every tile is one
   // unit and the result does not depend on the tiling order at all.  A tile whose rows are
@@ -356,6 +356,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
   int* nbt = (int*)(wl + 2 * kWU);                // [2][kvol + 1][kRows]; row kvol = output rows
   const int tstride = (kvol + 1) * kRows;
   int* ctl = nbt + 2 * tstride;                   // [0],[1]: offset masks; [2]: next tile
+  float* stat = (float*)(ctl + 72);               // [WV][2][NT * 16]: BN partials of the tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
@@ -770,6 +771,44 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
           }
         }
       }
+      // The BatchNorm that follows wants the per-channel sum and sum of squares of these
+      // rows: the tile's partials come from the accumulators (bn.hip's statistics pass
+      // would read the whole output again), one [2][c_out] slot per row tile, rows in fixed
+      // order: deterministic.
+      if (bn_part) {
+        float* st_w = stat + wave * (2 * NT * 16);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const bool ok = rt * kRows + lr[r] < n_out;
+            const f32x4 v = ok ? acc[r][n] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s1 += v;
+            s2 += v * v;
+          }
+#pragma unroll
+          for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s1[e] += __shfl_xor(s1[e], m, 64);
+              s2[e] += __shfl_xor(s2[e], m, 64);
+            }
+          if (j == 0) {
+            *(f32x4*)(st_w + 16 * n + 4 * q) = s1;
+            *(f32x4*)(st_w + NT * 16 + 16 * n + 4 * q) = s2;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < 2 * NT * 16) {
+          float v = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < WV; ++w2) v += stat[w2 * (2 * NT * 16) + tid];
+          const int which = tid >= NT * 16 ? 1 : 0, c = tid - which * NT * 16;
+          if (c < cout) bn_part[(size_t)rt * 2 * ldo + (size_t)which * ldo + 16 * mt0 + c] = v;
+        }
+      }
       // ---- lane (j,q) holds out[row j][16n + 4q .. +3] ----
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -810,7 +849,7 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
                      int ld, int n_out, int kvol, int flip, const int32_t* order,
                      int* tile_counter, float* out, int ldo, int cout, int nt_total, int mt0,
                      void* scratch, int* flags, const int32_t* tile_start, int sk_grid,
-                     hipStream_t st) {
+                     float* bn_part, hipStream_t st) {
   // stream-K: a tile visit's fixed cost in units (offset x k-block) of this instantiation,
   // charged per tile in ranks of ceil(cin / 32) units each
   // (swept 0..48 on the bench layers: 8 is within 2 % of the best for every width)
@@ -819,7 +858,8 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   const int sk_c0 = ((ovh_units + kbt - 1) / kbt) * (sk_c1() + 2);   // in cost units
   constexpr int kRows = WV * 32;
   const size_t smem = sizeof(u32x4) * 2 * UB * NP * NT * 64 +
-                      sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 72);
+                      sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 72) +
+                      sizeof(float) * WV * 2 * NT * 16;
   const int n_tiles = ceil_div(n_out, kRows);
   int nblk = n_tiles;
   const int slots = 256 * (WV == 4 ? split_slots_per_cu() : 1);
@@ -833,7 +873,7 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   }
   MSMD_LAUNCH(kern, dim3(nblk), dim3(WV * 64), smem, st, in, n_in, cin, (const u32x4*)wp, nbr, ld,
               n_out, kvol, flip, order, tile_counter, out, ldo, cout, nt_total, mt0,
-              (f32x4*)scratch, flags, tile_start, sk_c0, sk_c1(), env_int2("MSMD_DBG", 0));
+              (f32x4*)scratch, flags, tile_start, sk_c0, sk_c1(), env_int2("MSMD_DBG", 0), bn_part);
   return launch_status();
 }
 
@@ -875,7 +915,8 @@ template <int NP>
 int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                        int ld, int n_out, int kvol, int flip, const int32_t* order,
                        int* tile_counter, int sync_ints, float* out, int cout, void* ws,
-                       size_t ws_bytes, const int32_t* tile_prefix, hipStream_t st) {
+                       size_t ws_bytes, const int32_t* tile_prefix, float* bn_part,
+                       hipStream_t st) {
   const int nt_total = (cout + 15) / 16;
   const int n_pass = (nt_total + 7) / 8;
   const int per = (nt_total + n_pass - 1) / n_pass;   // tiles per pass
@@ -901,7 +942,7 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
 #define MSMD_GO(NT_, UB_, WV_)                                                                   \
   rc = launch_fwd_split<NT_, UB_, NP, WV_>(in, n_in, cin, wp, nbr, ld, n_out, kvol, flip, order, \
                                            tile_counter, o, cout, width, nt_total, mt0, ws,      \
-                                           flags, tile_start, sk_grid, st)
+                                           flags, tile_start, sk_grid, bn_part, st)
     if (tiles > 6) { MSMD_GO(8, 1, 4); }
     else if (tiles > 4) { MSMD_GO(6, 1, 4); }
     else if (tiles > 2) { MSMD_GO(4, 2, 4); }
@@ -1258,12 +1299,16 @@ MSMD_EXPORT size_t msmd_spconv_fwd_split_workspace_bytes(int n_out, int cout) {
   return fwd_sk_ws_bytes(n_out, kMaxK, cout);
 }
 
-MSMD_EXPORT int msmd_spconv_fwd_split(const float* planes, int n_in, int cin, const void* packed,
-                                      const int32_t* nbr, int ld, int n_out, int kvol,
-                                      int weight_flip, const int32_t* row_order,
-                                      int32_t* tile_counter, int sync_ints, float* out, int cout,
-                                      int np, void* workspace, size_t workspace_bytes,
-                                      const int32_t* tile_prefix, msmd_stream_t stream) {
+// bn_partials (or NULL): [ceil(n_out / 128)][2][c_out] floats -- per row tile the column sums
+// and sums of squares of the rows written (what msmd_bn_act_fwd_from_partials_f32 takes)
+MSMD_EXPORT int msmd_spconv_fwd_split_stats(const float* planes, int n_in, int cin,
+                                            const void* packed, const int32_t* nbr, int ld,
+                                            int n_out, int kvol, int weight_flip,
+                                            const int32_t* row_order, int32_t* tile_counter,
+                                            int sync_ints, float* out, int cout, int np,
+                                            void* workspace, size_t workspace_bytes,
+                                            const int32_t* tile_prefix, float* bn_partials,
+                                            msmd_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!msmd_spconv_fwd_split_supported(cin, cout, kvol) || np < 1 || np > 3)
     return MSMD_ERR_UNSUPPORTED;
@@ -1272,11 +1317,23 @@ MSMD_EXPORT int msmd_spconv_fwd_split(const float* planes, int n_in, int cin, co
   // the gathers address the features through a 32-bit buffer offset
   if ((size_t)n_in * cin * sizeof(float) >= (size_t)kOobOffset) return MSMD_ERR_RANGE;
 #define MSMD_ARGS planes, n_in, cin, packed, nbr, ld, n_out, kvol, weight_flip, row_order, \
-                  tile_counter, sync_ints, out, cout, workspace, workspace_bytes, tile_prefix, st
+                  tile_counter, sync_ints, out, cout, workspace, workspace_bytes, tile_prefix, \
+                  bn_partials, st
   if (np == 3) return dispatch_fwd_split<3>(MSMD_ARGS);
   if (np == 2) return dispatch_fwd_split<2>(MSMD_ARGS);
   return dispatch_fwd_split<1>(MSMD_ARGS);
 #undef MSMD_ARGS
+}
+
+MSMD_EXPORT int msmd_spconv_fwd_split(const float* planes, int n_in, int cin, const void* packed,
+                                      const int32_t* nbr, int ld, int n_out, int kvol,
+                                      int weight_flip, const int32_t* row_order,
+                                      int32_t* tile_counter, int sync_ints, float* out, int cout,
+                                      int np, void* workspace, size_t workspace_bytes,
+                                      const int32_t* tile_prefix, msmd_stream_t stream) {
+  return msmd_spconv_fwd_split_stats(planes, n_in, cin, packed, nbr, ld, n_out, kvol, weight_flip,
+                                     row_order, tile_counter, sync_ints, out, cout, np, workspace,
+                                     workspace_bytes, tile_prefix, nullptr, stream);
 }
 
 MSMD_EXPORT int msmd_rulebook_tile_prefix(const int32_t* nbr, int kvol, int ld, int n_rows,

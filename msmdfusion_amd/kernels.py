@@ -554,7 +554,7 @@ def tile_prefix(nbr, rows=TILE_ROWS):
 
 
 def conv_forward_split(feat, packed_weight, nbr, n_out, c_out, planes=3, weight_flip=False,
-                       row_order=None, split_tiles=True, tile_prefix=None):
+                       row_order=None, split_tiles=True, tile_prefix=None, bn_stats=False):
     """conv_forward at bf16 MFMA rate with fp32-equivalent results: fp32 features
     are split into `planes` bf16 planes in registers, weights are pre-split
     (pack_weight_split).  With row_order, `nbr` must be in tile order (permute_cols).
@@ -576,16 +576,25 @@ def conv_forward_split(feat, packed_weight, nbr, n_out, c_out, planes=3, weight_
         if tile_prefix.numel() != (int(n_out) + rows - 1) // rows + 1:
             raise ValueError("tile_prefix was not computed for %d-row tiles (K.tile_prefix(nbr, "
                              "K.split_tile_rows(c_out)))" % rows)
+    # bn_stats: also the per-tile column sums / sums of squares of the output, for the
+    # BatchNorm that follows (bn_act_forward(partials=...)) -> (out, partials)
+    part = None
+    if bn_stats and int(n_out) > 0:
+        rows = split_tile_rows(c_out)
+        part = torch.empty(((int(n_out) + rows - 1) // rows, 2, int(c_out)), dtype=torch.float32,
+                           device=f.device)
     ev = _prof_begin()
-    check(lib.msmd_spconv_fwd_split(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld,
-                                    int(n_out), kvol, int(bool(weight_flip)), _p(row_order),
-                                    _p(counter), counter.numel(), _p(out), int(c_out),
-                                    int(planes), _p(ws), 0 if ws is None else ws.numel(),
-                                    _p(tile_prefix) if split_tiles else None, _stream()),
-          "msmd_spconv_fwd_split")
+    check(lib.msmd_spconv_fwd_split_stats(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld,
+                                          int(n_out), kvol, int(bool(weight_flip)),
+                                          _p(row_order), _p(counter), counter.numel(), _p(out),
+                                          int(c_out), int(planes), _p(ws),
+                                          0 if ws is None else ws.numel(),
+                                          _p(tile_prefix) if split_tiles else None, _p(part),
+                                          _stream()),
+          "msmd_spconv_fwd_split_stats")
     _prof_end("spconv_fwd_split", ev, nbr=nbr, c_in=c_in, c_out=int(c_out), n_in=n_in,
               n_out=int(n_out))
-    return out
+    return (out, part) if bn_stats else out
 
 
 def conv_wgrad(feat, d_out, pairs, num, krsc_shape=None):
@@ -632,8 +641,10 @@ def conv_wgrad_split(feat, d_out, pairs, num, planes=3, krsc_shape=None):
 
 # ------------------------------------------------------------------ BN (+residual)(+ReLU)
 def bn_act_forward(x, residual, gamma, beta, running_mean, running_var, training, momentum, eps,
-                   relu):
-    """-> (y, save_mean, save_invstd)"""
+                   relu, partials=None):
+    """-> (y, save_mean, save_invstd).  partials (training only): [blocks, 2, c] column sums /
+    sums of squares of disjoint row blocks covering x, from the kernel that produced x
+    (conv_forward_split(bn_stats=True)): the statistics pass is skipped."""
     _need_cuda(x, gamma, beta)
     xx = x.contiguous().float()
     n, c = xx.shape
@@ -644,6 +655,13 @@ def bn_act_forward(x, residual, gamma, beta, running_mean, running_var, training
     nbytes = lib.msmd_bn_workspace_bytes(n, c)
     ws = _ws(nbytes, dev)
     res = None if residual is None else residual.contiguous().float()
+    if partials is not None and training and n > 0:
+        assert partials.shape[1:] == (2, c) and partials.is_contiguous()
+        check(lib.msmd_bn_act_fwd_from_partials_f32(
+            _p(xx), _p(res), n, c, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+            float(momentum), float(eps), int(bool(relu)), _p(y), _p(mean), _p(invstd),
+            _p(partials), int(partials.shape[0]), _stream()), "msmd_bn_act_fwd_from_partials_f32")
+        return y, mean, invstd
     check(lib.msmd_bn_act_fwd_f32(_p(xx), _p(res), n, c, _p(gamma), _p(beta), _p(running_mean),
                                   _p(running_var), int(bool(training)), float(momentum),
                                   float(eps), int(bool(relu)), _p(y), _p(mean), _p(invstd), _p(ws),

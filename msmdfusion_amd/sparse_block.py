@@ -42,12 +42,15 @@ class SparseBasicBlock(spconv.SparseModule):
         identity = x.features
         assert x.features.dim() == 2, f"x.features.dim()={x.features.dim()}"
         # relu(norm1(.)) and relu(norm2(.) + identity) each run as one fused op
+        self.conv1.emit_bn_stats = self.conv2.emit_bn_stats = True   # norm1 / norm2 follow
         out = self.conv1(x)
-        out = out.replace_feature(bn_act(out.features, self.norm1, relu=True))
+        out = out.replace_feature(bn_act(out.features, self.norm1, relu=True,
+                                         stats=getattr(out, "bn_stats", None)))
         out = self.conv2(out)
         if self.downsample is not None:
             identity = self.downsample(x)
-        out = out.replace_feature(bn_act(out.features, self.norm2, relu=True, residual=identity))
+        out = out.replace_feature(bn_act(out.features, self.norm2, relu=True, residual=identity,
+                                         stats=getattr(out, "bn_stats", None)))
         return out
 
 

@@ -158,12 +158,20 @@ class SparseConvolution(SparseModule):
                 indice_dict[self.indice_key] = datas
         if input.indices.shape[0] == 0 and datas.n_out == 0:
             out_features = features.new_zeros((0, self.out_channels))
+            stats = None
         else:
-            out_features = Fsp.sparse_conv(features, self.weight, datas, krsc=True)
+            # a BatchNorm1d follows (SparseSequential / SparseBasicBlock set the flag): let the
+            # conv kernel leave the per-tile sums the BN's statistics pass would recompute
+            stats = [None] if (getattr(self, "emit_bn_stats", False) and self.bias is None
+                               and features.is_cuda) else None
+            out_features = Fsp.sparse_conv(features, self.weight, datas, krsc=True,
+                                           bn_stats=stats)
         if self.bias is not None:
             out_features = out_features + self.bias
         out_tensor.indices = datas.out_indices
         out_tensor = out_tensor.replace_feature(out_features)
+        # (an attribute of THIS tensor object only: whatever replaces its features drops it)
+        out_tensor.bn_stats = stats[0] if stats else None
         out_tensor.indice_dict = indice_dict
         out_tensor.spatial_shape = out_spatial_shape
         return out_tensor

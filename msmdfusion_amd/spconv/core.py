@@ -205,6 +205,7 @@ class SparseConvTensor:
     @features.setter
     def features(self, val):
         self._features = val
+        self.__dict__.pop("bn_stats", None)
 
     def replace_feature(self, feature: torch.Tensor):
         assert feature.shape[0] == self.indices.shape[0], \
@@ -218,6 +219,8 @@ class SparseConvTensor:
         .features one after the other, so no row-count check here)."""
         new = SparseConvTensor.__new__(SparseConvTensor)
         new.__dict__.update(self.__dict__)
+        # (the BatchNorm partials a conv leaves on ITS output describe those features only)
+        new.__dict__.pop("bn_stats", None)
         return new
 
     @property

@@ -141,8 +141,8 @@ def invalidate_packed_weights():
     _FROZEN_PACKS.clear()
 
 
-def _conv_forward(features, weight, rb, krsc, want_dgrad):
-    """-> (out, packed W^T for dgrad | None)."""
+def _conv_forward(features, weight, rb, krsc, want_dgrad, bn_stats=False):
+    """-> (out, packed W^T for dgrad | None[, BN partials | None when bn_stats])."""
     c_in, c_out = (weight.shape[-1], weight.shape[0]) if krsc else weight.shape[1:]
     if _use_split(c_in, c_out, rb.nbr_fwd.shape[0], features.shape[0]):
         np_ = conv_planes()
@@ -158,10 +158,13 @@ def _conv_forward(features, weight, rb, krsc, want_dgrad):
         else:
             packed = K.pack_weight_split(weight, np_, krsc=krsc)
         table, order = rb.tiling_fwd()
-        return K.conv_forward_split(features, packed, table, rb.n_out, c_out, np_,
-                                    row_order=order, tile_prefix=rb.prefix_fwd(c_out)), packed_t
-    return _conv_f32(features, weight, krsc, False, rb.nbr_fwd, rb.n_out,
-                     row_order=rb.order_fwd() if _wants_order(c_in, c_out) else None), None
+        res = K.conv_forward_split(features, packed, table, rb.n_out, c_out, np_,
+                                   row_order=order, tile_prefix=rb.prefix_fwd(c_out),
+                                   bn_stats=bn_stats)
+        return (res[0], packed_t, res[1]) if bn_stats else (res, packed_t)
+    out = _conv_f32(features, weight, krsc, False, rb.nbr_fwd, rb.n_out,
+                    row_order=rb.order_fwd() if _wants_order(c_in, c_out) else None)
+    return (out, None, None) if bn_stats else (out, None)
 
 
 class _SparseConvFunction(Function):
@@ -169,10 +172,14 @@ class _SparseConvFunction(Function):
     are the same implicit-GEMM kernel, wgrad contracts over the pair lists."""
 
     @staticmethod
-    def forward(ctx, features, weight, rb, krsc):
+    def forward(ctx, features, weight, rb, krsc, stats=None):
         ctx.rb, ctx.krsc = rb, krsc
         ctx.save_for_backward(features, weight)
-        out, ctx.packed_t = _conv_forward(features, weight, rb, krsc, ctx.needs_input_grad[0])
+        if stats is not None:     # a one-slot list: receives the BN partials of the output
+            out, ctx.packed_t, stats[0] = _conv_forward(features, weight, rb, krsc,
+                                                        ctx.needs_input_grad[0], bn_stats=True)
+        else:
+            out, ctx.packed_t = _conv_forward(features, weight, rb, krsc, ctx.needs_input_grad[0])
         return out
 
     @staticmethod
@@ -212,15 +219,21 @@ class _SparseConvFunction(Function):
                                weight_flip=rb.is_subm, row_order=order)
         if ctx.needs_input_grad[1]:
             d_w = wgrad_done.result()
-        return d_feat, d_w, None, None
+        return d_feat, d_w, None, None, None
 
 
-def sparse_conv(features, weight, rb, krsc=False):
+def sparse_conv(features, weight, rb, krsc=False, bn_stats=None):
     """weight: [K,Cin,Cout], or the KRSC module parameter with krsc=True (read
-    and differentiated in place -- no permute/contiguous copies per step)."""
+    and differentiated in place -- no permute/contiguous copies per step).
+    bn_stats: a one-slot list that receives the output's BatchNorm partials (per-tile column
+    sums / sums of squares, or None where the kernel in use does not produce them) for
+    bn_act(..., stats=...)."""
     if not (torch.is_grad_enabled() and (features.requires_grad or weight.requires_grad)):
+        if bn_stats is not None:
+            out, _, bn_stats[0] = _conv_forward(features, weight, rb, krsc, False, bn_stats=True)
+            return out
         return _conv_forward(features, weight, rb, krsc, False)[0]   # nothing to record
-    return _SparseConvFunction.apply(features, weight, rb, krsc)
+    return _SparseConvFunction.apply(features, weight, rb, krsc, bn_stats)
 
 
 class _BNActFunction(Function):
@@ -229,9 +242,9 @@ class _BNActFunction(Function):
 
     @staticmethod
     def forward(ctx, x, residual, gamma, beta, running_mean, running_var, training, momentum,
-                eps, relu):
+                eps, relu, stats=None):
         y, mean, invstd = K.bn_act_forward(x, residual, gamma, beta, running_mean, running_var,
-                                           training, momentum, eps, relu)
+                                           training, momentum, eps, relu, partials=stats)
         ctx.save_for_backward(x, y, gamma, mean, invstd)
         ctx.cfg = (bool(training), bool(relu), residual is not None)
         return y
@@ -242,13 +255,16 @@ class _BNActFunction(Function):
         training, relu, has_res = ctx.cfg
         dx, dres, dgamma, dbeta = K.bn_act_backward(x, y, dy, gamma, mean, invstd, training, relu,
                                                     has_res and ctx.needs_input_grad[1])
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def bn_act(x, bn, relu=False, residual=None):
+def bn_act(x, bn, relu=False, residual=None, stats=None):
     """Apply an nn.BatchNorm1d module (its parameters / buffers / mode) fused
     with an optional residual add and ReLU.  Same semantics as
-    relu(bn(x) + residual), including the running-stat update."""
+    relu(bn(x) + residual), including the running-stat update.
+    stats: x's per-block column sums / sums of squares when the kernel that produced x left
+    them (sparse_conv(bn_stats=[None]) -> the list's entry): the statistics pass over x is
+    skipped in training mode."""
     if x.shape[0] == 0:     # SparseSequential skips dense modules on empty tensors
         return x
     fusable = (x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and bn.affine
@@ -274,9 +290,9 @@ def bn_act(x, bn, relu=False, residual=None):
                                          or bn.bias.requires_grad
                                          or (residual is not None and residual.requires_grad))):
         return K.bn_act_forward(x, residual, bn.weight, bn.bias, rm, rv, use_batch_stats,
-                                bn.momentum, bn.eps, relu)[0]
+                                bn.momentum, bn.eps, relu, partials=stats)[0]
     return _BNActFunction.apply(x, residual, bn.weight, bn.bias, rm, rv, use_batch_stats,
-                                bn.momentum, bn.eps, relu)
+                                bn.momentum, bn.eps, relu, stats)
 
 
 class _DenseFunction(Function):

@@ -99,6 +99,10 @@ class SparseSequential(SparseModule):
                 continue
             if is_spconv_module(child):
                 steps.append((_SPARSE, name, child, False))
+                # conv directly in front of a BatchNorm1d: its kernel can leave the BN's sums
+                follows = items[pos + 1][1] if pos + 1 < len(items) else None
+                if hasattr(child, "weight"):
+                    child.emit_bn_stats = isinstance(follows, nn.BatchNorm1d)
             elif isinstance(child, nn.BatchNorm1d):
                 follows = items[pos + 1][1] if pos + 1 < len(items) else None
                 skip = isinstance(follows, nn.ReLU)
@@ -124,7 +128,8 @@ class SparseSequential(SparseModule):
                     x = nn.functional.relu(x)
             elif x.indices.shape[0]:      # feature-only children are skipped on empty tensors
                 if kind == _BN:
-                    x = x.replace_feature(bn_act(x.features, child, relu=fuse_relu))
+                    x = x.replace_feature(bn_act(x.features, child, relu=fuse_relu,
+                                                 stats=getattr(x, "bn_stats", None)))
                 else:
                     x = x.replace_feature(child(x.features))
         return x

@@ -291,6 +291,48 @@ def test_rulebook_plan_equals_its_parts(dev, n_vox):
     assert torch.equal(again["prefix"][128], plan["prefix"][128])
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 128), (32, 64), (80, 80), (128, 192), (40, 72)])
+def test_conv_epilogue_leaves_the_batchnorm_partials(dev, cin, cout):
+    """msmd_spconv_fwd_split_stats: per 128-row tile the column sums and sums of squares of the
+    rows the conv wrote (every instantiation width: one and two column passes, a partial last
+    channel tile, a partial last row tile; stream-K pieces summed by the owner first), and
+    msmd_bn_act_fwd_from_partials_f32 == the BatchNorm with its own statistics pass."""
+    from msmdfusion_amd import kernels as K
+    shape = [11, 64, 64]
+    idx = S.random_voxel_indices(2100, 2, shape, seed=cin + cout)
+    n = idx.shape[0]
+    nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
+    plan = K.rulebook_plan(nbr, tile_rows=(128,))
+    g = torch.Generator(device=dev).manual_seed(cin * 7 + cout)
+    f = torch.randn(n, cin, device=dev, generator=g)
+    w = torch.randn(27, cin, cout, device=dev, generator=g) / (27 * cin) ** 0.5
+    ws = K.pack_weight_split(w, 3)
+    for pre in (plan["prefix"][128], None):      # stream-K and whole tiles
+        out, part = K.conv_forward_split(f, ws, plan["tiled"], n, cout, 3, row_order=plan["order"],
+                                         tile_prefix=pre, bn_stats=True)
+        assert torch.equal(out, K.conv_forward_split(f, ws, plan["tiled"], n, cout, 3,
+                                                     row_order=plan["order"], tile_prefix=pre))
+        assert part.shape == ((n + 127) // 128, 2, cout)
+        rows = out[plan["order"].long()].double()          # tile t = positions 128 t ..
+        for ti in (0, part.shape[0] // 2, part.shape[0] - 1):
+            blk = rows[128 * ti:128 * ti + 128]
+            scale = max(blk.abs().max().item(), 1.0)
+            assert (part[ti, 0].double() - blk.sum(0)).abs().max().item() <= 1e-4 * scale
+            assert (part[ti, 1].double() - (blk * blk).sum(0)).abs().max().item() <= 1e-4 * scale ** 2
+        tot = part.double().sum(0)
+        assert (tot[0] - rows.sum(0)).abs().max().item() <= 1e-3
+    if cout % 4 == 0:
+        bn = torch.nn.BatchNorm1d(cout).to(dev).train()
+        bn2 = torch.nn.BatchNorm1d(cout).to(dev).train()
+        y1, m1, i1 = K.bn_act_forward(out, None, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                      True, 0.1, 1e-5, True)
+        y2, m2, i2 = K.bn_act_forward(out, None, bn2.weight, bn2.bias, bn2.running_mean,
+                                      bn2.running_var, True, 0.1, 1e-5, True, partials=part)
+        assert (m1 - m2).abs().max().item() <= 1e-6 and (i1 / i2 - 1).abs().max().item() <= 1e-5
+        assert (y1 - y2).abs().max().item() <= 1e-4
+        assert (bn.running_var - bn2.running_var).abs().max().item() <= 1e-6
+
+
 def test_scans_do_not_depend_on_what_else_runs(dev):
     """The scan-based index kernels (pair-list compaction, strided rulebook ranks, sparse_add
     maps) give the same tables while another stream keeps the chip busy with persistent conv
