@@ -404,11 +404,17 @@ def run_workload(workload, args, dev, rank, world, profile):
     # packet that drains the queue, so bracketing all launches of every
     # step would slow the measured throughput by ~25 %.
     prof = [] if profile else None
-    sampled = set() if prof is None else {0, args.steps // 2}
+    # three sampled steps, spread over the timed region; the roofline figure is the MEDIAN
+    # step's (one sampled step that happens to share the chip with a burst of the index pass
+    # read 88 instead of 122 TF for the same kernel: DESIGN.md 9.5)
+    sampled = set() if prof is None else {0, args.steps // 3, (2 * args.steps) // 3}
+    marks = []          # where each sampled step's records start
     torch.cuda.synchronize()
     D.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if i in sampled:
+            marks.append(len(prof))
         K.PROFILE = prof if i in sampled else None
         loss = step(batch)
     torch.cuda.synchronize()
@@ -441,7 +447,7 @@ def run_workload(workload, args, dev, rank, world, profile):
            "config": {"workload": wl["name"], "global_batch": spg * world,
                       "parallelism": "dp%d" % world, "index_prefetch": prefetch is not None,
                       "trainable_params": sum(p.numel() for p in params)}}
-    res["roofline"] = roofline(prof, workload) if prof else None
+    res["roofline"] = roofline(prof, workload, marks) if prof else None
     if rank == 0:   # tools/stream_prof.py divides a rocprofv3 trace of this run by this count
         print("[bench] workload=%s steps_total=%d (+1 untimed check step)" % (workload, calls[0]),
               file=sys.stderr)
@@ -561,13 +567,16 @@ def pmc_traffic(kernel_name, workload):
     return e.get("hbm_bytes_per_launch"), e.get("mfma_pipe_busy_frac"), os.path.relpath(path, ROOT)
 
 
-def roofline(prof, workload):
+def roofline(prof, workload, marks=None):
     """Dominant kernel = the conv kernel class with the most accumulated time.
     achieved = algorithmic flops (2 * pairs * Cin * Cout, the reference's MAC
     count mmdet3d/apis/flops_counter.py:9-12) / measured launch duration."""
     pair_cache = {}
     groups = {}
-    for kind, s, e, meta in prof:
+    per_step = {}       # kernel class -> [ms of sampled step 0, 1, ..]
+    bounds = sorted(set(marks or [0])) + [len(prof)]
+    step_of = [max(i for i, b in enumerate(bounds[:-1]) if b <= r) for r in range(len(prof))]
+    for rec, (kind, s, e, meta) in enumerate(prof):
         ms = s.elapsed_time(e)
         if kind in ("spconv_fwd", "spconv_fwd_split"):
             nbr = meta["nbr"]
@@ -597,8 +606,16 @@ def roofline(prof, workload):
         g["ms"] += ms
         g["flops"] += 2.0 * pairs * meta["c_in"] * meta["c_out"]
         g["launches"] += 1
+        ps = per_step.setdefault(name, [dict(ms=0.0, flops=0.0, launches=0)
+                                        for _ in range(len(bounds) - 1)])[step_of[rec]]
+        ps["ms"] += ms
+        ps["flops"] += 2.0 * pairs * meta["c_in"] * meta["c_out"]
+        ps["launches"] += 1
     total_ms = sum(g["ms"] for g in groups.values())
-    name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    name, g_all = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    # the dominant class's MEDIAN sampled step (by its total time)
+    steps_of_class = sorted((p for p in per_step[name] if p["launches"]), key=lambda p: p["ms"])
+    g = steps_of_class[len(steps_of_class) // 2]
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
     traffic, mfma_busy, pmc_file = pmc_traffic(name, workload)
     peak, peak_note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA (v_mfma_f32_16x16x4_f32)"
@@ -619,7 +636,12 @@ def roofline(prof, workload):
                             "re-measured in this run" % pmc_file,
             "mfma_pipe_busy_frac_pmc": mfma_busy,
             "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2), "launches": g["launches"],
-            "share_of_conv_time": round(g["ms"] / total_ms, 3),
+            "sampling": "HIP events around every conv launch of %d sampled steps of the timed "
+                        "region; figures of the median step (TF of each: %s)" % (
+                            len(steps_of_class),
+                            ", ".join("%.1f" % (p["flops"] / (p["ms"] * 1e-3) / 1e12)
+                                      for p in per_step[name] if p["launches"])),
+            "share_of_conv_time": round(g_all["ms"] / total_ms, 3),
             "all_conv_kernels": {k: {"ms": round(v["ms"], 3),
                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 3),
                                      "launches": v["launches"]} for k, v in groups.items()}}

@@ -356,7 +356,6 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
   int* nbt = (int*)(wl + 2 * kWU);                // [2][kvol + 1][kRows]; row kvol = output rows
   const int tstride = (kvol + 1) * kRows;
   int* ctl = nbt + 2 * tstride;                   // [0],[1]: offset masks; [2]: next tile
-  float* stat = (float*)(ctl + 72);               // [WV][2][NT * 16]: BN partials of the tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
@@ -772,11 +771,13 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
         }
       }
       // The BatchNorm that follows wants the per-channel sum and sum of squares of these
-      // rows: the tile's partials come from the accumulators (bn.hip's statistics pass
-      // would read the whole output again), one [2][c_out] slot per row tile, rows in fixed
-      // order: deterministic.
+      // rows: each wave leaves the partials of its 32 rows, straight from the accumulators
+      // (bn.hip's statistics pass would read the whole output again) -- one [2][c_out] slot
+      // per (row tile, wave), rows in fixed order: deterministic.  No LDS, no barrier: 4 KB
+      // more of LDS took the NT = 8 instantiation from two workgroups per CU to one (145 ->
+      // 185 us per launch) when the waves' sums were first combined here.
       if (bn_part) {
-        float* st_w = stat + wave * (2 * NT * 16);
+        float* dst = bn_part + ((size_t)rt * WV + wave) * 2 * ldo + 16 * mt0 + 4 * q;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
@@ -794,19 +795,10 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
               s1[e] += __shfl_xor(s1[e], m, 64);
               s2[e] += __shfl_xor(s2[e], m, 64);
             }
-          if (j == 0) {
-            *(f32x4*)(st_w + 16 * n + 4 * q) = s1;
-            *(f32x4*)(st_w + NT * 16 + 16 * n + 4 * q) = s2;
+          if (j == 0 && 16 * n + 4 * q < cout) {
+            *(f32x4*)(dst + 16 * n) = s1;
+            *(f32x4*)(dst + ldo + 16 * n) = s2;
           }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (tid < 2 * NT * 16) {
-          float v = 0.f;
-#pragma unroll
-          for (int w2 = 0; w2 < WV; ++w2) v += stat[w2 * (2 * NT * 16) + tid];
-          const int which = tid >= NT * 16 ? 1 : 0, c = tid - which * NT * 16;
-          if (c < cout) bn_part[(size_t)rt * 2 * ldo + (size_t)which * ldo + 16 * mt0 + c] = v;
         }
       }
       // ---- lane (j,q) holds out[row j][16n + 4q .. +3] ----
@@ -858,8 +850,7 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   const int sk_c0 = ((ovh_units + kbt - 1) / kbt) * (sk_c1() + 2);   // in cost units
   constexpr int kRows = WV * 32;
   const size_t smem = sizeof(u32x4) * 2 * UB * NP * NT * 64 +
-                      sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 72) +
-                      sizeof(float) * WV * 2 * NT * 16;
+                      sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 72);
   const int n_tiles = ceil_div(n_out, kRows);
   int nblk = n_tiles;
   const int slots = 256 * (WV == 4 ? split_slots_per_cu() : 1);
@@ -1299,8 +1290,13 @@ MSMD_EXPORT size_t msmd_spconv_fwd_split_workspace_bytes(int n_out, int cout) {
   return fwd_sk_ws_bytes(n_out, kMaxK, cout);
 }
 
-// bn_partials (or NULL): [ceil(n_out / 128)][2][c_out] floats -- per row tile the column sums
-// and sums of squares of the rows written (what msmd_bn_act_fwd_from_partials_f32 takes)
+// bn_partials (or NULL): [4 * ceil(n_out / 128)][2][c_out] floats -- per 32-row block of the
+// tiled order the column sums and sums of squares of the rows written (what
+// msmd_bn_act_fwd_from_partials_f32 takes)
+MSMD_EXPORT int msmd_spconv_fwd_split_stats_blocks(int n_out) {
+  return 4 * ceil_div(n_out > 0 ? n_out : 0, 128);
+}
+
 MSMD_EXPORT int msmd_spconv_fwd_split_stats(const float* planes, int n_in, int cin,
                                             const void* packed, const int32_t* nbr, int ld,
                                             int n_out, int kvol, int weight_flip,

@@ -1,10 +1,11 @@
 cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$GRAFT_REPO_ROOT
-for rep in 1 2 3; do
-for f in 1 0; do
-echo "bn_from_conv=$f: $(MSMD_BN_FROM_CONV=$f timeout 300 python bench.py --no-also --no-cpu-baseline 2>/dev/null | tail -1 | cut -c100-200)"
-done; done
-for rep in 1 2; do
-for f in 1 0; do
-echo "TL bn_from_conv=$f: $(MSMD_BN_FROM_CONV=$f timeout 300 python bench.py --workload transfusion_l --no-also --no-cpu-baseline 2>/dev/null | tail -1 | cut -c80-180)"
-done; done
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "RCCL\|amdgpu\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -3
+for i in 1 2 3; do timeout 300 python bench.py --no-also --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print(d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['frac'], r['avg_launch_us'], r['launches'], r['sampling'][-40:])"; done
+timeout 300 python bench.py --workload transfusion_l --no-also --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print(d['value'], d['ms_per_step'], r['kernel'], r['achieved'], r['frac'], r['avg_launch_us'], r['launches'], r['sampling'][-40:])"
