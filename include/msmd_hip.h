@@ -262,8 +262,8 @@ int msmd_spconv_fwd_split(const float* in_feat /* [n_in,c_in] */, int n_in, int 
                                                         or NULL: dynamic tile scheduler */,
                           msmd_stream_t stream);
 
-/* The same call that also leaves, per 32-row block of the output (in tile order), the column
- * sums and sums of squares of the rows it wrote: bn_partials[4 * ceil(n_out / 128)][2][c_out]
+/* The same call that also leaves, per 128-row tile of the output, the column sums and sums of
+ * squares of the rows it wrote: bn_partials[ceil(n_out / 128)][2][c_out]
  * (msmd_spconv_fwd_split_stats_blocks(n_out) blocks) -- the statistics
  * pass of the BatchNorm1d that follows a conv in make_sparse_convmodule / SparseBasicBlock
  * (mmdet3d/ops/sparse_block.py:87-117,161-190) without reading the output again

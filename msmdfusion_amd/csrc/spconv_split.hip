@@ -771,13 +771,17 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
         }
       }
       // The BatchNorm that follows wants the per-channel sum and sum of squares of these
-      // rows: each wave leaves the partials of its 32 rows, straight from the accumulators
-      // (bn.hip's statistics pass would read the whole output again) -- one [2][c_out] slot
-      // per (row tile, wave), rows in fixed order: deterministic.  No LDS, no barrier: 4 KB
-      // more of LDS took the NT = 8 instantiation from two workgroups per CU to one (145 ->
-      // 185 us per launch) when the waves' sums were first combined here.
+      // rows: the tile's partials come straight from the accumulators (bn.hip's statistics
+      // pass would read the whole output again) -- one [2][c_out] slot per row tile, rows and
+      // waves in fixed order: deterministic.  The four waves' sums meet in the weight buffer,
+      // which is idle between a tile's last unit and the next tile's first (a barrier makes
+      // sure every wave has left that unit); LDS of its own for this -- 4 KB -- took the NT = 8
+      // instantiation from two workgroups per CU to one (145 -> 185 us per launch), and one
+      // slot per WAVE instead made the BN's finalize kernel read four times as many (7 -> 12 us).
       if (bn_part) {
-        float* dst = bn_part + ((size_t)rt * WV + wave) * 2 * ldo + 16 * mt0 + 4 * q;
+        float* stat = (float*)wl;
+        float* st_w = stat + wave * (2 * NT * 16);
+        __builtin_amdgcn_s_barrier();          // nobody reads weights from wl any more
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
@@ -795,11 +799,22 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
               s1[e] += __shfl_xor(s1[e], m, 64);
               s2[e] += __shfl_xor(s2[e], m, 64);
             }
-          if (j == 0 && 16 * n + 4 * q < cout) {
-            *(f32x4*)(dst + 16 * n) = s1;
-            *(f32x4*)(dst + ldo + 16 * n) = s2;
+          if (j == 0) {
+            *(f32x4*)(st_w + 16 * n + 4 * q) = s1;
+            *(f32x4*)(st_w + NT * 16 + 16 * n + 4 * q) = s2;
           }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < 2 * NT * 16) {
+          float v = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < WV; ++w2) v += stat[w2 * (2 * NT * 16) + tid];
+          const int which = tid >= NT * 16 ? 1 : 0, c = tid - which * NT * 16;
+          if (c < cout) bn_part[(size_t)rt * 2 * ldo + (size_t)which * ldo + 16 * mt0 + c] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // (before the next tile's weights land there)
       }
       // ---- lane (j,q) holds out[row j][16n + 4q .. +3] ----
 #pragma unroll
@@ -1290,11 +1305,10 @@ MSMD_EXPORT size_t msmd_spconv_fwd_split_workspace_bytes(int n_out, int cout) {
   return fwd_sk_ws_bytes(n_out, kMaxK, cout);
 }
 
-// bn_partials (or NULL): [4 * ceil(n_out / 128)][2][c_out] floats -- per 32-row block of the
-// tiled order the column sums and sums of squares of the rows written (what
-// msmd_bn_act_fwd_from_partials_f32 takes)
+// bn_partials (or NULL): [ceil(n_out / 128)][2][c_out] floats -- per row tile the column sums
+// and sums of squares of the rows written (what msmd_bn_act_fwd_from_partials_f32 takes)
 MSMD_EXPORT int msmd_spconv_fwd_split_stats_blocks(int n_out) {
-  return 4 * ceil_div(n_out > 0 ? n_out : 0, 128);
+  return ceil_div(n_out > 0 ? n_out : 0, 128);
 }
 
 MSMD_EXPORT int msmd_spconv_fwd_split_stats(const float* planes, int n_in, int cin,

@@ -293,8 +293,8 @@ def test_rulebook_plan_equals_its_parts(dev, n_vox):
 
 @pytest.mark.parametrize("cin,cout", [(64, 128), (32, 64), (80, 80), (128, 192), (40, 72)])
 def test_conv_epilogue_leaves_the_batchnorm_partials(dev, cin, cout):
-    """msmd_spconv_fwd_split_stats: per 32-row block (a wave's rows of a 128-row tile) the
-    column sums and sums of squares of the rows the conv wrote (every instantiation width: one and two column passes, a partial last
+    """msmd_spconv_fwd_split_stats: per 128-row tile the column sums and sums of squares of the
+    rows the conv wrote (every instantiation width: one and two column passes, a partial last
     channel tile, a partial last row tile; stream-K pieces summed by the owner first), and
     msmd_bn_act_fwd_from_partials_f32 == the BatchNorm with its own statistics pass."""
     from msmdfusion_amd import kernels as K
@@ -312,10 +312,10 @@ def test_conv_epilogue_leaves_the_batchnorm_partials(dev, cin, cout):
                                          tile_prefix=pre, bn_stats=True)
         assert torch.equal(out, K.conv_forward_split(f, ws, plan["tiled"], n, cout, 3,
                                                      row_order=plan["order"], tile_prefix=pre))
-        assert part.shape == (4 * ((n + 127) // 128), 2, cout)
-        rows = out[plan["order"].long()].double()          # block b = positions 32 b ..
-        for ti in (0, part.shape[0] // 2, (n - 1) // 32):
-            blk = rows[32 * ti:32 * ti + 32]
+        assert part.shape == ((n + 127) // 128, 2, cout)
+        rows = out[plan["order"].long()].double()          # tile t = positions 128 t ..
+        for ti in (0, part.shape[0] // 2, part.shape[0] - 1):
+            blk = rows[128 * ti:128 * ti + 128]
             scale = max(blk.abs().max().item(), 1.0)
             assert (part[ti, 0].double() - blk.sum(0)).abs().max().item() <= 1e-4 * scale
             assert (part[ti, 1].double() - (blk * blk).sum(0)).abs().max().item() <= 1e-4 * scale ** 2
