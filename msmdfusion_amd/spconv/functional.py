@@ -75,42 +75,6 @@ def _conv_f32(x, weight, krsc, transpose, nbr, n_out, weight_flip=False, row_ord
     return torch.cat(outs, 1)
 
 
-_SIDE_STREAMS = {}
-
-
-class _SideLaunch:
-    """Enqueue fn() on a per-device side stream behind everything the current
-    stream has queued; result() makes the current stream wait for it and hands
-    the tensor over.  Opt-in (MSMD_WGRAD_STREAM=1): measured +2 % on configs[1],
-    +3 % on the LC path, gradients bit-identical -- but two kernels sharing the
-    chip stretch each other's launch durations, which blurs the per-kernel
-    roofline figures bench.py and rocprofv3 report, so the default keeps one
-    kernel at a time."""
-
-    def __init__(self, fn, enabled=True):
-        self.event = None
-        if not enabled or os.environ.get("MSMD_WGRAD_STREAM", "0") != "1":
-            self.value = fn()
-            return
-        main = torch.cuda.current_stream()
-        key = main.device
-        side = _SIDE_STREAMS.get(key)
-        if side is None:
-            side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self.value = fn()
-            self.event = torch.cuda.Event()
-            self.event.record(side)
-        self.main = main
-
-    def result(self):
-        if self.event is not None:
-            self.main.wait_event(self.event)
-            self.value.record_stream(self.main)
-        return self.value
-
-
 _FROZEN_PACKS = {}
 
 
@@ -190,18 +154,17 @@ class _SparseConvFunction(Function):
         grad_out = grad_out.contiguous()
         d_feat = d_w = None
         if ctx.needs_input_grad[1]:
-            # wgrad and dgrad both need grad_out only: with MSMD_WGRAD_STREAM=1 wgrad
-            # goes to a side stream and its thousands of short workgroups fill the CUs
-            # the persistent dgrad kernel leaves idle in its tail
+            # (rounds 1-2 could put wgrad on a side stream, MSMD_WGRAD_STREAM=1: its thousands
+            # of short workgroups filled the CUs the persistent dgrad kernel left idle in its
+            # tail, +2-3 %.  The whole-block kernel is one 144 KB workgroup per CU: next to
+            # dgrad it measured -1 % on the LC path and -3 % on configs[1]; removed.)
             pairs, num = rb.pairs()     # (cached; built on this stream if not yet)
-
-            def run_wgrad():
-                if conv_planes() in (1, 2, 3) and K.wgrad_split_supported(c_in, c_out):
-                    return K.conv_wgrad_split(features, grad_out, pairs, num, conv_planes(),
-                                              krsc_shape=weight.shape if krsc else None)
-                return K.conv_wgrad(features, grad_out, pairs, num,
-                                    krsc_shape=weight.shape if krsc else None)
-            wgrad_done = _SideLaunch(run_wgrad, enabled=ctx.needs_input_grad[0])
+            if conv_planes() in (1, 2, 3) and K.wgrad_split_supported(c_in, c_out):
+                d_w = K.conv_wgrad_split(features, grad_out, pairs, num, conv_planes(),
+                                         krsc_shape=weight.shape if krsc else None)
+            else:
+                d_w = K.conv_wgrad(features, grad_out, pairs, num,
+                                   krsc_shape=weight.shape if krsc else None)
         if ctx.needs_input_grad[0] and _use_split(c_out, c_in, rb.nbr_fwd.shape[0],
                                                   grad_out.shape[0]):
             np_ = conv_planes()
@@ -217,8 +180,6 @@ class _SparseConvFunction(Function):
             d_feat = _conv_f32(grad_out, weight, krsc, True,
                                rb.nbr_fwd if rb.is_subm else rb.nbr_bwd, rb.n_in,
                                weight_flip=rb.is_subm, row_order=order)
-        if ctx.needs_input_grad[1]:
-            d_w = wgrad_done.result()
         return d_feat, d_w, None, None, None
 
 
