@@ -8,12 +8,17 @@
 //     mixed rows:    [ feat3D[row3] | gate(feat3D[row3]) * feat2D[row2]      ]
 // -- in the reference (and in this repo until round 3) a dozen indexing / cat / pad / mul
 // launches per stage and twice that in backward (three index_add_ with their zero fills:
-// 0.63 ms of the 14.5 ms LC step).  The two Linear+ReLU gates stay GEMMs; everything around
-// them is HBM-bound row copying: one thread per 16-byte piece of an output row.
+// 0.63 ms of the 14.5 ms LC step).  Everything around the two Linear+ReLU gates is HBM-bound
+// row copying: one thread per 16-byte piece of an output row.  (The gates themselves -- skinny
+// fp32 GEMMs that hipBLASLt ran at a few TF -- are the row-streaming kernels at the end of
+// this file: msmd_rows_linear_*.)
 //
 // backward: d conv3D = the left block of the only-3D rows; d gate = right block of the mixed
 // rows * feat2D; d cross_gate[t] = sum over the only-2D rows whose nearest voxel is t of
-// right block * feat2D -- float atomics, as torch's index_add_ (the one it replaces).
+// right block * feat2D -- a segmented sum over rows sorted by nearest voxel (`order` /
+// `starts` from the index pass: one wave per target row, fixed order, deterministic; the
+// dummy row that all unmatched rows share is spread over kDummyBlocks blocks and reduced);
+// without the sorted lists: float atomics, as torch's index_add_ (the one it replaces).
 // feat3D / feat2D get no gradient (frozen LiDAR encoder, raw virtual-point voxels): the
 // Python wrapper falls back to the unfused ops when they ask for one.
 #include "common.hpp"
