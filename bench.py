@@ -55,7 +55,6 @@ PINNED_CPUS = pin_host_threads() if (__name__ == "__main__" or
                                      os.environ.get("MSMD_PIN_ON_IMPORT") == "1") else None
 
 import torch  # noqa: E402
-import torch.nn.functional as F  # noqa: E402
 
 # more busy host threads than the cgroup pays CPUs for (8 ranks on a 16-CPU box): waits
 # block instead of spinning (device flag: before the first HIP call of the process)

@@ -19,7 +19,6 @@ different forward.
 import torch
 from torch import nn
 
-from . import kernels as K
 from .bev import SECOND, SECONDFPN, SPPModule
 from .spconv import functional as Fsp
 from .spconv.core import IndiceData

@@ -6,7 +6,6 @@ functions require CUDA (ROCm) tensors and raise otherwise -- no CPU path.
 """
 import ctypes as C
 import os
-import threading
 
 import torch
 

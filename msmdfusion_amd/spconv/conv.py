@@ -14,14 +14,13 @@ from typing import List, Optional, Tuple, Union
 
 import numpy as np
 import torch
-from torch import nn
 from torch.nn import init
 from torch.nn.parameter import Parameter
 
 from .. import kernels as K
 from ..registry import CONV_LAYERS
 from . import functional as Fsp
-from .core import IndiceData, SparseConvTensor, build_rulebook
+from .core import IndiceData, SparseConvTensor
 from .modules import SparseModule
 
 
