@@ -137,26 +137,38 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void bn_eval_stats(const float* __restrict__ rm,
-                                                     const float* __restrict__ rv, int c, float eps,
-                                                     float* mean, float* invstd) {
-  int ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch >= c) return;
-  mean[ch] = rm[ch];
-  invstd[ch] = 1.f / sqrtf(rv[ch] + eps);
-}
-
+// EVAL: `mean` / `invstd` are the running mean and VARIANCE; 1 / sqrt(var + eps) is taken on
+// the fly (correctly rounded divide and sqrt: the file's build flags) and block 0 leaves the per-channel
+// mean / invstd in save_mean / save_invstd for the backward pass -- one launch per frozen
+// BatchNorm instead of two (the LC recipe freezes the LiDAR encoder: 21 of them per step).
+template <bool EVAL>
 __global__ __launch_bounds__(256) void bn_fwd_apply(const float* __restrict__ x,
                                                     const float* __restrict__ res, long total4,
                                                     int c4, const float* __restrict__ mean,
                                                     const float* __restrict__ invstd,
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, int relu,
-                                                    float* __restrict__ y) {
+                                                    float* __restrict__ y, float eps,
+                                                    float* __restrict__ save_mean,
+                                                    float* __restrict__ save_invstd) {
+  if (EVAL && blockIdx.x == 0) {
+    for (int g = threadIdx.x; g < c4; g += 256) {
+      f32x4 is = ((const f32x4*)invstd)[g];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) is[s] = 1.f / sqrtf(is[s] + eps);
+      ((f32x4*)save_mean)[g] = ((const f32x4*)mean)[g];
+      ((f32x4*)save_invstd)[g] = is;
+    }
+  }
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long)gridDim.x * 256) {
     const int g = (int)(e % c4);
     f32x4 v = ((const f32x4*)x)[e];
-    const f32x4 m = ((const f32x4*)mean)[g], is = ((const f32x4*)invstd)[g];
+    const f32x4 m = ((const f32x4*)mean)[g];
+    f32x4 is = ((const f32x4*)invstd)[g];
+    if (EVAL) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) is[s] = 1.f / sqrtf(is[s] + eps);
+    }
     const f32x4 ga = ((const f32x4*)gamma)[g], be = ((const f32x4*)beta)[g];
     v = (v - m) * is * ga + be;
     if (res) v += ((const f32x4*)res)[e];
@@ -264,13 +276,16 @@ MSMD_EXPORT int msmd_bn_act_fwd_f32(const float* x, const float* residual, int n
     MSMD_LAUNCH(bn_fwd_partial, dim3(nblk), dim3(256), 0, st, x, n, c, part);
     MSMD_LAUNCH(bn_fwd_finalize, dim3(ceil_div(c, 16)), dim3(256), 0, st, part, nblk, n, c, eps,
                 momentum, running_mean, running_var, save_mean, save_invstd);
-  } else {
-    MSMD_LAUNCH(bn_eval_stats, dim3(ceil_div(c, 256)), dim3(256), 0, st, running_mean,
-                running_var, c, eps, save_mean, save_invstd);
   }
   const long total4 = (long)n * (c >> 2);
-  MSMD_LAUNCH(bn_fwd_apply, dim3(stream_blocks(total4)), dim3(256), 0, st, x, residual, total4,
-              c >> 2, save_mean, save_invstd, gamma, beta, relu, y);
+  if (training)
+    MSMD_LAUNCH(bn_fwd_apply<false>, dim3(stream_blocks(total4)), dim3(256), 0, st, x, residual,
+                total4, c >> 2, save_mean, save_invstd, gamma, beta, relu, y, eps,
+                (float*)nullptr, (float*)nullptr);
+  else
+    MSMD_LAUNCH(bn_fwd_apply<true>, dim3(stream_blocks(total4)), dim3(256), 0, st, x, residual,
+                total4, c >> 2, running_mean, running_var, gamma, beta, relu, y, eps, save_mean,
+                save_invstd);
   return launch_status();
 }
 
@@ -292,8 +307,9 @@ MSMD_EXPORT int msmd_bn_act_fwd_from_partials_f32(const float* x, const float* r
   MSMD_LAUNCH(bn_fwd_finalize, dim3(ceil_div(c, 16)), dim3(256), 0, st, partials, n_partials, n, c,
               eps, momentum, running_mean, running_var, save_mean, save_invstd);
   const long total4 = (long)n * (c >> 2);
-  MSMD_LAUNCH(bn_fwd_apply, dim3(stream_blocks(total4)), dim3(256), 0, st, x, residual, total4,
-              c >> 2, save_mean, save_invstd, gamma, beta, relu, y);
+  MSMD_LAUNCH(bn_fwd_apply<false>, dim3(stream_blocks(total4)), dim3(256), 0, st, x, residual,
+              total4, c >> 2, save_mean, save_invstd, gamma, beta, relu, y, eps, (float*)nullptr,
+              (float*)nullptr);
   return launch_status();
 }
 
