@@ -160,3 +160,28 @@ def test_tiling_rank_table_matches_its_derivation():
         want[k] = bit
     assert table == want
     assert table[13] == 0 and max(table[k] for k in (0, 2, 6, 8, 18, 20, 24, 26)) == 26
+
+
+def test_batchnorm_partials_belong_to_one_tensor_object():
+    """A conv in front of a BatchNorm1d is marked (SparseSequential / SparseBasicBlock) so that
+    its kernel leaves the BN's statistics partials on ITS output tensor object; whatever
+    replaces that tensor's features must not inherit them (stale sums would silently become
+    another layer's batch statistics)."""
+    import torch
+    from torch import nn
+    from msmdfusion_amd import spconv
+    from msmdfusion_amd.sparse_block import make_sparse_convmodule
+    idx = torch.tensor([[0, 1, 2, 3], [0, 1, 2, 4]], dtype=torch.int32)
+    x = spconv.SparseConvTensor(torch.zeros(2, 8), idx, [8, 8, 8], 1)
+    x.bn_stats = torch.ones(1, 2, 8)
+    assert getattr(x.replace_feature(torch.ones(2, 8)), "bn_stats", None) is None
+    assert getattr(x.shadow_copy(), "bn_stats", None) is None
+    x.features = torch.ones(2, 8)
+    assert getattr(x, "bn_stats", None) is None
+    seq = make_sparse_convmodule(8, 16, 3, "k", norm_cfg=dict(type="BN1d"), conv_type="SubMConv3d")
+    seq._compile()
+    conv = next(m for m in seq.children() if isinstance(m, spconv.SparseConvolution))
+    assert conv.emit_bn_stats is True
+    plain = spconv.SparseSequential(spconv.SubMConv3d(8, 8, 3, indice_key="a"), nn.ReLU())
+    plain._compile()
+    assert next(iter(plain.children())).emit_bn_stats is False
