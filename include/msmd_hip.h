@@ -362,7 +362,9 @@ int msmd_spconv_wgrad_split(const float* in_feat, int c_in, const float* d_out, 
  * pair lists (index data: once per rulebook), n_chunks its chunk count; NULL = one chunk (the
  * plain offset-major sequence, what msmd_spconv_wgrad_split runs).  Same sums per (offset,
  * channel pair) in another fixed order: results agree to fp32 rounding, run to run identical.
- * Workspace: msmd_spconv_wgrad_segments_workspace_bytes. */
+ * Workspace: msmd_spconv_wgrad_segments_workspace_bytes.
+ * msmd_rulebook_pair_segments_ints returns 0 for kernel volumes the whole-block kernel does
+ * not take (> 64, e.g. 5x5x5): build no table, pass seg_table = NULL, the slab kernel runs. */
 size_t msmd_rulebook_pair_segments_ints(int kernel_volume, int n_chunks);
 int msmd_rulebook_pair_segments(const int32_t* indice_pairs /* [K,2,ld] */,
                                 const int32_t* indice_num /* [K] device */, int ld,
@@ -725,7 +727,8 @@ int msmd_modality_split_stats(const int32_t* idx_3d, int n3,
 /* rows[r] = the r-th i, ascending, with flags[i * stride] == value (at most `capacity` are
  * written; total, if not NULL, receives the count): the row lists `mask.nonzero()` gives the
  * reference (sparse_multimodal_encoder_painting.py:332-340: only_3D / only_2D masks) without
- * the host waiting for the size -- the caller has it from msmd_modality_split_stats. */
+ * the host waiting for the size -- the caller has it from msmd_modality_split_stats.
+ * rows[count .. capacity) are set to -1 (torch.nonzero_static's padding). */
 size_t msmd_rows_where_workspace_bytes(int n);
 int msmd_rows_where_eq(const int32_t* flags, int stride, int n, int value, int64_t* rows,
                        int capacity, int32_t* total, void* workspace, size_t workspace_bytes,

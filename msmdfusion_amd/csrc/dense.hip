@@ -463,6 +463,13 @@ struct EmitRow {
     if (c && p < cap) out[p] = i;
   }
 };
+// rows[total .. cap) <- -1 (what torch.nonzero_static pads with): a caller whose host-side count
+// is larger than the real one (stale statistics) gets a row id that index_select rejects instead
+// of whatever the allocation held.  Normally total == cap and the block leaves at once.
+__global__ __launch_bounds__(256) void rows_tail_fill(int64_t* __restrict__ rows, int cap,
+                                                      const int* __restrict__ total) {
+  for (int i = *total + (int)threadIdx.x; i < cap; i += 256) rows[i] = -1;
+}
 }  // namespace
 }  // namespace msmd
 
@@ -481,6 +488,7 @@ MSMD_EXPORT int msmd_rows_where_eq(const int32_t* flags, int stride, int n, int 
   int* tiles = (int*)workspace;
   int* tot = total ? total : (int*)((char*)workspace + align_up(sizeof(int) * ((size_t)scan_num_tiles(n > 0 ? n : 1) + 1)));
   device_scan(FlagEq{flags, stride, value}, EmitRow{rows, capacity}, n, tiles, tot, -1, st);
+  if (capacity > 0) MSMD_LAUNCH(rows_tail_fill, dim3(1), dim3(256), 0, st, rows, capacity, tot);
   return launch_status();
 }
 

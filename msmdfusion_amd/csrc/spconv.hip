@@ -787,6 +787,7 @@ namespace msmd {   // spconv_wgrad_block.hip
 bool wgrad_block_supported(int c_in, int c_out, int kvol, int ld);
 size_t wgrad_block_workspace_bytes(int kvol, int c_in, int c_out, int nchunk);
 size_t wgrad_segment_table_ints(int kvol, int nchunk);
+int wgrad_block_max_kvol();
 int wgrad_pair_segments(const int32_t* pairs, const int32_t* num, int ld, int kvol,
                         int chunk_rows, int nchunk, int32_t* table, hipStream_t st);
 int wgrad_block(const float* in_feat, int c_in, const float* d_out, int c_out,
@@ -993,8 +994,12 @@ MSMD_EXPORT int msmd_spconv_wgrad_split_supported(int c_in, int c_out) {
 // sequence (spconv_wgrad_block.hip): int32 [msmd_rulebook_pair_segments_ints(K, n_chunks)],
 // chunk c = output rows [c * chunk_rows, (c + 1) * chunk_rows).  Index data: computed once per
 // rulebook, next to the pair lists.
+// 0 for kernel volumes the whole-block kernel does not take (> 64, e.g. 5x5x5): no table -- the
+// caller passes seg_table = NULL and msmd_spconv_wgrad_split_segments runs the slab kernel.
 MSMD_EXPORT size_t msmd_rulebook_pair_segments_ints(int kernel_volume, int n_chunks) {
-  return kernel_volume > 0 && n_chunks > 0 ? wgrad_segment_table_ints(kernel_volume, n_chunks) : 0;
+  return kernel_volume > 0 && kernel_volume <= wgrad_block_max_kvol() && n_chunks > 0
+             ? wgrad_segment_table_ints(kernel_volume, n_chunks)
+             : 0;
 }
 MSMD_EXPORT int msmd_rulebook_pair_segments(const int32_t* indice_pairs, const int32_t* indice_num,
                                             int ld, int kernel_volume, int chunk_rows,

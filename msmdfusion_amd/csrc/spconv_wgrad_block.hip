@@ -795,6 +795,7 @@ bool wgrad_block_supported(int c_in, int c_out, int kvol, int ld) {
 }
 
 size_t wgrad_segment_table_ints(int kvol, int nchunk) { return 3 * (size_t)nchunk * kvol + 1; }
+int wgrad_block_max_kvol() { return kMaxKvol; }
 
 int wgrad_pair_segments(const int32_t* pairs, const int32_t* num, int ld, int kvol,
                         int chunk_rows, int nchunk, int32_t* table, hipStream_t st) {

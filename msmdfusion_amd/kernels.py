@@ -197,7 +197,14 @@ def subm_index_method(n, batch_size, spatial_shape, method=None):
     method = method or _SUBM_INDEX
     if method != "auto":
         return method
-    words = int(batch_size) * int(spatial_shape[0]) * int(spatial_shape[1]) * int(spatial_shape[2]) / 32
+    # the bitmap is laid out in 4 x 8 x 8 bricks (csrc/rulebook.hip): the grid padded to
+    # whole bricks is what it clears and counts, and the entry point takes fewer than 2^24
+    # bricks -- a thin grid (D = 1..3 pads 4x along z) or a huge one takes the hash index
+    d, h, w = (int(v) for v in spatial_shape)
+    bricks = int(batch_size) * ((d + 3) // 4) * ((h + 7) // 8) * ((w + 7) // 8)
+    if bricks >= 1 << 24:
+        return "hash"
+    words = bricks * 8          # 256 cells per brick
     # the bitmap's clear + count (~3 ps per 32-cell word) against what it saves per voxel
     # (~0.3 ns), and not below the size where either is launch-bound anyway
     return "bitmap" if n >= _SUBM_BITMAP_MIN_VOXELS and words <= _SUBM_BITMAP_WORDS_PER_VOXEL * n \
@@ -911,7 +918,10 @@ def pair_segments(pairs, num, chunk_rows=None):
     if n_chunks > WGRAD_MAX_CHUNKS:          # very large sets: larger chunks
         chunk_rows = (ld + WGRAD_MAX_CHUNKS - 1) // WGRAD_MAX_CHUNKS
         n_chunks = (ld + chunk_rows - 1) // chunk_rows
-    table = torch.empty((int(lib.msmd_rulebook_pair_segments_ints(kvol, n_chunks)),),
+    n_ints = int(lib.msmd_rulebook_pair_segments_ints(kvol, n_chunks))
+    if n_ints == 0:      # kernel volume > 64 (5x5x5 ...): the slab wgrad kernel, which takes no table
+        return None
+    table = torch.empty((n_ints,),
                         dtype=torch.int32, device=pairs.device)
     check(lib.msmd_rulebook_pair_segments(_p(pairs), _p(num), ld, kvol, chunk_rows, n_chunks,
                                           _p(table), _stream()), "msmd_rulebook_pair_segments")

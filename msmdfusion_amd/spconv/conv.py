@@ -123,6 +123,13 @@ class SparseConvolution(SparseModule):
         Fsp.invalidate_packed_weights()
         return super()._load_from_state_dict(*args, **kwargs)
 
+    def train(self, mode=True):
+        # hooks that swap or rewrite parameters through `.data` (EMA, fp16 master copies) do
+        # it at train()/eval() boundaries and leave `_version` where it was: repack
+        from . import functional as Fsp
+        Fsp.invalidate_packed_weights(self.weight)
+        return super().train(mode)
+
     def forward(self, input: SparseConvTensor):
         assert isinstance(input, SparseConvTensor)
         assert input.features.shape[1] == self.in_channels, "channel size mismatch"

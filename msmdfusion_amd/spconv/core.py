@@ -59,8 +59,9 @@ class plan_batch:
             if exc_type is None:
                 self.flush()
             else:       # tables never filled: a rulebook that survives the error must not be used
-                for j in self.subm_jobs:
+                for j in self.subm_jobs:        # (cached_rulebook rebuilds a poisoned entry)
                     j["rb"].nbr_fwd = None
+                    j["rb"].pending = False
                 self.subm_jobs, self.jobs = [], {}
         return False
 
@@ -89,8 +90,11 @@ class plan_batch:
         except Exception:
             for j in subm:                      # never filled: must not be used
                 j["rb"].nbr_fwd = None
+                j["rb"].pending = False
             self.jobs = {}
             raise
+        for j in subm:
+            j["rb"].pending = False
         jobs, todo = list(self.jobs.values()), []
         self.jobs = {}
         for j in jobs:
@@ -139,6 +143,9 @@ class IndiceData:
         self.out_spatial_shape = out_spatial_shape
         self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
         self.algo = algo
+        # True between build_rulebook() inside a plan_batch() and that context's exit: the
+        # SubM table is allocated but not filled yet -- nothing may read it (table() checks)
+        self.pending = False
         self._pairs = None
         self._pair_segments = False     # not computed yet (None = chunking off)
         self._order_fwd = None
@@ -147,6 +154,16 @@ class IndiceData:
         self._tiled_bwd = None
         self._prefix_fwd = {}
         self._prefix_bwd = {}
+
+    def check_ready(self):
+        """Raise if the table cannot be read yet / any more (deferred fill still pending, or
+        the launch set that should have filled it failed)."""
+        if self.pending:
+            raise RuntimeError("this SubM rulebook's table is filled when the enclosing "
+                               "spconv.plan_batch() closes; it cannot be used inside it")
+        if self.nbr_fwd is None:
+            raise RuntimeError("this rulebook's table was never filled (its plan_batch() "
+                               "failed); build it again")
 
     @property
     def n_in(self):
@@ -332,6 +349,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
                         list(spatial_shape), ksize, [1, 1, 1], [k // 2 for k in ksize],
                         dilation, algo)
         if defer:
+            rb.pending = True
             batch.subm(rb, batch_size)
         return rb
     out_idx, nbr_fwd, nbr_bwd, out_shape = K.rulebook_conv(indices, batch_size, spatial_shape,
@@ -414,7 +432,8 @@ class SparseConvTensor:
         ident = (self.indices.data_ptr(), self.indices.shape[0], tuple(self.spatial_shape),
                  tuple(ksize), tuple(stride), tuple(padding), tuple(dilation), bool(subm))
         hit = self._rb_cache.get(ident)
-        if hit is not None and hit.indices is self.indices:
+        # (an entry whose deferred fill failed is rebuilt, not handed out again)
+        if hit is not None and hit.indices is self.indices and hit.nbr_fwd is not None:
             return hit
         rb = build_rulebook(self.indices, self.batch_size, self.spatial_shape, list(ksize),
                             list(stride), list(padding), list(dilation), subm)

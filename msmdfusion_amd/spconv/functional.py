@@ -151,16 +151,26 @@ def _pack_f32(weight, transpose, krsc):
     return packed
 
 
-def invalidate_packed_weights():
-    """Forget every cached packed image (call after writing weights through `.data` /
-    load_state_dict; SparseConvolution's load hook does)."""
-    _PACKS.clear()
-    _F32_PACKS.clear()
+def invalidate_packed_weights(weight=None):
+    """Forget the cached packed images -- all of them, or those of one parameter.  Writes
+    through `.data` (mmcv's Fp16OptimizerHook.copy_params_to_fp16, EMAHook's parameter swap,
+    `param.data.copy_` in custom loops) do not move `_version`; call this after them.
+    SparseConvolution calls it from its state-dict load hook and from train() / eval()
+    (EMA swaps sit at those boundaries); distributed.TrainStep calls it when its optimizer
+    is not one of torch's in-place ones."""
+    if weight is None:
+        _PACKS.clear()
+        _F32_PACKS.clear()
+        return
+    _PACKS.pop(id(weight), None)
+    for t in (False, True):
+        _F32_PACKS.pop((id(weight), t), None)
 
 
 def _conv_forward(features, weight, rb, krsc, want_dgrad, bn_stats=False):
     """-> (out, packed W^T for dgrad | None[, BN partials | None when bn_stats])."""
     c_in, c_out = (weight.shape[-1], weight.shape[0]) if krsc else weight.shape[1:]
+    rb.check_ready()
     if _use_split(c_in, c_out, rb.nbr_fwd.shape[0], features.shape[0]):
         np_ = conv_planes()
         packed_t = None

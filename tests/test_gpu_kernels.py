@@ -385,6 +385,13 @@ def test_rows_where_eq(dev):
         assert torch.equal(K.rows_where_eq(ones, 1, n), torch.arange(n, device=dev))
         if n > 10:      # (a smaller capacity: the first rows, nothing written past them)
             assert torch.equal(K.rows_where_eq(ones, 1, 10), torch.arange(10, device=dev))
+        # a host-side count LARGER than the real one (stale statistics): the tail is -1, the
+        # padding torch.nonzero_static uses -- never whatever the allocation held
+        half = (torch.arange(n, device=dev) % 2).int()
+        real = int((half == 1).sum())
+        got = K.rows_where_eq(half, 1, real + 5)
+        assert torch.equal(got[:real], (half == 1).nonzero().flatten())
+        assert bool((got[real:] == -1).all())
 
 
 def _plan_tables(dev):
@@ -701,6 +708,39 @@ def test_split_wgrad(dev, cin, cout, planes):
     pairs2, num2 = K.rulebook_pairs(nbr_fwd, ld=max(n, m))
     dw2 = K.conv_wgrad_split(t(f, dev), t(g2[perm], dev), pairs2, num2, planes)
     np.testing.assert_allclose(dw2.cpu().numpy(), edw2, rtol=tol, atol=5 * tol)
+
+
+def test_wgrad_kernel_volume_above_64(dev):
+    """5x5x5 SubM (K = 125), 64 -> 64: the whole-block wgrad kernel takes K <= 64, so no
+    segment table exists for this rulebook (pair_segments -> None) and the weight gradient
+    comes from the 64 x 64 slab kernel -- through IndiceData / autograd as a module would."""
+    from msmdfusion_amd import kernels as K
+    from msmdfusion_amd import spconv
+    shape = [9, 30, 30]
+    idx = S.random_voxel_indices(1200, 2, shape, seed=11)
+    n = idx.shape[0]
+    rng = np.random.RandomState(3)
+    f = rng.randn(n, 64).astype(np.float32)
+    g = rng.randn(n, 64).astype(np.float32)
+    w = (rng.randn(125, 64, 64) / np.sqrt(125 * 64)).astype(np.float32)
+    oi, pr, nm, _ = O.get_indice_pairs(idx, 2, shape, 5, 1, 2, 1, True)
+    exp = O.indice_conv_fwd(f, w, pr, nm, n, subm=True)
+    edin, edw = O.indice_conv_bwd(f, w, g, pr, nm, subm=True)
+    conv = spconv.SubMConv3d(64, 64, 5, padding=2, bias=False).to(dev)
+    with torch.no_grad():      # KRSC [c_out, kd, kh, kw, c_in]
+        conv.weight.copy_(t(w, dev).permute(2, 0, 1).reshape(64, 5, 5, 5, 64))
+    x = spconv.SparseConvTensor(t(f, dev).requires_grad_(True), t(idx, dev), shape, 2)
+    rb = x.cached_rulebook([5, 5, 5], [1, 1, 1], [2, 2, 2], [1, 1, 1], True)
+    rb.prepare(True, 64, 64)
+    assert rb.pair_segments() is None
+    y = conv(x).features
+    np.testing.assert_allclose(y.detach().cpu().numpy(), exp, rtol=TOL, atol=TOL)
+    y.backward(t(g, dev))
+    np.testing.assert_allclose(x.features.grad.cpu().numpy(), edin, rtol=TOL, atol=TOL)
+    dw = conv.weight.grad.reshape(64, 125, 64).permute(1, 2, 0)
+    np.testing.assert_allclose(dw.cpu().numpy(), edw, rtol=TOL, atol=TOL * 5)
+    pairs, num = rb.pairs()
+    assert K.pair_segments(pairs, num) is None
 
 
 @pytest.mark.parametrize("cin,cout,chunk_rows", [(64, 64, 256), (128, 96, 100), (192, 192, 512),

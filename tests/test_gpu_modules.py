@@ -360,6 +360,19 @@ def test_packed_parameter_images_follow_the_optimizer(dev):
     convs[0].weight.data.mul_(1.5)
     Fsp.invalidate_packed_weights()
     assert torch.equal(forward(), reference())
+    # ... for one parameter, and a module's train() / eval() does it for its own weight
+    # (EMA / fp16 hooks swap parameters through .data at those boundaries)
+    y2 = forward()
+    convs[1].weight.data.mul_(0.5)
+    assert torch.equal(forward(), y2)                # stale image: the documented exposure
+    Fsp.invalidate_packed_weights(convs[1].weight)
+    y3 = forward()
+    assert not torch.equal(y3, y2) and torch.equal(y3, reference())
+    forward()
+    convs[0].weight.data.mul_(2.0)
+    convs[0].eval()
+    convs[0].train()
+    assert torch.equal(forward(), reference())
 
 
 def test_plan_batch_equals_table_by_table_planning(dev, monkeypatch):

@@ -111,3 +111,52 @@ def test_exception_poisons_unfilled_subm_tables(calls, monkeypatch):
         with core.plan_batch("all") as b:
             b.subm(rb2, 1)
     assert rb2.nbr_fwd is None
+
+
+def test_pending_flag_guards_a_deferred_table(calls, monkeypatch):
+    """A SubM rulebook built inside plan_batch() has an allocated but unfilled table until the
+    context closes: check_ready() refuses it meanwhile and accepts it afterwards; a rulebook
+    whose fill failed is refused for good and rebuilt by cached_rulebook."""
+    monkeypatch.setattr(core, "PLAN_SCOPE", "all")
+    idx = torch.zeros((10, 4), dtype=torch.int32)
+    rb = core.IndiceData(idx, idx, torch.zeros((27, 10), dtype=torch.int32), None, True,
+                         [4, 4, 4], [4, 4, 4], [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1])
+    with core.plan_batch("all") as b:
+        rb.pending = True
+        b.subm(rb, 1)
+        with pytest.raises(RuntimeError, match="plan_batch"):
+            rb.check_ready()
+    assert rb.pending is False
+    rb.check_ready()
+    # a failed context: poisoned, and the shared cache does not hand it out again
+    rb2 = core.IndiceData(idx, idx, torch.zeros((27, 10), dtype=torch.int32), None, True,
+                          [4, 4, 4], [4, 4, 4], [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1])
+    with pytest.raises(RuntimeError, match="boom"):
+        with core.plan_batch("all") as b:
+            rb2.pending = True
+            b.subm(rb2, 1)
+            raise RuntimeError("boom")
+    with pytest.raises(RuntimeError, match="never filled"):
+        rb2.check_ready()
+    t = core.SparseConvTensor(torch.zeros((10, 4)), idx, [4, 4, 4], 1)
+    ident = (idx.data_ptr(), 10, (4, 4, 4), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True)
+    t._rb_cache[ident] = rb2
+    fresh = object()
+    monkeypatch.setattr(core, "build_rulebook", lambda *a, **k: fresh)
+    assert t.cached_rulebook([3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], True) is fresh
+
+
+def test_subm_index_choice_counts_the_brick_padding():
+    """The bitmap SubM index works on the grid padded to 4 x 8 x 8 bricks: the choice between
+    it and the hash index uses the padded size, and grids of 2^24 bricks and more (which the
+    entry point refuses) always take the hash index."""
+    from msmdfusion_amd import kernels as K
+    n = 200000
+    assert K.subm_index_method(n, 2, [41, 1440, 1440], "auto") == "bitmap"
+    # a thin grid pads 4x along z: 1 x 8192 x 8192 = 2^26 cells = 2^20 bricks of 256 cells
+    thin = K.subm_index_method(n, 1, [1, 8192, 8192], "auto")
+    words_padded = 1 * 1 * 1024 * 1024 * 8
+    assert thin == ("bitmap" if words_padded <= K._SUBM_BITMAP_WORDS_PER_VOXEL * n else "hash")
+    # 2^24 bricks: never the bitmap, however many voxels
+    assert K.subm_index_method(10 ** 9, 16, [4, 8192, 8192], "auto") == "hash"
+    assert K.subm_index_method(n, 2, [41, 1440, 1440], "hash") == "hash"
