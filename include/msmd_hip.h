@@ -724,6 +724,26 @@ int msmd_modality_split_stats(const int32_t* idx_3d, int n3,
                               void* workspace, size_t workspace_bytes,
                               msmd_stream_t stream);
 
+/* a14 with the REFERENCE's float32 keys (`reference_quirks=True` of the detector): key =
+ * fl(fl(fl(z) * 1e6 + fl(y) * 1e3) + fl(x)) (MSMDFusion.py:271-272: int tensor * python float
+ * promotes to float32), both sets sorted per sample, the r-th occurrence of a key in one list
+ * matched with the r-th in the other (type_assign's two-pointer walk, :27-45; ties in row
+ * order).  Keys alias for z >= 17 (2^24 < 17e6) and for x >= 1000: voxels that merely share a
+ * rounded key are marked mixed -- what a checkpoint trained with the reference has seen.
+ * pair_3d / pair_2d: matched rows in key order per sample, samples concatenated (:262-318).
+ * reference_offsets != 0: pair rows numbered as the reference does (:288-289,313-314:
+ * position in the sample + the PREVIOUS sample's count only; identical to global rows for
+ * batch <= 2; needs each set's rows grouped by sample, ascending).  sample_stats (or NULL) as
+ * msmd_modality_split_stats.  Grids whose largest key reaches 2^26, or batch_size > 64:
+ * MSMD_ERR_RANGE. */
+size_t msmd_modality_split_float_keys_workspace_bytes(int n3, int n2, int batch_size);
+int msmd_modality_split_float_keys(const int32_t* idx_3d, int n3, const int32_t* idx_2d, int n2,
+                                   int batch_size, const int* spatial_shape, int32_t* mix3d,
+                                   int32_t* mix2d, int32_t* pair_3d, int32_t* pair_2d,
+                                   int32_t* n_mixed, int32_t* sample_stats /* or NULL */,
+                                   int reference_offsets, void* workspace,
+                                   size_t workspace_bytes, msmd_stream_t stream);
+
 /* rows[r] = the r-th i, ascending, with flags[i * stride] == value (at most `capacity` are
  * written; total, if not NULL, receives the count): the row lists `mask.nonzero()` gives the
  * reference (sparse_multimodal_encoder_painting.py:332-340: only_3D / only_2D masks) without

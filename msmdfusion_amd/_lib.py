@@ -131,6 +131,9 @@ SIGNATURES = {
     "msmd_modality_split": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "msmd_modality_split_stats": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                        _vp]),
+    "msmd_modality_split_float_keys_workspace_bytes": (_sz, [_i, _i, _i]),
+    "msmd_modality_split_float_keys": (_i, [_vp, _i, _vp, _i, _i, _ip, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                            _vp, _sz, _vp]),
     "msmd_rows_where_workspace_bytes": (_sz, [_i]),
     "msmd_rows_where_eq": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "msmd_furthest_point_sample": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -187,8 +187,13 @@ class MSMDFusionDetector(TransFusionDetector):
 
     def __init__(self, spatial_shapes=None, downscale_factors=None, fps_num_list=None,
                  radius_list=None, max_cluster_samples_list=None, dist_thresh_list=None,
-                 multimodal_middle_encoder=None, **kwargs):
+                 multimodal_middle_encoder=None, reference_quirks=False, **kwargs):
+        """reference_quirks (config key of the same name, default False): True reproduces
+        the reference's float32-key voxel_modality_split and its batch-offset arithmetic bit
+        for bit -- the mode that matches a checkpoint trained with the reference
+        (fusion.SparseFusionPath, INTEGRATION.md)."""
         super().__init__(**kwargs)
+        self.reference_quirks = bool(reference_quirks)
         from .bev import SPPModule
         from .image_glue import DepthAwareChannelCompression, ScoreNet
         self.spatial_shapes = [list(s) for s in spatial_shapes]
@@ -215,7 +220,8 @@ class MSMDFusionDetector(TransFusionDetector):
             self.pts_voxel_layer, self.pts_middle_encoder, self.multimodal_middle_encoder,
             self.spatial_shapes, self.downscale_factors, self.fps_num_list, self.radius_list,
             self.max_cluster_samples_list, self.dist_thresh_list,
-            base_voxel_size=self.pts_voxel_layer.voxel_size))
+            base_voxel_size=self.pts_voxel_layer.voxel_size,
+            reference_quirks=self.reference_quirks))
 
     # ---- image side --------------------------------------------------------------------
     def virtual_points_from_images(self, img_feats, img_metas):
@@ -225,7 +231,8 @@ class MSMDFusionDetector(TransFusionDetector):
         pack = pack_foreground(img_metas, img_feats[0].device)
         comp = self._compress(img_feats, img_metas, pack=pack)
         per_scale = [comp[0]] + list(comp)               # img_feat_list[0] twice, :404-405
-        return [get_foreground2D(f, img_metas, self.score_net, pack=pack) for f in per_scale[:4]]
+        return [get_foreground2D(f, img_metas, self.score_net, pack=pack,
+                                 reference_quirks=self.reference_quirks) for f in per_scale[:4]]
 
     # ---- the path ----------------------------------------------------------------------
     def prepare(self, points, virtual_points, nn_side_stream=True):

@@ -54,73 +54,36 @@ def virtual_points_to_voxels(voxel_layer, fg_points, spatial_shape, downscale_fa
     return spconv.SparseConvTensor(mean, coors, spatial_shape, batch_size)
 
 
-def modality_split_indices(idx3, idx2, batch_size, spatial_shape):
+def modality_split_indices(idx3, idx2, batch_size, spatial_shape, float_keys=False,
+                           reference_offsets=False):
     """Index-level voxel_modality_split: 4-column (b,z,y,x) indices of the two
     voxel sets -> (5-column indices of each with the mix flag inserted, matched
     row lists).  Needs no features."""
-    mix3, mix2, pair3, pair2 = K.modality_split(idx3, idx2, batch_size, spatial_shape)
+    mix3, mix2, pair3, pair2 = K.modality_split(idx3, idx2, batch_size, spatial_shape,
+                                                float_keys=float_keys,
+                                                reference_offsets=reference_offsets)
     idx3_5 = torch.cat([idx3[:, :1], mix3[:, None], idx3[:, 1:]], 1).contiguous()
     idx2_5 = torch.cat([idx2[:, :1], mix2[:, None], idx2[:, 1:]], 1).contiguous()
     return idx3_5, idx2_5, pair3.long(), pair2.long()
 
 
-def _split_float_keys(idx3, idx2, batch_size):
-    """voxel_modality_split with the REFERENCE's float32 keys (MSMDFusion.py:271-272:
-    `z*1e6 + y*1e3 + x` on an int tensor promotes to float32, each step rounded) and its
-    two-pointer merge (type_assign, :27-45), sample by sample, bit for bit: keys alias once
-    z >= 17 (2^24 < 17e6) or x >= 1000, and voxels that merely share a rounded key are
-    marked "mixed" -- what a checkpoint trained with the reference has seen.  Compatibility
-    mode: torch ops and one host read, not the hot path.  Equal keys inside a set keep row
-    order (stable sort; torch.sort's tie order in the reference is unspecified)."""
-    dev = idx3.device
-    mix3 = torch.zeros((idx3.shape[0],), dtype=torch.int32, device=dev)
-    mix2 = torch.zeros((idx2.shape[0],), dtype=torch.int32, device=dev)
-    ids = torch.arange(batch_size, device=dev, dtype=idx3.dtype)
-    counts = torch.stack([(idx3[:, :1] == ids).sum(0), (idx2[:, :1] == ids).sum(0)]).tolist()
-    p3, p2, o3, o2 = [], [], 0, 0
-
-    def keys(zyx):
-        k = zyx[:, 0].float() * 1e6
-        k = k + zyx[:, 1].float() * 1e3
-        return k + zyx[:, 2].float()
-    for b in range(batch_size):
-        n3, n2 = counts[0][b], counts[1][b]
-        a, ia = torch.sort(keys(idx3[o3:o3 + n3, 1:]), stable=True)
-        c, ic = torch.sort(keys(idx2[o2:o2 + n2, 1:]), stable=True)
-        # the merge pairs the r-th occurrence of a key in one list with the r-th in the other
-        lo_c = torch.searchsorted(c, a, right=False)
-        cnt_c = torch.searchsorted(c, a, right=True) - lo_c
-        occ_a = torch.arange(n3, device=dev) - torch.searchsorted(a, a, right=False)
-        hit = occ_a < cnt_c
-        rows3 = ia[hit]
-        rows2 = ic[(lo_c + occ_a)[hit]]
-        mix3[o3 + rows3] = 1
-        mix2[o2 + rows2] = 1
-        p3.append(rows3 + o3)      # cumulative offsets (the reference adds the LAST sample's
-        p2.append(rows2 + o2)      # count only: SURVEY Appendix B.4)
-        o3 += n3
-        o2 += n2
-    return mix3, mix2, torch.cat(p3), torch.cat(p2)
-
-
-def voxel_modality_split(voxel_3D, voxel_2D, batch_size, float_keys=False):
+def voxel_modality_split(voxel_3D, voxel_2D, batch_size, float_keys=False,
+                         reference_offsets=None):
     """MSMDFusion.py:251-325: mark voxels present in both modalities.
     indices become 5 columns (batch, mix_flag, z, y, x); syn_mix_3D / syn_mix_2D
-    list the matched rows of each tensor, aligned, in ascending (b,z,y,x) order.
-    Default: exact integer keys on the GPU (the reference's float32 keys + numba merge
-    alias for z >= 17 or x >= 1000: SURVEY Appendix B.3, deliberate fix).
-    float_keys=True reproduces the reference's aliasing matches bit for bit (for running
-    a checkpoint trained with the reference at matched behaviour)."""
+    list the matched rows of each tensor, aligned, in ascending key order per sample.
+    Default: exact integer keys (the reference's float32 keys alias for z >= 17 or
+    x >= 1000 and mark voxels that merely share a rounded key: SURVEY Appendix B.3).
+    float_keys=True: the reference's keys and two-pointer merge, bit for bit
+    (csrc/modality_float.hip) -- what a checkpoint trained with the reference has seen;
+    reference_offsets (default: follows float_keys): pair rows numbered with the reference's
+    non-cumulative batch offsets (:288-289,313-314; the same rows for batch <= 2)."""
     idx3, idx2 = voxel_3D.indices, voxel_2D.indices
     assert idx3.shape[1] == 4 and idx2.shape[1] == 4
-    if float_keys:
-        mix3, mix2, pair3, pair2 = _split_float_keys(idx3, idx2, batch_size)
-        voxel_3D.indices = torch.cat([idx3[:, :1], mix3[:, None], idx3[:, 1:]], 1).contiguous()
-        voxel_2D.indices = torch.cat([idx2[:, :1], mix2[:, None], idx2[:, 1:]], 1).contiguous()
-        return voxel_3D, voxel_2D, pair3.long(), pair2.long()
     shape = [max(a, b) for a, b in zip(voxel_3D.spatial_shape, voxel_2D.spatial_shape)]
     voxel_3D.indices, voxel_2D.indices, pair3, pair2 = modality_split_indices(
-        idx3, idx2, batch_size, shape)
+        idx3, idx2, batch_size, shape, float_keys=float_keys,
+        reference_offsets=float_keys if reference_offsets is None else reference_offsets)
     return voxel_3D, voxel_2D, pair3, pair2
 
 
@@ -147,8 +110,17 @@ class SparseFusionPath(nn.Module):
                  spatial_shapes=([41, 1440, 1440], [21, 720, 720], [11, 360, 360], [5, 180, 180]),
                  downscale_factors=(1, 2, 4, 8), fps_num_list=(2048,) * 4,
                  radius_list=(6, 3, 2, 1), max_cluster_samples_list=(200, 100, 50, 25),
-                 dist_thresh_list=(13.3, 6.6, 3.3, 1.6), base_voxel_size=(0.075, 0.075, 0.2)):
+                 dist_thresh_list=(13.3, 6.6, 3.3, 1.6), base_voxel_size=(0.075, 0.075, 0.2),
+                 reference_quirks=False):
+        """reference_quirks=True: the behaviours of the reference a published checkpoint was
+        trained with, bit for bit, instead of their fixes -- float32 voxel keys in
+        voxel_modality_split (MSMDFusion.py:271-272: false "mixed" voxels wherever keys
+        alias, on every real frame at the 0.075 m scale) and non-cumulative batch offsets
+        (:288-289,313-314 and sparse_multimodal_encoder_painting.py:355-369; same rows for
+        batch <= 2).  INTEGRATION.md, "Which mode reproduces a published checkpoint"."""
         super().__init__()
+        self.reference_quirks = bool(reference_quirks)
+        multimodal_encoder.reference_quirks = self.reference_quirks
         self.pts_voxel_layer = voxel_layer
         self.pts_middle_encoder = middle_encoder
         self.multimodal_middle_encoder = multimodal_encoder
@@ -212,7 +184,9 @@ class SparseFusionPath(nn.Module):
                 shape = [max(a, b) for a, b in zip(stages[i][1], v2[i].spatial_shape)]
                 jobs.append((stages[i][0], v2[i].indices, shape))
             idx3_5, s3, s2, plans = [], [], [], []
-            for i, (mix3, mix2, pa, pb, stats) in enumerate(K.modality_split_many(jobs, B)):
+            q = self.reference_quirks
+            for i, (mix3, mix2, pa, pb, stats) in enumerate(
+                    K.modality_split_many(jobs, B, float_keys=q, reference_offsets=q)):
                 idx3, idx2 = jobs[i][0], jobs[i][1]
                 i3 = torch.cat([idx3[:, :1], mix3[:, None], idx3[:, 1:]], 1).contiguous()
                 v2[i].indices = torch.cat([idx2[:, :1], mix2[:, None], idx2[:, 1:]], 1).contiguous()

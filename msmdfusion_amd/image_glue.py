@@ -143,14 +143,16 @@ class _ForegroundGather(torch.autograd.Function):
         return K.fg_scatter_add(g, 0, c, cells, ctx.like), None, None, None
 
 
-def get_foreground2D(img_feats, img_metas, score_net, pack=None, check=True):
+def get_foreground2D(img_feats, img_metas, score_net, pack=None, check=True,
+                     reference_quirks=False):
     """MSMDFusion.py:169-238.  img_feats: [B*cams, C, h, w] (any memory format).
     Returns batch_fg_pcd_cams: B tensors [n_b, pts_dim + C], rows in (camera,
     point) order, the C image channels scaled by score_net.
 
-    Deviation kept on purpose: the reference copies the scaled channels back for
-    samples 0 and 1 only ("only suit for bs = 2", :229-234); here every sample is
-    scaled.  Identical for B <= 2, the only sizes the reference trains with."""
+    Default: every sample's channels are scaled.  The reference copies the scaled channels
+    back for samples 0 and 1 only ("only suit for bs = 2", :229-234): identical for B <= 2,
+    the only sizes it trains with; reference_quirks=True reproduces it for larger batches too
+    (samples 2.. keep their unscaled channels)."""
     if pack is None:
         pack = pack_foreground(img_metas, img_feats.device)
     downscale = img_feats.shape[-1] / img_metas[0]["input_shape"][-1]
@@ -160,8 +162,11 @@ def get_foreground2D(img_feats, img_metas, score_net, pack=None, check=True):
                          % (img_feats.shape[0], pack.batch_size, pack.cameras))
     fg, score_in = _ForegroundGather.apply(img_feats.float(), pack, downscale, check)
     scores = score_net(score_in)                             # [n,1], Linear(66,1)+ReLU
-    fg = torch.cat([fg[:, :-C], fg[:, -C:] * scores], 1)
-    return list(torch.split(fg, pack.sample_counts, 0))
+    scaled = torch.cat([fg[:, :-C], fg[:, -C:] * scores], 1)
+    out = list(torch.split(scaled, pack.sample_counts, 0))
+    if reference_quirks and len(out) > 2:
+        out[2:] = list(torch.split(fg, pack.sample_counts, 0))[2:]
+    return out
 
 
 def sparse_depth_canvas(img_metas, H, W, device, pack=None, check=True):

@@ -1383,59 +1383,71 @@ def gma_assemble(conv3, cross_gate, gate, feat3, feat2, nn3, rows_o2, rows_m3, r
                               rows_m2.contiguous(), int(n_o2_pad), int(n_mix_pad), order, starts)
 
 
-def modality_split(idx_3d, idx_2d, batch_size, spatial_shape):
-    """-> (mix3d[n3], mix2d[n2], pair_3d[m], pair_2d[m])"""
+def _modality_split_launch(idx_3d, idx_2d, batch_size, spatial_shape, float_keys,
+                           reference_offsets, want_stats):
+    """Enqueue one split -> (mix3d, mix2d, pair_3d, pair_2d, out) with out = int32
+    [count | 4 * batch stats] on the device (capacity-sized pair lists: the caller trims)."""
     _need_bzyx(idx_3d, idx_2d)
     _need_cuda(idx_3d, idx_2d)
     a, b = idx_3d.contiguous().int(), idx_2d.contiguous().int()
     n3, n2 = a.shape[0], b.shape[0]
     dev = a.device
+    B = int(batch_size)
     cap = max(min(n3, n2), 1)
     mix3 = torch.empty((n3,), dtype=torch.int32, device=dev)
     mix2 = torch.empty((n2,), dtype=torch.int32, device=dev)
     p3 = torch.empty((cap,), dtype=torch.int32, device=dev)
     p2 = torch.empty((cap,), dtype=torch.int32, device=dev)
-    count = torch.empty((1,), dtype=torch.int32, device=dev)
-    nbytes = lib.msmd_modality_split_workspace_bytes(int(batch_size), int3(spatial_shape))
-    ws = _ws(nbytes, dev)
-    check(lib.msmd_modality_split(_p(a), n3, _p(b), n2, int(batch_size), int3(spatial_shape),
-                                  _p(mix3), _p(mix2), _p(p3), _p(p2), _p(count), _p(ws), nbytes,
-                                  _stream()), "msmd_modality_split")
-    m = int(count.item())
+    out = torch.empty((1 + 4 * B,), dtype=torch.int32, device=dev)   # count | stats
+    stats_p = C.c_void_p(out.data_ptr() + 4) if want_stats else None
+    if float_keys:
+        nbytes = lib.msmd_modality_split_float_keys_workspace_bytes(n3, n2, B)
+        ws = _ws(nbytes, dev)
+        check(lib.msmd_modality_split_float_keys(_p(a), n3, _p(b), n2, B, int3(spatial_shape),
+                                                 _p(mix3), _p(mix2), _p(p3), _p(p2), _p(out),
+                                                 stats_p, int(bool(reference_offsets)), _p(ws),
+                                                 nbytes, _stream()),
+              "msmd_modality_split_float_keys")
+    else:
+        nbytes = lib.msmd_modality_split_workspace_bytes(B, int3(spatial_shape))
+        ws = _ws(nbytes, dev)
+        if want_stats:
+            check(lib.msmd_modality_split_stats(_p(a), n3, _p(b), n2, B, int3(spatial_shape),
+                                                _p(mix3), _p(mix2), _p(p3), _p(p2), _p(out),
+                                                stats_p, _p(ws), nbytes, _stream()),
+                  "msmd_modality_split_stats")
+        else:
+            check(lib.msmd_modality_split(_p(a), n3, _p(b), n2, B, int3(spatial_shape), _p(mix3),
+                                          _p(mix2), _p(p3), _p(p2), _p(out), _p(ws), nbytes,
+                                          _stream()), "msmd_modality_split")
+    return mix3, mix2, p3, p2, out, (a, b, ws)
+
+
+def modality_split(idx_3d, idx_2d, batch_size, spatial_shape, float_keys=False,
+                   reference_offsets=False):
+    """-> (mix3d[n3], mix2d[n2], pair_3d[m], pair_2d[m]).
+    float_keys: the reference's float32 keys and two-pointer merge (csrc/modality_float.hip;
+    MSMDFusion.py:271-272, 27-45) instead of exact integer keys; reference_offsets: pair rows
+    numbered with the reference's non-cumulative batch offsets (:288-289,313-314)."""
+    mix3, mix2, p3, p2, out, _keep = _modality_split_launch(
+        idx_3d, idx_2d, batch_size, spatial_shape, float_keys, reference_offsets, False)
+    m = int(out[0].item())
     return mix3, mix2, p3[:m], p2[:m]
 
 
-def modality_split_many(jobs, batch_size):
+def modality_split_many(jobs, batch_size, float_keys=False, reference_offsets=False):
     """Several independent modality splits (the four image scales of a step) with ONE
     host read.  jobs: [(idx_3d, idx_2d, spatial_shape), ...] -> per job
     (mix3d, mix2d, pair_3d, pair_2d, stats) with stats = dict of per-sample row
     counts as python lists: c3_plain, c3_mixed, c2_plain, c2_mixed."""
-    pending = []
     B = int(batch_size)
-    for idx_3d, idx_2d, spatial_shape in jobs:
-        _need_bzyx(idx_3d, idx_2d)
-        _need_cuda(idx_3d, idx_2d)
-        a, b = idx_3d.contiguous().int(), idx_2d.contiguous().int()
-        n3, n2 = a.shape[0], b.shape[0]
-        dev = a.device
-        cap = max(min(n3, n2), 1)
-        mix3 = torch.empty((n3,), dtype=torch.int32, device=dev)
-        mix2 = torch.empty((n2,), dtype=torch.int32, device=dev)
-        p3 = torch.empty((cap,), dtype=torch.int32, device=dev)
-        p2 = torch.empty((cap,), dtype=torch.int32, device=dev)
-        out = torch.empty((1 + 4 * B,), dtype=torch.int32, device=dev)   # count | stats
-        nbytes = lib.msmd_modality_split_workspace_bytes(B, int3(spatial_shape))
-        ws = _ws(nbytes, dev)
-        check(lib.msmd_modality_split_stats(_p(a), n3, _p(b), n2, B, int3(spatial_shape),
-                                            _p(mix3), _p(mix2), _p(p3), _p(p2), _p(out),
-                                            C.c_void_p(out.data_ptr() + 4), _p(ws), nbytes,
-                                            _stream()), "msmd_modality_split_stats")
-        pending.append((mix3, mix2, p3, p2, out, a, b, ws))
+    pending = [_modality_split_launch(i3, i2, B, shape, float_keys, reference_offsets, True)
+               for i3, i2, shape in jobs]
     if not pending:
         return []
     host = torch.stack([p[4] for p in pending]).tolist()
     res = []
-    for (mix3, mix2, p3, p2, _, _, _, _), h in zip(pending, host):
+    for (mix3, mix2, p3, p2, _, _), h in zip(pending, host):
         m = h[0]
         stats = dict(c3_plain=h[1:1 + B], c3_mixed=h[1 + B:1 + 2 * B],
                      c2_plain=h[1 + 2 * B:1 + 3 * B], c2_mixed=h[1 + 3 * B:1 + 4 * B])

@@ -11,7 +11,7 @@ no [1,2048,N,3] broadcast temporaries and no host round trip.
 
 Documented deviations from the reference:
   * B.4 batch offsets are cumulative (the reference's are right only for
-    batch <= 2; identical results there);
+    batch <= 2; identical results there) unless `reference_quirks` is set;
   * B.5 the per-call random `dummy_embedding` (:372) comes from
     `self.dummy_embedding_fn` so tests can pin it;
   * B.6 a query covered by several balls takes the highest representative
@@ -88,6 +88,10 @@ class SparseMultiModalEncoderPaint(nn.Module):
         self.fp16_enabled = False
         # one-launch stage assembly (kernels.gma_assemble); MSMD_FUSED_ASSEMBLY=0: the op chain
         self.fused_assembly = os.environ.get("MSMD_FUSED_ASSEMBLY", "1") != "0"
+        # True (set by SparseFusionPath / the detector's `reference_quirks`): batch offsets of
+        # the nearest-voxel rows as the reference computes them (:355-369: the PREVIOUS
+        # sample's count only) instead of cumulative ones; the same rows for batch <= 2
+        self.reference_quirks = False
         self.dummy_embedding_fn = pinned_dummy_embedding
         self.make_grouped_sparse_conv_blocks(norm_cfg)
         self.make_aggregation_block(norm_cfg)
@@ -201,8 +205,10 @@ class SparseMultiModalEncoderPaint(nn.Module):
                 group = K.ball_query(0, radius, max_cluster_samples, q_f,
                                      rep.float().unsqueeze(0))[0]
                 nn_idx = K.nn_assign(group, rep_nn, c2[b]).long()
-            out[o2[b]:o2[b + 1]] = torch.where(nn_idx >= 0, nn_idx + o3[b], nn_idx)
-        return out   # offsets are cumulative (reference: last sample's count only, B.4)
+            # cumulative offsets; the reference adds the previous sample's count only (B.4)
+            base = (c3[b - 1] if b > 0 else 0) if self.reference_quirks else o3[b]
+            out[o2[b]:o2[b + 1]] = torch.where(nn_idx >= 0, nn_idx + base, nn_idx)
+        return out
 
     # ---- index-only half of a GMA-Conv stage ------------------------------------
     def plan_stage_rows(self, idx3_5, idx2_5, batch_size, stats=None, bzyx3=None, bzyx2=None,

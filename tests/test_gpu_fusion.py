@@ -123,12 +123,14 @@ def test_modality_split_float_keys_reproduce_the_reference_aliasing(dev):
     assert (i3[exact[2]] == i2[exact[3]]).all()
 
 
-def _oracle_stage(enc, stage, i3, f3, i2, f2, shape, batch, dummy, fps_num, radius, mcs, thresh):
-    """grouped_sparse_conv (:325-430) with numpy + oracle ops."""
+def _oracle_stage(enc, stage, i3, f3, i2, f2, shape, batch, dummy, fps_num, radius, mcs, thresh,
+                  float_keys=False):
+    """grouped_sparse_conv (:325-430) with numpy + oracle ops.  float_keys: the split with
+    the reference's float32 keys (MSMDFusion.py:271-272) instead of exact ones."""
     e3, e2, p3, p2 = [], [], [], []
     for bi in range(batch):
         r3, r2 = np.flatnonzero(i3[:, 0] == bi), np.flatnonzero(i2[:, 0] == bi)
-        m3, m2, q3, q2 = O.modality_split(i3[r3, 1:], i2[r2, 1:], shape)
+        m3, m2, q3, q2 = O.modality_split(i3[r3, 1:], i2[r2, 1:], shape, float_keys=float_keys)
         e3.append(m3); e2.append(m2); p3.append(r3[q3]); p2.append(r2[q2])
     mix3, mix2 = np.concatenate(e3), np.concatenate(e2)
     s3, s2 = np.concatenate(p3), np.concatenate(p2)
