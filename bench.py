@@ -323,7 +323,14 @@ def _cpu_baseline(workload, seed, budget_s, max_samples):
         ref = B.reference_conv_leg(seed)
     except Exception as e:     # the leg is a report, never a reason to lose the line
         ref = dict(error=repr(e)[:200])
+    # ... and the index part (voxelization, rulebooks) likewise
+    try:
+        ref_index = B.reference_index_leg(seed)
+    except Exception as e:
+        ref_index = dict(error=repr(e)[:200])
     return dict(value=round(len(timed) / secs, 4), unit="samples/s", cores=cores, kind="port",
+                reference_index=ref_index if ref_index is not None else
+                "oracle/_ref/libmsmd_ref.so is not on this box",
                 reference_conv=ref if ref is not None else
                 "oracle/_ref/libmsmd_ref.so (the reference's gather / torch::mm / scatter-add "
                 "loop, built from /root/reference by oracle/Makefile) is not on this box",
@@ -471,6 +478,9 @@ def run_workload(workload, args, dev, rank, world, profile):
                       "parallelism": "dp%d" % world, "index_prefetch": prefetch is not None,
                       "trainable_params": sum(p.numel() for p in params)}}
     res["roofline"] = roofline(prof, workload, marks) if prof else None
+    if res["roofline"]:
+        r = res["roofline"]
+        r["step_frac"] = round(r["step_gflop"] / res["ms_per_step"] / r["peak_tflops"], 4)
     if rank == 0:   # tools/stream_prof.py divides a rocprofv3 trace of this run by this count
         print("[bench] workload=%s steps_total=%d (+1 untimed check step)" % (workload, calls[0]),
               file=sys.stderr)
@@ -627,14 +637,14 @@ HBM_PEAK_TBPS = 8.0     # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measur
 
 def roofline(prof, workload, marks=None):
     """Dominant kernel = the conv kernel (by TEMPLATE INSTANTIATION, the unit rocprofv3
-    reports) with the most accumulated time.  Two fractions for it:
-      mfma  = algorithmic flops (2 * pairs * Cin * Cout, the reference's MAC count,
+    reports) with the most accumulated time.  SURVEY 8(d): two fractions of ALGORITHMIC work,
+      mfma  = flops (2 * pairs * Cin * Cout, the reference's MAC count,
               mmdet3d/apis/flops_counter.py:9-12) / launch time / the matrix peak of its
               arithmetic;
-      bytes = HBM bytes per launch (committed PMC passes) / launch time / 8 TB/s;
-    `bound` names the larger one, `frac` is its value.  `algorithmic_bytes` (features in +
-    out once, the packed weights, the table: DESIGN.md section 3) beside `traffic` gives the
-    re-fetch ratio."""
+      bytes = algorithmic bytes (features in + out once, the packed weights, the table:
+              DESIGN.md section 3) / launch time / 8 TB/s;
+    `bound` names the larger one, `frac` is its value.  `traffic` = HBM bytes per launch from
+    the PMC counters, beside it: traffic_over_algorithmic is the re-fetch ratio."""
     from msmdfusion_amd.spconv.functional import conv_planes
     pair_cache = {}
     groups = {}
@@ -703,30 +713,47 @@ def roofline(prof, workload, marks=None):
                      "(operands split into %d bf16 planes, fp32 accumulate)"
                      % (PEAK_BF16_MFMA_TFLOPS, products, conv_planes()))
     frac_mfma = achieved / peak
-    tbps = None if traffic is None else traffic / (avg_us * 1e-6) / 1e12
-    frac_bytes = None if tbps is None else tbps / HBM_PEAK_TBPS
-    hbm_bound = frac_bytes is not None and frac_bytes > frac_mfma
     algo_per_launch = g["algo"] / g["launches"]
+    # the fraction is ALGORITHMIC work / launch time / peak on either roof --
+    # flops against the matrix peak of the arithmetic, algorithmic bytes (each feature row in
+    # and out once, the packed weights, the table) against 8 TB/s -- and `bound` names the
+    # larger.  Counter bytes (`traffic`) are reported beside it, never priced as achievement:
+    # re-fetched lines are waste, not work.
+    algo_tbps = algo_per_launch / (avg_us * 1e-6) / 1e12
+    frac_algo_bytes = algo_tbps / HBM_PEAK_TBPS
+    hbm_bound = frac_algo_bytes > frac_mfma
+    tbps = None if traffic is None else traffic / (avg_us * 1e-6) / 1e12
+    # every conv kernel of the median sampled step together, against the same matrix peak
+    # (the 5- / 16-channel layers run fp32 MFMAs: their flops are priced against it too)
+    med = sorted(range(len(bounds) - 1),
+                 key=lambda i: sum(p[i]["ms"] for p in per_step.values()))[(len(bounds) - 1) // 2]
+    step_flops = sum(p[med]["flops"] for p in per_step.values())
+    step_conv_ms = sum(p[med]["ms"] for p in per_step.values())
     out = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
-           "achieved": round(tbps * 1e3, 1) if hbm_bound else round(achieved, 3),
+           "achieved": round(algo_tbps * 1e3, 1) if hbm_bound else round(achieved, 3),
            "peak": HBM_PEAK_TBPS * 1e3 if hbm_bound else peak,
            "unit": "GB/s" if hbm_bound else "TFLOP/s",
-           "frac": round(frac_bytes if hbm_bound else frac_mfma, 4),
+           "frac": round(frac_algo_bytes if hbm_bound else frac_mfma, 4),
            "frac_mfma": round(frac_mfma, 4), "achieved_tflops": round(achieved, 3),
            "peak_tflops": peak, "peak_note": peak_note,
-           "frac_bytes": None if frac_bytes is None else round(frac_bytes, 4),
-           "achieved_hbm_gbps": None if tbps is None else round(tbps * 1e3, 1),
+           "frac_algorithmic_bytes": round(frac_algo_bytes, 4),
+           "algorithmic_gbps": round(algo_tbps * 1e3, 1),
            "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
            "traffic": traffic,
+           "traffic_gbps": None if tbps is None else round(tbps * 1e3, 1),
            "algorithmic_bytes": int(algo_per_launch),
            "traffic_over_algorithmic": None if traffic is None else
            round(traffic / algo_per_launch, 2),
-           "traffic_note": "HBM bytes per launch of `%s` from the committed rocprofv3 --pmc "
-                           "passes (%s: (2*FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction; an "
-                           "upper bound where reads are narrow row gathers), not re-measured in "
-                           "this run; algorithmic_bytes = features in + out once, packed "
+           "traffic_note": "HBM bytes per launch of `%s` from the rocprofv3 --pmc passes of this "
+                           "command under its default (pipelined) schedule (%s: (2*FETCH_SIZE + "
+                           "WRITE_SIZE) KiB, gfx950 correction; Infinity-Cache hits are counted, "
+                           "an upper bound); algorithmic_bytes = features in + out once, packed "
                            "weights, neighbour table, mean over the same launches"
                            % (pmc_key, pmc_file),
+           "step_gflop": round(step_flops / 1e9, 1),
+           "step_conv_ms": round(step_conv_ms, 3),
+           "step_frac_note": "step_frac (set by the caller) = step_gflop / ms_per_step / peak_tflops: "
+                             "all conv flops of a step over the WHOLE step time",
            "l2_hit_rate_pmc": pmc.get("l2_hit_rate"),
            "mfma_pipe_busy_frac_pmc": pmc.get("mfma_pipe_busy_frac"),
            "avg_launch_us": round(avg_us, 2), "launches": g["launches"],

@@ -57,7 +57,7 @@ __device__ __forceinline__ int block_range_sum(const int* __restrict__ a, int lo
   // ... and the next user of smem (block_excl_scan writes it without a barrier in front) must
   // not overtake a wave still reading here.  Without this barrier a block now and then took
   // a wrong carry: garbage positions in pair lists / row ranks, only under load (round 3:
-  // memory faults in one bench leg out of ~6 -- found by bisecting, tools/scratch/r3_bisect.sh)
+  // memory faults in one bench leg out of ~6 -- found by bisecting, a bisection script of round 3, since pruned: git history)
   __syncthreads();
   return t;
 }

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
   }
 }
 
-// Tuning constants chosen from on-device sweeps (tools/scratch/conv_sweep.py; the environment
+// Tuning constants chosen from on-device sweeps (round-1 sweep script, since pruned: git history; the environment
 // overrides of rounds 1-2 -- MSMD_FWD_SLOTS / _R / _PIPE / _KC, MSMD_PIPE_MIN_NT,
 // MSMD_NARROW_ORDER, MSMD_WGRAD_MULTISLAB -- are gone: measured, decided).
 inline int env_int(const char* name, int dflt) {

@@ -234,3 +234,52 @@ def reference_conv_leg(seed=0, budget_s=6.0):
                 rounds=rounds - 1 if rounds > 1 else 1,
                 layers="SubM 3x3x3 fwd+dgrad+wgrad on one synthetic sample's LiDAR voxel sets, "
                        "widths 128, 64, 32, 16; whole rounds after an untimed first one")
+
+
+def reference_index_leg(seed=0, rounds=2):
+    """The INDEX part of the path -- hard voxelization (voxelization_cpu.cpp:68-96) of the
+    LiDAR cloud and of the virtual points at the four scales, and the rulebooks
+    (geometry.h getIndicePairsConv / getIndicePairsSubM via spconv's CPU entry) of the four
+    SubM voxel sets and three stride-2 convs of one synthetic sample -- through the
+    REFERENCE's own compiled CPU code (oracle/_ref: ref_hard_voxelize, ref_get_indice_pairs)
+    beside the port, same inputs, both single-threaded as the reference's loops are.
+    -> dict of seconds per sample for both, or None when the reference build is absent."""
+    if not O.have_ref():
+        return None
+    pts, virt = S.lidar_sweep(seed), S.virtual_points(seed)
+    out = {}
+    for use_ref in (False, True):
+        t_vox = t_rb = 0.0
+        for r in range(rounds + 1):
+            t0 = time.perf_counter()
+            v, c, n = O.hard_voxelize(pts, S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 120000,
+                                      use_ref=use_ref)
+            for i in range(4):
+                vs = [x * (2 ** i) for x in S.VOXEL_SIZE]
+                O.hard_voxelize(virt, vs, S.POINT_CLOUD_RANGE, 10, 120000, use_ref=use_ref)
+            t1 = time.perf_counter()
+            idx = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+            shape = list(S.SPARSE_SHAPE)
+            pairs = 0
+            for s in range(4):
+                if s:
+                    idx, _, nm, shape = O.get_indice_pairs(idx, 1, shape, 3, 2, DOWN_PADS[s - 1], 1,
+                                                           False, use_ref=use_ref)
+                    shape = list(shape)
+                    pairs += int(nm.sum())
+                _, _, nm, _ = O.get_indice_pairs(idx, 1, shape, 3, 1, 1, 1, True, use_ref=use_ref)
+                pairs += int(nm.sum())
+            t2 = time.perf_counter()
+            if r:                       # the first round warms the page cache
+                t_vox += t1 - t0
+                t_rb += t2 - t1
+        key = "reference" if use_ref else "port"
+        out[key + "_voxelize_s"] = round(t_vox / rounds, 4)
+        out[key + "_rulebooks_s"] = round(t_rb / rounds, 4)
+    out["points"] = int(pts.shape[0] + 4 * virt.shape[0])
+    out["rulebook_pairs"] = pairs
+    out["what"] = ("one synthetic sample: hard_voxelize of the LiDAR cloud + the virtual points at "
+                   "4 scales; SubM 3x3x3 rulebooks of the 4 encoder voxel sets + the 3 stride-2 "
+                   "rulebooks between them; reference = oracle/_ref (voxelization_cpu.cpp, "
+                   "geometry.h compiled where they lie), port = oracle/msmd_oracle.c; 1 thread each")
+    return out

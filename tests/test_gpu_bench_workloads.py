@@ -1,0 +1,216 @@
+"""The two workloads bench.py TIMES, pinned end to end at their real size against a CPU
+oracle walk of the same seeds:
+
+  * `bench.Backbone` -- BASELINE configs[1]: 4 synthetic clouds, the real [41,1440,1440]
+    grid: the five encode_features (sparse_encoder.py:96-133) and the BEV map
+    [4,256,180,180] (transfusion.py:61-74);
+  * `bench.FusionBackbone.extract_sparse_feat` -- configs[2], the headline batch (2 x (28.7 k
+    LiDAR + 50 k virtual points)): the five encode_features of the frozen encoder, every
+    GMA-Conv stage output after sparse_add + downscale
+    (sparse_multimodal_encoder_painting.py:433-459) and the final BEV [2,640,180,180]
+    (MSMDFusion.py:421-443) -- the ORACLE's own intermediate results feed its next stage
+    (earlier tests fed each oracle stage the HIP path's outputs) -- plus the weight
+    gradients of the four downscale convs and of one 192 x 192 SubM conv against
+    O.indice_conv_bwd on the full-size tensors of the same backward pass.
+
+Tolerances (stated, fp32 against fp32 in another summation order): a single conv is pinned at
+1e-4 elsewhere (test_gpu_kernels / test_gpu_production); here whole compositions -- up to 21
+conv + BatchNorm layers for the encoder, ~35 for the last fusion stage -- are held to
+2e-4 * (1 + |expected|) element-wise ... measured worst errors are written to
+gpurun_out/r05_workload_parity.txt when that directory exists.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from msmdfusion_amd import synthetic as S
+from oracle import oracle as O
+from test_gpu_fusion_edges import oracle_stage_with_pads
+from test_gpu_modules import OracleSparse, _np, oracle_forward
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 2e-4            # composed layers: |got - exp| <= TOL * (1 + |exp|)
+TOL_DW = 1e-4         # weight gradients: of the tensor's largest entry (a sum over ~10^5 pairs)
+
+
+def _record(lines):
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "r05_workload_parity.txt"), "a") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+def _scaled_err(got, exp):
+    got, exp = np.asarray(got, np.float64), np.asarray(exp, np.float64)
+    assert got.shape == exp.shape, (got.shape, exp.shape)
+    return float((np.abs(got - exp) / (1.0 + np.abs(exp))).max()) if exp.size else 0.0
+
+
+def _oracle_lidar_voxels(clouds):
+    f, idx = [], []
+    for b, pts in enumerate(clouds):
+        v, c, n = O.hard_voxelize(pts, S.VOXEL_SIZE, S.POINT_CLOUD_RANGE, 10, 120000)
+        f.append(O.voxel_mean(v, n))
+        idx.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+    return np.concatenate(f), np.concatenate(idx)
+
+
+def _oracle_encoder(enc, f, idx, batch):
+    """SparseEncoder.forward (sparse_encoder.py:96-133) with oracle ops -> (the five
+    encode_features, conv_out's sparse output)."""
+    x = oracle_forward(enc.conv_input, OracleSparse(f, idx, list(S.SPARSE_SHAPE), batch))
+    stages = [x]
+    for layer in enc.encoder_layers:
+        x = oracle_forward(layer, x)
+        stages.append(x)
+    return stages, oracle_forward(enc.conv_out, stages[-1])
+
+
+def _check_sparse(tag, got, exp, lines, tol=TOL):
+    assert list(got.spatial_shape) == list(exp.shape), (tag, got.spatial_shape, exp.shape)
+    assert np.array_equal(_np(got.indices), exp.idx), tag + ": voxel set / row order"
+    err = _scaled_err(_np(got.features), exp.feat)
+    lines.append("%-34s rows %7d  c %4d  max |exp| %8.3f  scaled err %.3e" % (
+        tag, exp.feat.shape[0], exp.feat.shape[1], float(np.abs(exp.feat).max()), err))
+    assert err <= tol, "%s: scaled error %.3e > %.1e" % (tag, err, tol)
+
+
+def test_bench_backbone_configs1_full_size_matches_oracle(dev):
+    import bench
+    O.set_threads(min(os.cpu_count() or 1, 32))
+    torch.manual_seed(0)
+    model = bench.Backbone().to(dev).train()
+    B = bench.SAMPLES_PER_GPU
+    clouds = [S.lidar_sweep(i) for i in range(B)]
+    d_clouds = [torch.from_numpy(c).to(dev) for c in clouds]
+    enc = model.det.pts_middle_encoder
+    with torch.no_grad():
+        feats, coors = model.det.voxelize(d_clouds)
+        bev, enc_feats = enc(feats, coors, B)
+        assert torch.equal(model(d_clouds), bev)         # what bench.py's step differentiates
+    f, idx = _oracle_lidar_voxels(clouds)
+    assert np.array_equal(_np(coors), idx)
+    assert idx.shape[0] > 100000 and list(enc.sparse_shape) == [41, 1440, 1440]
+    stages, out = _oracle_encoder(enc, f, idx, B)
+    lines = ["configs[1] bench.Backbone, %d clouds, %d voxels" % (B, idx.shape[0])]
+    assert len(enc_feats) == len(stages) == 5
+    for i, (got, exp) in enumerate(zip(enc_feats, stages)):
+        _check_sparse("encode_features[%d]" % i, got, exp, lines)
+    dense = O.dense(out.feat, out.idx, B, out.shape).reshape(B, -1, 180, 180)
+    assert tuple(bev.shape) == (B, 256, 180, 180) == dense.shape
+    err = _scaled_err(_np(bev), dense)
+    lines.append("%-34s scaled err %.3e" % ("BEV [%d,256,180,180]" % B, err))
+    _record(lines)
+    assert err <= TOL, "BEV: scaled error %.3e" % err
+
+
+def _conv_grad_probe(conv, store, key):
+    """Capture a sparse conv's input features / indices and the gradient of its raw output."""
+    def fwd_hook(mod, inputs, output):
+        x = inputs[0]
+        rec = dict(f=x.features.detach(), idx=x.indices, shape=list(x.spatial_shape),
+                   batch=x.batch_size)
+        store[key] = rec
+        if output.features.requires_grad:
+            output.features.register_hook(lambda g, rec=rec: rec.__setitem__("g", g.detach()))
+    return conv.register_forward_hook(fwd_hook)
+
+
+def test_bench_fusion_backbone_configs2_full_size_matches_oracle(dev):
+    import bench
+    import proc_prefetch_helper as H
+    from msmdfusion_amd import spconv
+    O.set_threads(min(os.cpu_count() or 1, 32))
+    model = H.build_model(dev)                # bench.FusionBackbone, seed 0, dummy = 0.25
+    det, path, B = model.det, model.path, 2
+    enc, mm = path.pts_middle_encoder, path.multimodal_middle_encoder
+    clouds = [S.lidar_sweep(i) for i in range(B)]
+    virt = [S.virtual_points(i) for i in range(B)]
+    d_clouds = [torch.from_numpy(c).to(dev) for c in clouds]
+    d_virt = [torch.from_numpy(v).to(dev) for v in virt]
+
+    got = {}
+    hooks = [enc.register_forward_hook(lambda m, i, o: got.__setitem__("enc", o))]
+    for i in range(4):
+        blk = getattr(mm.downscale_blocks, "stage_%d" % (i + 1))
+        hooks.append(blk.register_forward_hook(lambda m, inp, o, i=i: got.__setitem__("stage%d" % i, o)))
+    probes = {}
+    for i in range(4):
+        conv = spconv.sparse_convs(getattr(mm.downscale_blocks, "stage_%d" % (i + 1)))[0]
+        hooks.append(_conv_grad_probe(conv, probes, "down%d" % i))
+    wide = mm.aggregation_blocks.stage_4.conv1          # SubM 192 -> 192
+    assert wide.in_channels == wide.out_channels == 192 and wide.subm
+    hooks.append(_conv_grad_probe(wide, probes, "subm192"))
+
+    target = torch.randn(B, 640, 180, 180, device=dev).contiguous(memory_format=torch.channels_last)
+    bev = model(d_clouds, d_virt)
+    bench.mean_of_product(bev, target).backward()
+    for h in hooks:
+        h.remove()
+    torch.cuda.synchronize()
+
+    # ---- the oracle's own walk, points to BEV
+    f, idx = _oracle_lidar_voxels(clouds)
+    stages, out = _oracle_encoder(enc, f, idx, B)
+    lines = ["configs[2] bench.FusionBackbone, %d LiDAR voxels" % idx.shape[0]]
+    x_sparse, enc_feats = got["enc"]
+    for i, (g, e) in enumerate(zip(enc_feats, stages)):
+        _check_sparse("encode_features[%d]" % i, g, e, lines)
+    prev = None
+    shapes = path.spatial_shapes
+    for i in range(4):
+        f2, i2 = [], []
+        vs = [v * path.downscale_factors[i] for v in S.VOXEL_SIZE]
+        for b in range(B):            # fetch_2D_voxels' voxel half (MSMDFusion.py:374-393)
+            v, c, n = O.hard_voxelize(virt[b], vs, S.POINT_CLOUD_RANGE, 10, 120000)
+            m = O.voxel_mean(v, n)
+            m[:, :3] /= np.array([13.5, 13.5, 2.0], np.float32)
+            f2.append(m)
+            i2.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+        f2, i2 = np.concatenate(f2), np.concatenate(i2)
+        c3 = mm.in_channels_3D[i]
+        x = oracle_stage_with_pads(mm, i, stages[i].idx, stages[i].feat, i2, f2, shapes[i], B,
+                                   np.full((1, c3), 0.25, np.float32), path.fps_num_list[i],
+                                   path.radius_list[i], path.max_cluster_samples_list[i],
+                                   path.dist_thresh_list[i])
+        if prev is not None:          # :455 sparse_add with the previous stage's output
+            assert prev.shape == list(shapes[i])
+            oi, of, _, _ = O.sparse_add(x.feat, x.idx, prev.feat, prev.idx, shapes[i])
+            x = OracleSparse(of, oi, shapes[i], B)
+        prev = oracle_forward(getattr(mm.downscale_blocks, "stage_%d" % (i + 1)), x)
+        _check_sparse("fusion stage %d output" % i, got["stage%d" % i], prev, lines)
+    x_dense = O.dense(out.feat, out.idx, B, out.shape).reshape(B, -1, 180, 180)
+    mm_dense = O.dense(prev.feat, prev.idx, B, prev.shape).reshape(B, -1, 180, 180)
+    exp_bev = np.concatenate([x_dense, mm_dense], 1)           # MSMDFusion.py:436-440
+    assert tuple(bev.shape) == (B, 640, 180, 180) == exp_bev.shape
+    err = _scaled_err(_np(bev.detach()), exp_bev)
+    lines.append("%-34s scaled err %.3e" % ("BEV [2,640,180,180]", err))
+    assert err <= TOL, "BEV: scaled error %.3e" % err
+
+    # ---- weight gradients at full size: the conv's own input rows and output gradient of
+    # this backward pass through O.indice_conv_bwd (spconv_ops.h:363-456)
+    for key, conv in [("down%d" % i, spconv.sparse_convs(getattr(mm.downscale_blocks, "stage_%d" % (i + 1)))[0])
+                      for i in range(4)] + [("subm192", wide)]:
+        rec = probes[key]
+        fi, ii, g = _np(rec["f"]), _np(rec["idx"]), _np(rec["g"])
+        oi, pr, nm, osz = O.get_indice_pairs(ii, rec["batch"], rec["shape"], conv.kernel_size,
+                                             conv.stride, conv.padding, 1, conv.subm)
+        if conv.subm:
+            g_or = g
+        else:       # HIP output rows are in ascending linear id: canonical row r = oracle row perm[r]
+            _, _, perm = O.canonical_rulebook(oi, pr, nm, osz)
+            g_or = np.zeros_like(g)
+            g_or[perm] = g
+        w = _np(conv.weight_kio()).copy()
+        _, edw = O.indice_conv_bwd(fi, w, g_or, pr, nm, subm=conv.subm)
+        kv = edw.shape[0]
+        dw = _np(conv.weight.grad).reshape(conv.out_channels, kv, conv.in_channels).transpose(1, 2, 0)
+        scale = max(float(np.abs(edw).max()), 1e-12)
+        e = float(np.abs(dw - edw).max()) / scale
+        lines.append("dW %-12s %3d->%3d K=%2d pairs %8d  max |dW| %.3e  err/max %.3e" % (
+            key, conv.in_channels, conv.out_channels, kv, int(nm.sum()), scale, e))
+        assert e <= TOL_DW, "dW %s: %.3e of the largest entry" % (key, e)
+    _record(lines)

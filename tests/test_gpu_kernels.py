@@ -524,7 +524,7 @@ def test_scans_do_not_depend_on_what_else_runs(dev):
     took a wrong carry -- only when its waves were descheduled in between, i.e. under load.
     (An invariance check, not a reproducer: the library without the barrier passes this too;
     what exposed it was the training step itself, one bench leg in ~6 --
-    tools/scratch/seq_repro.py repeats legs in one process.)"""
+    a round-3 script (pruned; git history) repeated legs in one process.)"""
     from msmdfusion_amd import kernels as K
     shape = [21, 160, 160]
     idx = t(S.random_voxel_indices(60000, 2, shape, seed=5), dev)

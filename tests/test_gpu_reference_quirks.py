@@ -109,12 +109,27 @@ def test_float_key_split_kernel_edges(dev):
     assert all(torch.equal(u, v) for u, v in zip(f, x))
 
 
+def _spacing2_cloud(rng, n, b, odd_share):
+    """z in 17..32 (keys in [2^24, 2^25): float spacing 2), x < 1000: a voxel at odd x shares
+    its key with the even neighbour the rounding picks (ties to even: the multiple of 4),
+    voxels at even x are exact.  odd_share: fraction of odd-x voxels."""
+    z = rng.randint(17, 33, n)
+    y = rng.randint(100, 105, n)
+    x = 2 * rng.randint(200, 420, n) + (rng.rand(n) < odd_share)
+    u = np.unique(np.stack([np.full(n, b), z, y, x], 1), axis=0)
+    return u[rng.permutation(u.shape[0])].astype(np.int32)
+
+
 def test_gma_stage_with_reference_quirks_matches_the_oracle(dev):
     """GMA-Conv stage 0 on the scale-1 grid with aliasing voxel sets: the module path in
-    reference mode == the oracle walk with float keys.  Mixed 2D voxels whose partner is a
-    DIFFERENT 3D voxel can coincide with an only-3D voxel: the unified set then repeats a
-    coordinate, which the rulebook resolves as the reference's CPU grid does (the last row
-    wins, geometry.h:277-282) -- in the product and in the oracle alike."""
+    reference mode == the oracle walk with float keys, false "mixed" voxels included.
+    LiDAR voxels at even x only, virtual-point voxels at even AND odd x: an odd-x 2D voxel
+    is paired with the even-x 3D voxel its rounded key lands on (a false match), but no
+    mixed voxel can land on an only-3D voxel's coordinate -- the unified set has no repeated
+    coordinate.  (Where it does -- real data -- the reference's result depends on which of
+    two racing hash inserts of spconv-2.x wins, a package that is not in the tree; the
+    product resolves it deterministically: the last row wins every look-up, every row gets
+    its own output.  INTEGRATION.md records this.)"""
     from msmdfusion_amd import spconv
     from msmdfusion_amd.fusion import voxel_modality_split
     from msmdfusion_amd.multimodal_encoder import SparseMultiModalEncoderPaint
@@ -124,8 +139,8 @@ def test_gma_stage_with_reference_quirks_matches_the_oracle(dev):
     enc.reference_quirks = True
     rng = np.random.RandomState(9)
     batch, c3 = 2, 16
-    i3 = np.concatenate([_aliasing_cloud(rng, 2600, b, 100, 110) for b in range(batch)])
-    i2 = np.concatenate([_aliasing_cloud(rng, 2200, b, 100, 110) for b in range(batch)])
+    i3 = np.concatenate([_spacing2_cloud(rng, 2600, b, 0.0) for b in range(batch)])
+    i2 = np.concatenate([_spacing2_cloud(rng, 2200, b, 0.5) for b in range(batch)])
     f3 = rng.randn(i3.shape[0], c3).astype(np.float32)
     f2 = rng.randn(i2.shape[0], 64).astype(np.float32)
     dummy = np.random.RandomState(5).rand(1, c3).astype(np.float32)
@@ -133,18 +148,20 @@ def test_gma_stage_with_reference_quirks_matches_the_oracle(dev):
     a = spconv.SparseConvTensor(torch.from_numpy(f3).to(dev), torch.from_numpy(i3).to(dev), SHAPE0, batch)
     b = spconv.SparseConvTensor(torch.from_numpy(f2).to(dev), torch.from_numpy(i2).to(dev), SHAPE0, batch)
     a, b, s3, s2 = voxel_modality_split(a, b, batch, float_keys=True)
+    false_matches = int((i3[_np(s3)] != i2[_np(s2)]).any(1).sum())
+    true_matches = int((i3[_np(s3)] == i2[_np(s2)]).all(1).sum())
+    assert false_matches > 100 and true_matches > 100, (false_matches, true_matches)
     out = enc.grouped_sparse_conv(a, b, s3, s2, 0, 2048, 6, 50, 13.3)
     exp = _oracle_stage(enc, 0, i3, f3, i2, f2, SHAPE0, batch, dummy, 2048, 6, 50, 13.3,
                         float_keys=True)
     assert np.array_equal(_np(out.indices), exp.idx)
-    uniq = np.unique(exp.idx, axis=0).shape[0]
-    assert uniq < exp.idx.shape[0], "the aliasing should produce a repeated coordinate here"
+    assert np.unique(exp.idx, axis=0).shape[0] == exp.idx.shape[0]     # no repeated coordinate
     np.testing.assert_allclose(_np(out.features), exp.feat, rtol=2e-4, atol=2e-4)
     # ... and it is not what the exact mode computes
     a2 = spconv.SparseConvTensor(torch.from_numpy(f3).to(dev), torch.from_numpy(i3).to(dev), SHAPE0, batch)
     b2 = spconv.SparseConvTensor(torch.from_numpy(f2).to(dev), torch.from_numpy(i2).to(dev), SHAPE0, batch)
     a2, b2, t3, t2 = voxel_modality_split(a2, b2, batch)
-    assert t3.shape[0] != s3.shape[0] or not torch.equal(t3, s3)
+    assert t3.shape[0] == true_matches < s3.shape[0]
 
 
 def test_detector_switch_selects_the_reference_split(dev):
@@ -173,7 +190,10 @@ def test_detector_switch_selects_the_reference_split(dev):
             bev = model.extract_sparse_feat(pts, virt, prepared=prep)
             bev2 = model.extract_sparse_feat(pts, virt)
         torch.cuda.synchronize()
-        assert torch.isfinite(bev).all() and torch.equal(bev, bev2)
+        # (reference mode: a unified set may repeat a coordinate, and three rows summed into
+        # one by sparse_add's atomics have no fixed order -- equal to rounding, not to the bit)
+        assert torch.isfinite(bev).all()
+        assert torch.equal(bev, bev2) if not quirks else torch.allclose(bev, bev2, atol=1e-5)
         outs[quirks] = (prep, bev)
         for i in range(4):
             i3 = _np(prep["stages"][i][0])
