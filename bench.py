@@ -621,7 +621,8 @@ def split_instantiation(c_out, planes):
     """The template instantiation msmd_spconv_fwd_split runs for a layer with c_out output
     channels (csrc/spconv_split.hip: dispatch_fwd_split): passes of <= 8 tiles of 16 channels,
     a pass's tile count rounded up to 2, 4, 6 or 8.  -> (name as rocprofv3 prints it, kernel
-    launches per call).  80, 96 and 192 output channels all run `<6, 1, ..>`."""
+    launches per call).  80, 96 and 192 output channels all run `<6, 1, ..>`; above 64
+    channels the 8-wave ping-pong instantiation."""
     from msmdfusion_amd import kernels as K
     nt_total = (c_out + 15) // 16
     n_pass = (nt_total + 7) // 8
@@ -629,7 +630,9 @@ def split_instantiation(c_out, planes):
     nt = 8 if per > 6 else 6 if per > 4 else 4 if per > 2 else 2
     ub = {8: 1, 6: 1, 4: 2, 2: 4}[nt]
     waves = K.split_tile_rows(c_out) // 32
-    return "spconv_fwd_split_kernel<%d, %d, %d, %d, 2>" % (nt, ub, planes, waves), n_pass
+    if waves == 8:      # the ping-pong form (> 64 output channels): 6 or 8 tiles, 3 weight buffers
+        return "spconv_fwd_split_kernel<%d, 1, %d, 8, 3, true>" % (max(nt, 6), planes), n_pass
+    return "spconv_fwd_split_kernel<%d, %d, %d, %d, 2, false>" % (nt, ub, planes, waves), n_pass
 
 
 HBM_PEAK_TBPS = 8.0     # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy rate)

@@ -308,9 +308,9 @@ int msmd_spconv_fwd_split(const float* in_feat /* [n_in,c_in] */, int n_in, int 
                                                         or NULL: dynamic tile scheduler */,
                           msmd_stream_t stream);
 
-/* The same call that also leaves, per 128-row tile of the output, the column sums and sums of
- * squares of the rows it wrote: bn_partials[ceil(n_out / 128)][2][c_out]
- * (msmd_spconv_fwd_split_stats_blocks(n_out) blocks) -- the statistics
+/* The same call that also leaves, per row tile of the output (128 or 256 rows:
+ * msmd_spconv_fwd_split_tile_rows(c_out)), the column sums and sums of squares of the rows
+ * it wrote: bn_partials[msmd_spconv_fwd_split_stats_blocks(n_out, c_out)][2][c_out] -- the statistics
  * pass of the BatchNorm1d that follows a conv in make_sparse_convmodule / SparseBasicBlock
  * (mmdet3d/ops/sparse_block.py:87-117,161-190) without reading the output again
  * (msmd_bn_act_fwd_from_partials_f32 takes them).  bn_partials = NULL: msmd_spconv_fwd_split. */
@@ -321,10 +321,12 @@ int msmd_spconv_fwd_split_stats(const float* in_feat, int n_in, int c_in,
                                 float* out_feat, int c_out, int planes, void* workspace,
                                 size_t workspace_bytes, const int32_t* tile_prefix,
                                 float* bn_partials, msmd_stream_t stream);
-int msmd_spconv_fwd_split_stats_blocks(int n_out);
+int msmd_spconv_fwd_split_stats_blocks(int n_out, int c_out);
 
-/* Rows per tile the split kernel uses for a layer of c_out output channels (128 or 256):
- * the rows_per_tile to compute its tile_prefix with. */
+/* Rows per tile the split kernel uses for a layer of c_out output channels: 256 (the
+ * ping-pong form: 8 waves, one workgroup and one weight stream per CU) above 64 channels,
+ * 128 up to 64 -- the rows_per_tile to compute its tile_prefix with.  MSMD_FWD_PP=0 in the
+ * environment: 128 everywhere. */
 int msmd_spconv_fwd_split_tile_rows(int c_out);
 
 /* Stream-K work table of a neighbour table (in the order the conv kernel tiles it):

@@ -15,7 +15,9 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsmd_hip.so")
+# (MSMD_LIB: another build of the same library -- tools/kprof.py loads the instrumented
+# `make PROF=1 OUT=../libmsmd_hip_prof.so` one; the product never sets it)
+LIB_PATH = os.environ.get("MSMD_LIB") or os.path.join(_HERE, "libmsmd_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
@@ -81,7 +83,7 @@ SIGNATURES = {
     "msmd_spconv_fwd_split_stats": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "msmd_rulebook_tile_prefix": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "msmd_spconv_fwd_split_tile_rows": (_i, [_i]),
-    "msmd_spconv_fwd_split_stats_blocks": (_i, [_i]),
+    "msmd_spconv_fwd_split_stats_blocks": (_i, [_i, _i]),
     "msmd_spconv_wgrad_split_supported": (_i, [_i, _i]),
     "msmd_spconv_wgrad_split": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "msmd_spconv_pack_weight_split_many": (_i, [_vp, _i, C.c_long, _i, _vp]),

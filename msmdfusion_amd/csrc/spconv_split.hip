@@ -358,7 +358,21 @@ inline int sk_c1() { return kSkC1Default; }
 // one workgroup per CU: the same 2 waves per SIMD, but ONE weight stream per CU instead of
 // two -- at ~17 B/clk the CU's memory pipeline could not feed two 24-KiB-per-item weight
 // streams plus the gathers at MFMA rate; stream-K removed the reason tiles had to be small).
-template <int NT, int UB, int NP, int WV, int NB = 2>
+// PP (round 5): the PING-PONG schedule of the 8-wave / 256-row form.  What bounds the 4-wave
+// kernel is the CU's vector-memory rate (~17-18 B/clk: two workgroups x one 18-24 KiB weight
+// image per item + eight waves x 4 KiB of gathered rows per ~3000 matrix cycles = 26-30 B/clk
+// wanted); one 8-wave workgroup per CU shares ONE weight stream (-40 % bytes per MFMA), but
+// with a single barrier per item (round 2, round 4) the two waves of every SIMD meet at it,
+// issue their memory work together and then queue their MFMA phases behind each other on the
+// one matrix pipe.  Here the workgroup is two 4-wave groups -- rows 0-127 (waves 0-3) and rows
+// 128-255 (waves 4-7), one wave of each per SIMD -- half an item apart: an item is a LOAD
+// segment (weight DMA of the next item, gathers of the next unit, wait for this unit's rows,
+// fp32 -> bf16 planes) and a MULTIPLY segment (the unit's MFMAs, weight fragments from LDS),
+// a barrier after each, and group B runs one segment behind group A: at any moment one wave
+// of a SIMD feeds the matrix pipe while its partner uses the vector-memory and VALU pipes.
+// Three weight buffers: the image of item g is read in segments 2g+1 (A) and 2g+2 (B), so its
+// buffer is free for item g+3's DMA from segment 2g+3 on (A issues it in 2g+4, B in 2g+5).
+template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false>
 __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_kernel(
     const float* __restrict__ in, int n_in, int cin, const u32x4* __restrict__ wp,
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
@@ -407,6 +421,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
   constexpr int kWp = UB * kPw;           // ... per item per wave
   constexpr int NS = NT / 2;            // fragment steps (pairs of 16-channel tiles) per unit
   static_assert(NT % 2 == 0, "pairs of output tiles");
+  static_assert(!PP || (WV == 8 && NB == 3 && UB == 1), "ping-pong: 8 waves, 3 buffers, 1 unit");
   using P = Products<NP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u32x4* wl = (u32x4*)smem;                       // [NB][kWU]
@@ -690,10 +705,123 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
     };
 
     u32x4 raw0[R][2], raw1[R][2];     // fp32 rows in flight (units g+1, g+2)
-    u32x4 cv0[R][NP], cv1[R][NP];     // bf16 planes (units g, g+1)
     int vr0 = -1, vr1 = -1;
     bool staged = false;
     int nxt = tile_lim;
+    KP_BEGIN();
+#ifdef MSMD_KERNEL_PROF
+    const unsigned long long kt0 = wall_clock64();
+#endif
+    if constexpr (PP) {
+      // ---- ping-pong item loop (see the kernel's header) ----
+      u32x4 cv[R][NP];
+      const bool grp_b = wave >= WV / 2;
+      // the unit's MFMAs alone (its rows' planes `b` were made in the load segment)
+      auto multiply = [&](int it, const u32x4 (&b)[R][NP], int valid) {
+        if (!__any(valid >= 0) || (dbg & 4)) return;
+        const u32x4* wb = wl + (it % NB) * kWU + lane;
+        u32x4 a[2][2][NP];
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) a[0][nn][p] = wb[(p * NT + nn) * 64];
+        constexpr int kHead = P::n >= 3 ? P::n / 3 : 0;
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < kHead; ++t)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+              for (int r = 0; r < R; ++r)
+                acc[r][2 * st + nn] =
+                    mfma_bf16(a[st & 1][nn][P::a[t]], b[r][P::b[t]], acc[r][2 * st + nn]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 1 < NS) {
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+              for (int p = 0; p < NP; ++p)
+                a[(st + 1) & 1][nn][p] = wb[(p * NT + 2 * (st + 1) + nn) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = kHead; t < P::n; ++t)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+              for (int r = 0; r < R; ++r)
+                acc[r][2 * st + nn] =
+                    mfma_bf16(a[st & 1][nn][P::a[t]], b[r][P::b[t]], acc[r][2 * st + nn]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto pin_planes = [&](u32x4 (&c)[R][NP]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(c[r][p]));
+      };
+      // prologue: weights of item 0, rows of unit 0, indices of unit 1.  Every wave has its
+      // own pieces of the image landed before its first barrier (the 4 newest ops = the rows)
+      issue_w(0);
+      load_src();
+      issue_g(raw0, vr0);
+      load_src();
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGr) : "memory");
+      if (grp_b) __builtin_amdgcn_s_barrier();      // group B runs one segment behind
+      // One item: LOAD segment | barrier | MULTIPLY segment | barrier.
+      // Queue at the counted wait (oldest first): rows(g) [4] | weights(g+1) [kPw] | rows(g+1)
+      // [4]: "all but the newest kPw + 4" = rows(g); after the MFMAs "all but the newest 4"
+      // = this wave's pieces of weights(g+1), a multiply segment after their issue.
+#define MSMD_PP_ITEM(G, RAW_C, V_C, RAW_N, V_N)                                          \
+  {                                                                                     \
+    if ((G) == 0 && tid == 0) {                                                         \
+      ctl[2] = nxt_v;                                                                   \
+      ctl[tb ^ 1] = 0;                                                                  \
+      if (!sk && nxt_v == last_ticket) *tile_counter = 0;                               \
+    }                                                                                   \
+    if ((G) == 1) { /* (both groups are past the barrier that follows A's first load) */ \
+      nxt = __builtin_amdgcn_readfirstlane(ctl[2]);                                     \
+      if (nxt < tile_lim) stage_table(nxt, tb ^ 1);                                     \
+      staged = true;                                                                    \
+    }                                                                                   \
+    KP_MARK(6);                                                                         \
+    issue_w((G) + 1);                                                                   \
+    KP_MARK(2);                                                                         \
+    issue_g(RAW_N, V_N);                                                                \
+    load_src();                                                                         \
+    KP_MARK(3);                                                                         \
+    wait_rows<kGr + kWp>(RAW_C);                                                        \
+    KP_MARK(4);                                                                         \
+    split_all(RAW_C, cv);                                                               \
+    /* (the conversion belongs to THIS segment: left alone the optimiser sinks it below \
+       the barrier into multiply()'s branch, where it competes with the MFMAs) */       \
+    pin_planes(cv);                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    KP_MARK(8);                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
+    __builtin_amdgcn_s_barrier();                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    KP_MARK(1);                                                                         \
+    if (dbg & 32) __builtin_amdgcn_s_setprio(1);                                        \
+    multiply((G), cv, V_C);                                                             \
+    if (dbg & 32) __builtin_amdgcn_s_setprio(0);                                        \
+    KP_MARK(5);                                                                         \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGr) : "memory");                          \
+    KP_MARK(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                       \
+    KP_MARK(9);                                                                         \
+  }
+      for (int it = 0; it < n_items; it += 2) {
+        MSMD_PP_ITEM(it, raw0, vr0, raw1, vr1);
+        if (it + 1 < n_items) MSMD_PP_ITEM(it + 1, raw1, vr1, raw0, vr0);
+      }
+#undef MSMD_PP_ITEM
+      if (!grp_b) __builtin_amdgcn_s_barrier();     // group A makes up B's head start
+    } else {
+    u32x4 cv0[R][NP], cv1[R][NP];     // bf16 planes (units g, g+1)
     // ---- prologue: weights of item 0, rows of units 0 and 1, indices of unit 2,
     // planes of unit 0
     issue_w(0);
@@ -769,14 +897,11 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
     // gathers BETWEEN the MFMA groups of the unit instead of in front of them.  Correct, and
     // no faster -- 256 against 258 us on the 128->128 layer in the same call: the issue cycles
     // moved under the MFMAs stretch the MFMA stream by as much.  Removed in round 3.)
-    KP_BEGIN();
-#ifdef MSMD_KERNEL_PROF
-    const unsigned long long kt0 = wall_clock64();
-#endif
     for (int it = 0; it < n_items; it += 2) {
       MSMD_ITEM(it, 0);
       if (it + 1 < n_items) MSMD_ITEM(it + 1, 1);
     }
+    }   // (!PP)
 #ifdef MSMD_KERNEL_PROF
     if (lane == 0 && wave == 1 && blockIdx.x < 8) atomicAdd(&g_kprof[7], (unsigned long long)n_items);
     if (tid == 0) {
@@ -956,7 +1081,7 @@ int reserved_cus() {
   return n;
 }
 
-template <int NT, int UB, int NP, int WV, int NB = 2>
+template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false>
 int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                      int ld, int n_out, int kvol, int flip, const int32_t* order,
                      int* tile_counter, float* out, int ldo, int cout, int nt_total, int mt0,
@@ -977,7 +1102,7 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   if (nblk > slots) nblk = slots;
   // stream-K: sk_grid ranges for (at most) one workgroup per slot
   if (tile_start) nblk = sk_grid < slots ? sk_grid : slots;
-  auto kern = spconv_fwd_split_kernel<NT, UB, NP, WV, NB>;
+  auto kern = spconv_fwd_split_kernel<NT, UB, NP, WV, NB, PP>;
   static LdsGrant granted;  // per instantiation
   const int lds_rc = optin_dynamic_lds((const void*)kern, smem, granted);
   if (lds_rc != MSMD_OK) return lds_rc;
@@ -988,27 +1113,20 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   return launch_status();
 }
 
-// Waves per workgroup / rows per tile of the split kernel (see the kernel): 4 x 128 rows,
-// two workgroups per CU.  (The 8-wave / 256-row instantiations of round 2 -- one workgroup
-// and one weight stream per CU -- measured within +-5 % on the 128-/192-channel layers and
-// 25 % slower on the 80-channel ones: the two waves of a SIMD then belong to one workgroup
-// and stall at its barriers together.  Removed in round 3; the kernel keeps its WV
-// parameter.)
-int fwd_waves(int cout) {
-  (void)cout;
-#ifdef MSMD_FWD_EXPERIMENTS
-  // `make EXTRA=-DMSMD_FWD_EXPERIMENTS`, MSMD_FWD_WAVES=8: 256-row tiles, one 8-wave workgroup
-  // per CU -- one weight stream per CU instead of two; MSMD_FWD_NB=3 with it: three weight
-  // buffers, weights two items ahead behind a counted wait.  Round 4 measured both again
-  // (DESIGN.md section 10): half the weight bytes and no weight wait left at the item top, and
-  // the same 240 us on the 128 -> 128 layer -- two waves of ONE workgroup per SIMD meet at
-  // every barrier and serialise their MFMA phases.  Not in the shipped library.
-  static const int w = env_int2("MSMD_FWD_WAVES", 4) == 8 ? 8 : 4;
-  return w;
-#else
-  return 4;
-#endif
+// Waves per workgroup / rows per tile of the split kernel (see the kernel).  Layers of more than
+// 64 output channels (6 or 8 column tiles per pass: one 18-24 KiB weight image per unit) run
+// the ping-pong form -- 8 waves, 256-row tiles, one workgroup and ONE weight stream per CU;
+// narrower layers keep 4 x 128 rows, two workgroups per CU (their items are short and their
+// weight images small: the bytes are not what they wait for).  MSMD_FWD_PP=0: 4 waves
+// everywhere (the round-1..4 kernel, for A/B runs).
+// (History: plain 8-wave / 256-row instantiations -- one barrier per item -- measured within
+// +-5 % on the 128-/192-channel layers and 25 % slower on the 80-channel ones in rounds 2 and
+// 4: the two waves of a SIMD met at every barrier and serialised their MFMA phases.)
+int fwd_pp() {
+  static const int v = env_int2("MSMD_FWD_PP", 1);
+  return v;
 }
+int fwd_waves(int cout) { return (fwd_pp() && cout > 64) ? 8 : 4; }
 // stream-K: workgroups (= segments = exchange slots) of a launch over `row_tiles` tiles,
 // and the exchange buffer: one pass's accumulators of one tile per workgroup
 // (ranges per workgroup slot: MSMD_SK_MULT)
@@ -1030,6 +1148,7 @@ size_t fwd_sk_ws_bytes(int n_out, int kvol, int cout) {
   const int n_pass = (nt_total + 7) / 8;
   int per = (nt_total + n_pass - 1) / n_pass;
   per = per > 6 ? 8 : per > 4 ? 6 : per > 2 ? 4 : 2;      // the instantiation's NT
+  if (fwd_waves(cout) == 8 && per < 6) per = 6;           // (ping-pong: NT = 6 or 8)
   size_t need = 0;
   for (int waves = fwd_waves(cout); waves <= fwd_waves(cout); waves += 4) {
     const int rows = waves * 32;
@@ -1070,28 +1189,19 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
     const int width = (16 * (mt0 + tiles) <= cout ? 16 * tiles : cout - 16 * mt0);
     float* o = out + 16 * mt0;
     int rc;
-#define MSMD_GO(NT_, UB_, WV_, NB_)                                                              \
-  rc = launch_fwd_split<NT_, UB_, NP, WV_, NB_>(in, n_in, cin, wp, nbr, ld, n_out, kvol, flip,   \
-                                                order, tile_counter, o, cout, width, nt_total,   \
-                                                mt0, ws, flags, tile_start, sk_grid, bn_part, st)
-#ifdef MSMD_FWD_EXPERIMENTS
-    static const int nb3 = env_int2("MSMD_FWD_NB", 2) == 3;
-    if (waves == 8 && nb3) {
-      if (tiles > 6) { MSMD_GO(8, 1, 8, 3); }
-      else if (tiles > 4) { MSMD_GO(6, 1, 8, 3); }
-      else if (tiles > 2) { MSMD_GO(4, 2, 8, 3); }
-      else { MSMD_GO(2, 4, 8, 3); }
-    } else if (waves == 8) {
-      if (tiles > 6) { MSMD_GO(8, 1, 8, 2); }
-      else if (tiles > 4) { MSMD_GO(6, 1, 8, 2); }
-      else if (tiles > 2) { MSMD_GO(4, 2, 8, 2); }
-      else { MSMD_GO(2, 4, 8, 2); }
-    } else
-#endif
-    if (tiles > 6) { MSMD_GO(8, 1, 4, 2); }
-    else if (tiles > 4) { MSMD_GO(6, 1, 4, 2); }
-    else if (tiles > 2) { MSMD_GO(4, 2, 4, 2); }
-    else { MSMD_GO(2, 4, 4, 2); }
+#define MSMD_GO(NT_, UB_, WV_, NB_, PP_)                                                         \
+  rc = launch_fwd_split<NT_, UB_, NP, WV_, NB_, PP_>(in, n_in, cin, wp, nbr, ld, n_out, kvol,    \
+                                                     flip, order, tile_counter, o, cout, width,  \
+                                                     nt_total, mt0, ws, flags, tile_start,       \
+                                                     sk_grid, bn_part, st)
+    if (waves == 8) {          // ping-pong; a short last pass computes (and drops) spare tiles
+      if (tiles > 6) { MSMD_GO(8, 1, 8, 3, true); }
+      else { MSMD_GO(6, 1, 8, 3, true); }
+    }
+    else if (tiles > 6) { MSMD_GO(8, 1, 4, 2, false); }
+    else if (tiles > 4) { MSMD_GO(6, 1, 4, 2, false); }
+    else if (tiles > 2) { MSMD_GO(4, 2, 4, 2, false); }
+    else { MSMD_GO(2, 4, 4, 2, false); }
 #undef MSMD_GO
     if (rc != MSMD_OK) return rc;
   }
@@ -1467,10 +1577,11 @@ MSMD_EXPORT size_t msmd_spconv_fwd_split_workspace_bytes(int n_out, int cout) {
   return fwd_sk_ws_bytes(n_out, kMaxK, cout);
 }
 
-// bn_partials (or NULL): [ceil(n_out / 128)][2][c_out] floats -- per row tile the column sums
+// bn_partials (or NULL): [msmd_spconv_fwd_split_stats_blocks(n_out, c_out)][2][c_out] floats
+// (one block per row tile of this width's kernel: 128 or 256 rows) -- per row tile the column sums
 // and sums of squares of the rows written (what msmd_bn_act_fwd_from_partials_f32 takes)
-MSMD_EXPORT int msmd_spconv_fwd_split_stats_blocks(int n_out) {
-  return ceil_div(n_out > 0 ? n_out : 0, 32 * fwd_waves(0));
+MSMD_EXPORT int msmd_spconv_fwd_split_stats_blocks(int n_out, int cout) {
+  return ceil_div(n_out > 0 ? n_out : 0, 32 * fwd_waves(cout));
 }
 
 MSMD_EXPORT int msmd_spconv_fwd_split_stats(const float* planes, int n_in, int cin,

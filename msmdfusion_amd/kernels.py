@@ -853,7 +853,7 @@ def conv_forward_split(feat, packed_weight, nbr, n_out, c_out, planes=3, weight_
     # BatchNorm that follows (bn_act_forward(partials=...)) -> (out, partials)
     part = None
     if bn_stats and int(n_out) > 0:
-        part = torch.empty((int(lib.msmd_spconv_fwd_split_stats_blocks(int(n_out))), 2,
+        part = torch.empty((int(lib.msmd_spconv_fwd_split_stats_blocks(int(n_out), int(c_out))), 2,
                             int(c_out)), dtype=torch.float32, device=f.device)
     ev = _prof_begin()
     check(lib.msmd_spconv_fwd_split_stats(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld,
