@@ -625,14 +625,18 @@ def split_instantiation(c_out, planes):
     channels the 8-wave ping-pong instantiation."""
     from msmdfusion_amd import kernels as K
     nt_total = (c_out + 15) // 16
-    n_pass = (nt_total + 7) // 8
-    per = (nt_total + n_pass - 1) // n_pass
-    nt = 8 if per > 6 else 6 if per > 4 else 4 if per > 2 else 2
-    ub = {8: 1, 6: 1, 4: 2, 2: 4}[nt]
     waves = K.split_tile_rows(c_out) // 32
-    if waves == 8:      # the ping-pong form (> 64 output channels): 6 or 8 tiles, 3 weight buffers
-        return "spconv_fwd_split_kernel<%d, 1, %d, 8, 3, true>" % (max(nt, 6), planes), n_pass
-    return "spconv_fwd_split_kernel<%d, %d, %d, %d, 2, false>" % (nt, ub, planes, waves), n_pass
+    n_pass = (nt_total + 7) // 8
+    if waves == 8 and nt_total in (11, 12) and os.environ.get("MSMD_FWD_NT12", "1") != "0":
+        n_pass = 1          # 161..192 channels: one 12-tile pass (csrc/spconv_split.hip)
+    per = (nt_total + n_pass - 1) // n_pass
+    nt = 12 if per > 8 else 8 if per > 6 else 6 if per > 4 else 4 if per > 2 else 2
+    if waves == 8:      # the ping-pong form: 6, 8 or 12 tiles, 3 weight buffers
+        nt = max(nt, 6)
+        return "spconv_fwd_split_kernel<%d, 1, %d, 8, 3, true, %d>" % (
+            nt, planes, 1 if nt == 12 else 2), n_pass
+    ub = {8: 1, 6: 1, 4: 2, 2: 4}[nt]
+    return "spconv_fwd_split_kernel<%d, %d, %d, %d, 2, false, 2>" % (nt, ub, planes, waves), n_pass
 
 
 HBM_PEAK_TBPS = 8.0     # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy rate)

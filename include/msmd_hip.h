@@ -324,8 +324,8 @@ int msmd_spconv_fwd_split_stats(const float* in_feat, int n_in, int c_in,
 int msmd_spconv_fwd_split_stats_blocks(int n_out, int c_out);
 
 /* Rows per tile the split kernel uses for a layer of c_out output channels: 256 (the
- * ping-pong form: 8 waves, one workgroup and one weight stream per CU) above 64 channels,
- * 128 up to 64 -- the rows_per_tile to compute its tile_prefix with.  MSMD_FWD_PP=0 in the
+ * ping-pong form: 8 waves, one workgroup and one weight stream per CU) above 96 channels,
+ * 128 up to 96 -- the rows_per_tile to compute its tile_prefix with.  MSMD_FWD_PP=0 in the
  * environment: 128 everywhere. */
 int msmd_spconv_fwd_split_tile_rows(int c_out);
 

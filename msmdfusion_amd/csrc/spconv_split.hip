@@ -372,7 +372,11 @@ inline int sk_c1() { return kSkC1Default; }
 // of a SIMD feeds the matrix pipe while its partner uses the vector-memory and VALU pipes.
 // Three weight buffers: the image of item g is read in segments 2g+1 (A) and 2g+2 (B), so its
 // buffer is free for item g+3's DMA from segment 2g+3 on (A issues it in 2g+4, B in 2g+5).
-template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false>
+// TB = table buffers: 2 (the next tile's slice staged under the current tile's item 1), or 1
+// for the 12-tile instantiation, whose three 36 KiB weight buffers leave room for one table
+// only -- the next slice is staged at the tile switch (one exposed load per tile of ~100+
+// items).
+template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false, int TB = 2>
 __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_kernel(
     const float* __restrict__ in, int n_in, int cin, const u32x4* __restrict__ wp,
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
   u32x4* wl = (u32x4*)smem;                       // [NB][kWU]
   int* nbt = (int*)(wl + NB * kWU);               // [2][kvol + 1][kRows]; row kvol = output rows
   const int tstride = (kvol + 1) * kRows;
-  int* ctl = nbt + 2 * tstride;                   // [0],[1]: offset masks; [2]: next tile
+  int* ctl = nbt + TB * tstride;                  // [0],[1]: offset masks; [2]: next tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
   // table slice of tile T -> buffer b, by LDS-DMA (4 bytes per lane).  Positions
   // past n_out are clamped: their results are computed and dropped.
   auto stage_table = [&](int T, int b) {
-    int* dst = nbt + b * tstride;
+    int* dst = nbt + (TB == 1 ? 0 : b) * tstride;
     const int n_e = (kvol + (order ? 1 : 0)) * kRows;
     for (int e0 = wave * 64; e0 < n_e; e0 += WV * 64) {
       const int e = e0 + lane, k = e >> kRowShift;
@@ -528,7 +532,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
       sk_tw = tile_start[tile + 1] - t0s;
       sk_ts = t0s + sk_c0 * (tile + 1);        // where the tile's ranks start
     }
-    const int* tab = nbt + tb * tstride;
+    const int* tab = nbt + (TB == 1 ? 0 : tb) * tstride;
     int* cst = ctl + 4 + tb * 32;     // stream-K cost of every offset of this tile (0: none)
     {  // offsets any row of this tile is connected through, and how many waves each keeps busy
       unsigned m = 0;
@@ -782,7 +786,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
       ctl[tb ^ 1] = 0;                                                                  \
       if (!sk && nxt_v == last_ticket) *tile_counter = 0;                               \
     }                                                                                   \
-    if ((G) == 1) { /* (both groups are past the barrier that follows A's first load) */ \
+    if (TB == 2 && (G) == 1) { /* (both groups are past the barrier after A's first load) */ \
       nxt = __builtin_amdgcn_readfirstlane(ctl[2]);                                     \
       if (nxt < tile_lim) stage_table(nxt, tb ^ 1);                                     \
       staged = true;                                                                    \
@@ -1081,7 +1085,7 @@ int reserved_cus() {
   return n;
 }
 
-template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false>
+template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false, int TB = 2>
 int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                      int ld, int n_out, int kvol, int flip, const int32_t* order,
                      int* tile_counter, float* out, int ldo, int cout, int nt_total, int mt0,
@@ -1095,14 +1099,14 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   const int sk_c0 = ((ovh_units + kbt - 1) / kbt) * (sk_c1() + 2);   // in cost units
   constexpr int kRows = WV * 32;
   const size_t smem = sizeof(u32x4) * NB * UB * NP * NT * 64 +
-                      sizeof(int) * (2 * (size_t)(kvol + 1) * kRows + 72);
+                      sizeof(int) * (TB * (size_t)(kvol + 1) * kRows + 72);
   const int n_tiles = ceil_div(n_out, kRows);
   int nblk = n_tiles;
   const int slots = (256 - reserved_cus()) * (WV == 4 ? split_slots_per_cu() : 1);
   if (nblk > slots) nblk = slots;
   // stream-K: sk_grid ranges for (at most) one workgroup per slot
   if (tile_start) nblk = sk_grid < slots ? sk_grid : slots;
-  auto kern = spconv_fwd_split_kernel<NT, UB, NP, WV, NB, PP>;
+  auto kern = spconv_fwd_split_kernel<NT, UB, NP, WV, NB, PP, TB>;
   static LdsGrant granted;  // per instantiation
   const int lds_rc = optin_dynamic_lds((const void*)kern, smem, granted);
   if (lds_rc != MSMD_OK) return lds_rc;
@@ -1114,7 +1118,7 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
 }
 
 // Waves per workgroup / rows per tile of the split kernel (see the kernel).  Layers of more than
-// 64 output channels (6 or 8 column tiles per pass: one 18-24 KiB weight image per unit) run
+// 96 output channels (8 or 12 column tiles per pass: one 24-36 KiB weight image per unit) run
 // the ping-pong form -- 8 waves, 256-row tiles, one workgroup and ONE weight stream per CU;
 // narrower layers keep 4 x 128 rows, two workgroups per CU (their items are short and their
 // weight images small: the bytes are not what they wait for).  MSMD_FWD_PP=0: 4 waves
@@ -1126,7 +1130,22 @@ int fwd_pp() {
   static const int v = env_int2("MSMD_FWD_PP", 1);
   return v;
 }
-int fwd_waves(int cout) { return (fwd_pp() && cout > 64) ? 8 : 4; }
+int fwd_waves(int cout) {
+  // measured layer by layer against the 4-wave kernel (profiles/r05_pp_layers.txt): 96 -> 128
+  // +3.5 %, 128 -> 192 +4.7 %, 192 -> 192 +4.8 % (two passes) ... 80 -> 80 / 80 -> 96 -7 %
+  static const int min_cout = env_int2("MSMD_FWD_PP_MIN", 97);
+  return (fwd_pp() && cout >= min_cout) ? 8 : 4;
+}
+// Column passes: at most 8 tiles of 16 channels each -- except 161..192 channels in the
+// ping-pong form, ONE pass of 12 tiles: a row piece is gathered and split into planes once
+// for all of c_out (two 6-tile passes did that work twice: the load segment of an item --
+// weight DMA, gathers, conversion, ~2400 cycles -- is longer than its 72 MFMAs' 1150).
+int fwd_passes(int cout) {
+  const int nt_total = (cout + 15) / 16;
+  static const int one12 = env_int2("MSMD_FWD_NT12", 1);
+  if (fwd_waves(cout) == 8 && one12 && (nt_total == 11 || nt_total == 12)) return 1;
+  return (nt_total + 7) / 8;
+}
 // stream-K: workgroups (= segments = exchange slots) of a launch over `row_tiles` tiles,
 // and the exchange buffer: one pass's accumulators of one tile per workgroup
 // (ranges per workgroup slot: MSMD_SK_MULT)
@@ -1145,9 +1164,9 @@ int sk_grid_size(int row_tiles, int kvol, int waves) {
 }
 size_t fwd_sk_ws_bytes(int n_out, int kvol, int cout) {
   const int nt_total = (cout + 15) / 16;
-  const int n_pass = (nt_total + 7) / 8;
+  const int n_pass = fwd_passes(cout);
   int per = (nt_total + n_pass - 1) / n_pass;
-  per = per > 6 ? 8 : per > 4 ? 6 : per > 2 ? 4 : 2;      // the instantiation's NT
+  per = per > 8 ? 12 : per > 6 ? 8 : per > 4 ? 6 : per > 2 ? 4 : 2;      // the instantiation's NT
   if (fwd_waves(cout) == 8 && per < 6) per = 6;           // (ping-pong: NT = 6 or 8)
   size_t need = 0;
   for (int waves = fwd_waves(cout); waves <= fwd_waves(cout); waves += 4) {
@@ -1168,7 +1187,7 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
                        size_t ws_bytes, const int32_t* tile_prefix, float* bn_part,
                        hipStream_t st) {
   const int nt_total = (cout + 15) / 16;
-  const int n_pass = (nt_total + 7) / 8;
+  const int n_pass = fwd_passes(cout);
   const int per = (nt_total + n_pass - 1) / n_pass;   // tiles per pass
   const int waves = fwd_waves(cout);
   const int row_tiles = ceil_div(n_out, waves * 32);
@@ -1194,8 +1213,14 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
                                                      flip, order, tile_counter, o, cout, width,  \
                                                      nt_total, mt0, ws, flags, tile_start,       \
                                                      sk_grid, bn_part, st)
+#define MSMD_GO12()                                                                              \
+  rc = launch_fwd_split<12, 1, NP, 8, 3, true, 1>(in, n_in, cin, wp, nbr, ld, n_out, kvol, flip, \
+                                                  order, tile_counter, o, cout, width, nt_total, \
+                                                  mt0, ws, flags, tile_start, sk_grid, bn_part,  \
+                                                  st)
     if (waves == 8) {          // ping-pong; a short last pass computes (and drops) spare tiles
-      if (tiles > 6) { MSMD_GO(8, 1, 8, 3, true); }
+      if (tiles > 8) { MSMD_GO12(); }
+      else if (tiles > 6) { MSMD_GO(8, 1, 8, 3, true); }
       else { MSMD_GO(6, 1, 8, 3, true); }
     }
     else if (tiles > 6) { MSMD_GO(8, 1, 4, 2, false); }
@@ -1203,6 +1228,7 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
     else if (tiles > 2) { MSMD_GO(4, 2, 4, 2, false); }
     else { MSMD_GO(2, 4, 4, 2, false); }
 #undef MSMD_GO
+#undef MSMD_GO12
     if (rc != MSMD_OK) return rc;
   }
   return MSMD_OK;

@@ -475,10 +475,12 @@ def test_rulebook_plan_many_equals_the_single_plans(dev):
         assert torch.equal(r["pairs"][1], one["pairs"][1])
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 128), (32, 64), (80, 80), (128, 192), (40, 72)])
+@pytest.mark.parametrize("cin,cout", [(64, 128), (32, 64), (80, 80), (128, 192), (40, 72),
+                                      (96, 176), (128, 160)])
 def test_conv_epilogue_leaves_the_batchnorm_partials(dev, cin, cout):
-    """msmd_spconv_fwd_split_stats: per 128-row tile the column sums and sums of squares of the
-    rows the conv wrote (every instantiation width: one and two column passes, a partial last
+    """msmd_spconv_fwd_split_stats: per row tile (128 rows, 256 in the ping-pong form above 96
+    output channels) the column sums and sums of squares of the rows the conv wrote (every
+    instantiation width: 2 / 4 / 6 / 8 / 12 column tiles, a partial last
     channel tile, a partial last row tile; stream-K pieces summed by the owner first), and
     msmd_bn_act_fwd_from_partials_f32 == the BatchNorm with its own statistics pass."""
     from msmdfusion_amd import kernels as K
@@ -486,20 +488,21 @@ def test_conv_epilogue_leaves_the_batchnorm_partials(dev, cin, cout):
     idx = S.random_voxel_indices(2100, 2, shape, seed=cin + cout)
     n = idx.shape[0]
     nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
-    plan = K.rulebook_plan(nbr, tile_rows=(128,))
+    tr = K.split_tile_rows(cout)
+    plan = K.rulebook_plan(nbr, tile_rows=(tr,))
     g = torch.Generator(device=dev).manual_seed(cin * 7 + cout)
     f = torch.randn(n, cin, device=dev, generator=g)
     w = torch.randn(27, cin, cout, device=dev, generator=g) / (27 * cin) ** 0.5
     ws = K.pack_weight_split(w, 3)
-    for pre in (plan["prefix"][128], None):      # stream-K and whole tiles
+    for pre in (plan["prefix"][tr], None):      # stream-K and whole tiles
         out, part = K.conv_forward_split(f, ws, plan["tiled"], n, cout, 3, row_order=plan["order"],
                                          tile_prefix=pre, bn_stats=True)
         assert torch.equal(out, K.conv_forward_split(f, ws, plan["tiled"], n, cout, 3,
                                                      row_order=plan["order"], tile_prefix=pre))
-        assert part.shape == ((n + 127) // 128, 2, cout)
-        rows = out[plan["order"].long()].double()          # tile t = positions 128 t ..
+        assert part.shape == ((n + tr - 1) // tr, 2, cout)
+        rows = out[plan["order"].long()].double()          # tile t = positions tr * t ..
         for ti in (0, part.shape[0] // 2, part.shape[0] - 1):
-            blk = rows[128 * ti:128 * ti + 128]
+            blk = rows[tr * ti:tr * ti + tr]
             scale = max(blk.abs().max().item(), 1.0)
             assert (part[ti, 0].double() - blk.sum(0)).abs().max().item() <= 1e-4 * scale
             assert (part[ti, 1].double() - (blk * blk).sum(0)).abs().max().item() <= 1e-4 * scale ** 2
@@ -560,7 +563,10 @@ SPLIT_CHANNELS = [(32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (96, 96),
                   (128, 64), (128, 96),
                   # the fusion stack's widths: partial last k-block (c_in % 32 != 0), odd
                   # tile counts, c_out > 128 (two column passes)
-                  (80, 80), (80, 96), (96, 128), (128, 192), (192, 192), (40, 72)]
+                  (80, 80), (80, 96), (96, 128), (128, 192), (192, 192), (40, 72),
+                  # round 5: 11 tiles in the 12-tile single pass, 10 tiles as two 5-tile
+                  # passes of the 6-tile ping-pong instantiation, 13 tiles as 7 + 6
+                  (96, 176), (64, 160), (32, 208)]
 
 
 @pytest.mark.parametrize("planes", [3, 2])
