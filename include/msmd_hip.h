@@ -324,9 +324,10 @@ int msmd_spconv_fwd_split_stats(const float* in_feat, int n_in, int c_in,
 int msmd_spconv_fwd_split_stats_blocks(int n_out, int c_out);
 
 /* Rows per tile the split kernel uses for a layer of c_out output channels: 256 (the
- * ping-pong form: 8 waves, one workgroup and one weight stream per CU) above 96 channels,
- * 128 up to 96 -- the rows_per_tile to compute its tile_prefix with.  MSMD_FWD_PP=0 in the
- * environment: 128 everywhere. */
+ * ping-pong form: 8 waves, one workgroup and one weight stream per CU; 161..192 channels as
+ * one 12-tile pass) from 161 channels up, 128 below -- the rows_per_tile to compute its
+ * tile_prefix with.  Environment: MSMD_FWD_PP_MIN moves the threshold, MSMD_FWD_PP=0 = 128
+ * everywhere. */
 int msmd_spconv_fwd_split_tile_rows(int c_out);
 
 /* Stream-K work table of a neighbour table (in the order the conv kernel tiles it):

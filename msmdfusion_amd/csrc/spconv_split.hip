@@ -1117,12 +1117,16 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   return launch_status();
 }
 
-// Waves per workgroup / rows per tile of the split kernel (see the kernel).  Layers of more than
-// 96 output channels (8 or 12 column tiles per pass: one 24-36 KiB weight image per unit) run
-// the ping-pong form -- 8 waves, 256-row tiles, one workgroup and ONE weight stream per CU;
-// narrower layers keep 4 x 128 rows, two workgroups per CU (their items are short and their
-// weight images small: the bytes are not what they wait for).  MSMD_FWD_PP=0: 4 waves
-// everywhere (the round-1..4 kernel, for A/B runs).
+// Waves per workgroup / rows per tile of the split kernel (see the kernel).  Layers of
+// 161..192 output channels (and wider) run the ping-pong form -- 8 waves, 256-row tiles, one
+// workgroup and ONE weight stream per CU -- where 192 channels are ONE 12-tile pass: 506 us
+// against 604 on 192 -> 192, 407 against 498 on 128 -> 192 (profiles/r05_pp_layers.txt).
+// Narrower layers keep 4 x 128 rows, two workgroups per CU: layer by layer the ping-pong form
+// is within +-5 % of it there (96 -> 128 +3.5 %, 128 -> 128 0, 80 -> 80 -7 %), and inside the
+// LC step -- other streams' kernels wanting CUs that an 8-wave, 130 KiB workgroup holds whole
+// -- its 8-tile instantiation ran 10 % slower (101-104 against 113-114 TF, same call).
+// MSMD_FWD_PP_MIN moves the threshold (97: every layer above 96 channels), MSMD_FWD_PP=0
+// keeps 4 waves everywhere (the round-1..4 kernel), for A/B runs.
 // (History: plain 8-wave / 256-row instantiations -- one barrier per item -- measured within
 // +-5 % on the 128-/192-channel layers and 25 % slower on the 80-channel ones in rounds 2 and
 // 4: the two waves of a SIMD met at every barrier and serialised their MFMA phases.)
@@ -1131,9 +1135,7 @@ int fwd_pp() {
   return v;
 }
 int fwd_waves(int cout) {
-  // measured layer by layer against the 4-wave kernel (profiles/r05_pp_layers.txt): 96 -> 128
-  // +3.5 %, 128 -> 192 +4.7 %, 192 -> 192 +4.8 % (two passes) ... 80 -> 80 / 80 -> 96 -7 %
-  static const int min_cout = env_int2("MSMD_FWD_PP_MIN", 97);
+  static const int min_cout = env_int2("MSMD_FWD_PP_MIN", 161);
   return (fwd_pp() && cout >= min_cout) ? 8 : 4;
 }
 // Column passes: at most 8 tiles of 16 channels each -- except 161..192 channels in the

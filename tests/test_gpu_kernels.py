@@ -478,8 +478,8 @@ def test_rulebook_plan_many_equals_the_single_plans(dev):
 @pytest.mark.parametrize("cin,cout", [(64, 128), (32, 64), (80, 80), (128, 192), (40, 72),
                                       (96, 176), (128, 160)])
 def test_conv_epilogue_leaves_the_batchnorm_partials(dev, cin, cout):
-    """msmd_spconv_fwd_split_stats: per row tile (128 rows, 256 in the ping-pong form above 96
-    output channels) the column sums and sums of squares of the rows the conv wrote (every
+    """msmd_spconv_fwd_split_stats: per row tile (128 rows, 256 in the ping-pong form from 161
+    output channels up) the column sums and sums of squares of the rows the conv wrote (every
     instantiation width: 2 / 4 / 6 / 8 / 12 column tiles, a partial last
     channel tile, a partial last row tile; stream-K pieces summed by the owner first), and
     msmd_bn_act_fwd_from_partials_f32 == the BatchNorm with its own statistics pass."""
@@ -638,9 +638,12 @@ def test_split_conv_subm(dev, cin, cout, planes):
             m = nb[k] >= 0
             ref[m] += f[nb[k][m]].astype(np.float64) @ w[k].astype(np.float64)
         e_split = np.abs(out.cpu().numpy() - ref).max()
-        e_fp32 = np.abs(K.conv_forward(fd, K.pack_weight(wd), nbr, n, cout).cpu().numpy()
-                        - ref).max()
-        assert e_split <= 2.0 * e_fp32 + 1e-7, (e_split, e_fp32)
+        if (cout + 15) // 16 in (12, 8, 6, 5, 4, 3, 2, 1):     # widths msmd_spconv_fwd_f32 takes
+            e_fp32 = np.abs(K.conv_forward(fd, K.pack_weight(wd), nbr, n, cout).cpu().numpy()
+                            - ref).max()
+            assert e_split <= 2.0 * e_fp32 + 1e-7, (e_split, e_fp32)
+        else:                           # (10, 11, 13 tiles: against the fp64 sum alone)
+            assert e_split <= 4e-6 * np.abs(ref).max(), e_split
 
 
 @pytest.mark.parametrize("ks,st,pd", [(3, 2, 1), (3, 2, [0, 1, 1]), ([3, 1, 1], [2, 1, 1], 0)])

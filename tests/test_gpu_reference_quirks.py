@@ -161,7 +161,10 @@ def test_gma_stage_with_reference_quirks_matches_the_oracle(dev):
     a2 = spconv.SparseConvTensor(torch.from_numpy(f3).to(dev), torch.from_numpy(i3).to(dev), SHAPE0, batch)
     b2 = spconv.SparseConvTensor(torch.from_numpy(f2).to(dev), torch.from_numpy(i2).to(dev), SHAPE0, batch)
     a2, b2, t3, t2 = voxel_modality_split(a2, b2, batch)
-    assert t3.shape[0] == true_matches < s3.shape[0]
+    # (fewer pairs, all of them true matches; a few true matches of the exact mode are taken
+    # by an earlier row with the same rounded key in the reference's)
+    assert true_matches <= t3.shape[0] < s3.shape[0]
+    assert (i3[_np(t3)] == i2[_np(t2)]).all()
 
 
 def test_detector_switch_selects_the_reference_split(dev):
