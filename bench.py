@@ -100,6 +100,17 @@ WORKLOADS = {
              "focal), fwd+bwd+AdamW, 2 x (28.7k LiDAR + 50k virtual pts)/GPU, fp32 (image backbone "
              "out of scope: virtual points arrive with their 49 image channels)",
         spg=MSMDFUSION_LC["samples_per_gpu"], bev_channels=0, settle=16),
+    "lc_img": dict(
+        metric="samples/sec MSMDFusion fwd+bwd nuScenes 0.075m voxel (MSMDFusion-LC sparse "
+               "fusion path fed from image feature maps)",
+        name="configs[2] + rows a13 (image half) / f2: the virtual points are MADE inside the "
+             "step -- synthetic FPN maps [B*6,256,112x200 / 56x100 / 28x50] + per-camera pixel "
+             "lists (~50k foreground points per sample, host arrays as the loader hands them) -> "
+             "pack_foreground (H2D) -> depth canvas -> DepthAwareChannelCompression (3 x Conv2d "
+             "257->49 + BN + ReLU) -> msmd_fg_gather_f32 x 4 scales -> ScoreNet -> 4-scale "
+             "voxelization (MSMDFusion.py:335-393,169-238; no gradient flows back through it: "
+             "voxelize is @no_grad, :462) -> the MSMDFusion-LC sparse path, fwd+bwd+AdamW, fp32",
+        spg=MSMDFUSION_LC["samples_per_gpu"], bev_channels=640, settle=16),
     "transfusion_l": dict(
         metric="samples/sec TransFusion-L voxel backbone fwd+bwd (nuScenes 0.075m voxel)",
         name="configs[1]: TransFusion-L voxel backbone (voxelize+VFE+SparseEncoder->BEV), "
@@ -187,6 +198,96 @@ class FusionBackbone(torch.nn.Module):
         # cat([x, x_mm], 1) -- bev_fusion's input (MSMDFusion.py:440) -- as ONE
         # channels-last map both sparse tensors scatter into (no dense()+view+cat)
         return self.det.extract_sparse_feat(points, virtual, prepared=prepared)
+
+
+class FusionImageBackbone(FusionBackbone):
+    """FusionBackbone fed from IMAGE FEATURES: MSMDFusionDetector.extract_multiscale_voxel_feat's
+    image half (MSMDFusion.py:400-407 -> depth_aware_channel_compression :335-368,
+    get_foreground2D :169-238) makes the per-scale virtual points inside the step.  It is
+    input + frozen-weight work (the reference's voxelize is @no_grad: conv1x1_blocks and
+    score_net receive no gradient, configs/...LC.py:309 find_unused_parameters), so it runs
+    with the index pass, a step ahead on the prefetcher's stream."""
+
+    def prepare(self, points, img_feats, metas):
+        with torch.no_grad():
+            virt = self.det.virtual_points_from_images(img_feats, metas)
+        return dict(virt=virt, index=self.det.prepare(points, virt, nn_side_stream=True))
+
+    def forward(self, points, img_feats, metas, prepared=None):
+        p = prepared if prepared is not None else self.prepare(points, img_feats, metas)
+        return self.det.extract_sparse_feat(points, p["virt"], prepared=p["index"])
+
+
+def synthetic_image_batch(sample_ids, dev, cams=6, input_hw=(448, 800)):
+    """Image-side inputs of a batch: FPN maps (strides 4 / 8 / 16 of the 800 x 448 input,
+    configs/...LC.py:17,159-163) and img_metas whose foreground2D_info holds, per camera, the
+    foreground pixel list (x, y, depth), the virtual points' own 15 attributes (the first 15
+    columns of synthetic.virtual_points: the image channels come from the maps now) and the
+    real-point pixels of the sparse depth map -- numpy arrays, as MyLoadForeground2D leaves
+    them (my_loading_multi_proj.py:38-97)."""
+    import numpy as np
+    from msmdfusion_amd import synthetic as S
+    H, W = input_hw
+    B = len(sample_ids)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    feats = [torch.randn(B * cams, 256, H // s, W // s, generator=g).to(dev) for s in (4, 8, 16)]
+    metas = []
+    for i in sample_ids:
+        rs = np.random.RandomState(500 + i)
+        pts = S.virtual_points(i)[:, :15]
+        parts = np.array_split(np.arange(pts.shape[0]), cams)
+        pix, fpts, real, l2i = [], [], [], []
+        for j in range(cams):
+            n = parts[j].shape[0]
+            p = np.stack([rs.uniform(0, W - 1, n), rs.uniform(0, H - 1, n),
+                          rs.uniform(1, 60, n)], 1).astype(np.float32)
+            pix.append(p)
+            fpts.append(np.ascontiguousarray(pts[parts[j]]))
+            m = n // 4                   # LiDAR returns that hit the camera: integer pixels
+            real.append(np.stack([rs.randint(0, W, m), rs.randint(0, H, m),
+                                  rs.uniform(1, 60, m)], 1).astype(np.float32))
+            l2i.append(rs.randn(4, 4).astype(np.float32))
+        metas.append(dict(foreground2D_info=dict(fg_pixels=pix, fg_points=fpts, fg_real_pixels=real),
+                          lidar2img=l2i, input_shape=(H, W), pad_shape=(H, W, 3)))
+    return feats, metas
+
+
+def image_glue_kernel_times(model, batch, reps=10):
+    """The image half alone, after the timed steps: ms per call of virtual_points_from_images
+    (the whole glue) and us / GB/s of one msmd_fg_gather_f32 launch at each scale's map
+    (algorithmic bytes: per point the C gathered floats read + the two rows written)."""
+    from msmdfusion_amd import kernels as K
+    from msmdfusion_amd.image_glue import pack_foreground
+    _, feats, metas = batch
+    det = model.det
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps
+    with torch.no_grad():
+        whole = timed(lambda: det.virtual_points_from_images(feats, metas))
+        pack = pack_foreground(metas, feats[0].device)
+        comp = det._compress(feats, metas, pack=pack)
+        out = {"virtual_points_from_images_ms": round(whole, 3), "fg_gather": []}
+        n = pack.pixels.shape[0]
+        for f in comp:
+            c = f.shape[1]
+            ds = f.shape[-1] / metas[0]["input_shape"][-1]
+            ms = timed(lambda: K.fg_gather(f, pack.pixels, pack.plane, ds, pack.points,
+                                           pack.lidar2img))
+            nbytes = n * 4 * (c + 3 + 15 + (15 + c) + (c + 17) + 1)
+            out["fg_gather"].append({"map": list(f.shape), "points": int(n), "us": round(ms * 1e3, 1),
+                                     "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                                     "frac_hbm": round(nbytes / (ms * 1e-3) / 1e12 / HBM_PEAK_TBPS, 4)})
+    return out
 
 
 class FusionTailBackbone(FusionBackbone):
@@ -352,12 +453,13 @@ def run_workload(workload, args, dev, rank, world, profile):
     from msmdfusion_amd.prefetch import IndexPrefetcher
 
     wl = WORKLOADS[workload]
-    lc = workload in ("lc", "lc_tail", "lc_b4", "lc_full")
+    lc = workload in ("lc", "lc_tail", "lc_b4", "lc_full", "lc_img")
     spg = wl["spg"]
     torch.manual_seed(0)
     ids = D.shard_sample_ids(rank, world, spg)      # disjoint samples per rank (weak scaling)
     model = (FusionDetector(ids) if workload == "lc_full" else
-             FusionTailBackbone() if workload == "lc_tail" else FusionBackbone() if lc
+             FusionTailBackbone() if workload == "lc_tail" else
+             FusionImageBackbone() if workload == "lc_img" else FusionBackbone() if lc
              else Backbone()).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     net = D.wrap_data_parallel(model, device_ids=[dev.index])
@@ -368,7 +470,9 @@ def run_workload(workload, args, dev, rank, world, profile):
 
     clouds = [torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in ids]
     batch = (clouds,)
-    if lc:
+    if workload == "lc_img":
+        batch = (clouds,) + synthetic_image_batch(ids, dev)
+    elif lc:
         batch = (clouds, [torch.from_numpy(S.virtual_points(i)).to(dev) for i in ids])
     if workload == "lc_full":       # the module returns its loss: (loss * 1).mean()
         target = torch.ones((), device=dev)
@@ -477,6 +581,8 @@ def run_workload(workload, args, dev, rank, world, profile):
            "config": {"workload": wl["name"], "global_batch": spg * world,
                       "parallelism": "dp%d" % world, "index_prefetch": prefetch is not None,
                       "trainable_params": sum(p.numel() for p in params)}}
+    if workload == "lc_img":
+        res["image_glue"] = image_glue_kernel_times(model, batch)
     res["roofline"] = roofline(prof, workload, marks) if prof else None
     if res["roofline"]:
         r = res["roofline"]
@@ -551,6 +657,7 @@ def main():
 
         leg("configs[1]", "transfusion_l", profile=not args.no_profile, cpu=not args.no_cpu_baseline)
         if os.environ.get("MSMD_BENCH_TAIL", "1") == "1":
+            leg("configs[2]+image glue", "lc_img")
             leg("configs[2]+f1", "lc_tail")
             leg("configs[2]+f1+f3", "lc_full")
             leg("configs[2] @ 4/GPU", "lc_b4")

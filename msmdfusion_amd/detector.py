@@ -227,12 +227,15 @@ class MSMDFusionDetector(TransFusionDetector):
     def virtual_points_from_images(self, img_feats, img_metas):
         """depth_aware_channel_compression + get_foreground2D per scale
         (MSMDFusion.py:400-407, 169-238) -> 4 lists of B [n, 15 + 49] tensors."""
-        from .image_glue import get_foreground2D, pack_foreground
+        from .image_glue import get_foreground2D, pack_foreground, raise_if_any_bad
         pack = pack_foreground(img_metas, img_feats[0].device)
-        comp = self._compress(img_feats, img_metas, pack=pack)
+        bad = []       # out-of-map pixel counters of the five kernels: ONE host read below
+        comp = self._compress(img_feats, img_metas, pack=pack, check=bad)
         per_scale = [comp[0]] + list(comp)               # img_feat_list[0] twice, :404-405
-        return [get_foreground2D(f, img_metas, self.score_net, pack=pack,
-                                 reference_quirks=self.reference_quirks) for f in per_scale[:4]]
+        out = [get_foreground2D(f, img_metas, self.score_net, pack=pack, check=bad,
+                                reference_quirks=self.reference_quirks) for f in per_scale[:4]]
+        raise_if_any_bad(bad)
+        return out
 
     # ---- the path ----------------------------------------------------------------------
     def prepare(self, points, virtual_points, nn_side_stream=True):

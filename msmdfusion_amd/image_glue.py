@@ -112,6 +112,19 @@ def pack_foreground(img_metas, device):
         sample_counts=counts, batch_size=B, cameras=cams)
 
 
+def raise_if_any_bad(collected):
+    """One host read for the out-of-map counters a whole batch collected (check=[] passed
+    to get_foreground2D / DepthAwareChannelCompression): the reference's IndexError, raised
+    once per batch instead of after every gather (five waits for the stream per step)."""
+    if not collected:
+        return
+    counts = torch.stack([b.reshape(()) for b, _ in collected]).tolist()
+    for n, (_, what) in zip(counts, collected):
+        if n:
+            raise IndexError("%s: %d pixel(s) fall outside the map (the reference's advanced "
+                             "indexing raises IndexError here too)" % (what, n))
+
+
 def _raise_if_bad(bad, what):
     n = int(bad.item())
     if n:
@@ -127,7 +140,9 @@ class _ForegroundGather(torch.autograd.Function):
     def forward(ctx, img_feat, pack, downscale, check):
         fg, sc, cells, bad = K.fg_gather(img_feat, pack.pixels, pack.plane, downscale,
                                          pack.points, pack.lidar2img, want_cells=True)
-        if check:
+        if isinstance(check, list):      # deferred: the caller reads all counters at once
+            check.append((bad, "get_foreground2D"))
+        elif check:
             _raise_if_bad(bad, "get_foreground2D")
         ctx.save_for_backward(cells)
         ctx.like = img_feat
@@ -177,7 +192,9 @@ def sparse_depth_canvas(img_metas, H, W, device, pack=None, check=True):
     if pack.real_pixels is None:
         return torch.zeros((planes, 1, H, W), dtype=torch.float32, device=device)
     canvas, bad = K.depth_canvas(pack.real_pixels, pack.real_plane, planes, H, W)
-    if check:
+    if isinstance(check, list):
+        check.append((bad, "depth_aware_channel_compression"))
+    elif check:
         _raise_if_bad(bad, "depth_aware_channel_compression")
     return canvas.view(planes, 1, H, W)
 

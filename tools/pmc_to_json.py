@@ -40,8 +40,8 @@ for name in sorted(agg):
     if e.get("TCC_REQ_sum"):
         e["l2_hit_rate"] = round(e.get("TCC_HIT_sum", 0.0) / e["TCC_REQ_sum"], 4)
     out[name] = e
-note = ("rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only) over `MSMD_PREFETCH=0 "
-        "python bench.py --workload %s --no-also --steps 3 --warmup 2 --no-cpu-baseline "
+note = ("rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only) over the default, "
+        "pipelined schedule: `python bench.py --workload %s --no-also --steps 3 --warmup 2 --no-cpu-baseline "
         "--no-profile`; values are means per launch.  " % workload +
         "FETCH_SIZE/WRITE_SIZE are in KiB as rocprofv3 reports them; hbm_bytes_per_launch applies "
         "the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 128-B requests as 64 B for "
