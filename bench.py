@@ -636,6 +636,8 @@ def main():
                         "device_schedule_flags": sched_flags},
                "config": head["config"],
                "roofline": head["roofline"]}
+        if "image_glue" in head:
+            out["image_glue"] = head["image_glue"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
     if world == 1 and not args.no_also and args.workload == "lc":

@@ -13,10 +13,10 @@ OUT=${2:-$R/gpurun_out/pmc_$WL}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT; mkdir -p $OUT
 i=0
-GROUPS=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES" \
+PMC_GROUPS=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES" \
         "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum")
-[ "${3:-}" = "all" ] && GROUPS+=("SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY")
-for grp in "${GROUPS[@]}"; do
+[ "${3:-}" = "all" ] && PMC_GROUPS+=("SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY")
+for grp in "${PMC_GROUPS[@]}"; do
   i=$((i+1))
   timeout 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -o s -- \
     env MSMD_BENCH_SETTLE_S=0.3 python $R/bench.py --workload $WL --no-also --steps 3 --warmup 2 \

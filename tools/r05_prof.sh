@@ -1,8 +1,7 @@
-# round 5 evidence: the new image-glue leg alone, rocprofv3 kernel stats + stream summary of the
-# LC line, PMC passes (HBM bytes, MFMA busy, L2) under the pipelined schedule.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05e; mkdir -p $O; cd $R
+# round 5 evidence: the image-glue leg alone, PMC passes (HBM bytes, MFMA busy, L2) under the
+# pipelined schedule.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05f; mkdir -p $O; cd $R
 timeout 400 python bench.py --workload lc_img --no-also --no-cpu-baseline > $O/bench_lc_img.json 2> $O/bench_lc_img.err
-tail -c 1500 $O/bench_lc_img.json; tail -5 $O/bench_lc_img.err
-bash tools/prof_bench.sh r05e lc > $O/prof.log 2>&1
+tail -c 1200 $O/bench_lc_img.json; tail -5 $O/bench_lc_img.err
 bash tools/pmc_collect.sh lc $O/pmc_lc > $O/pmc.log 2>&1
-tail -3 $O/prof.log $O/pmc.log
+tail -3 $O/pmc.log
