@@ -835,11 +835,15 @@ def test_split_conv_bf16_operands(dev):
     assert (out - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
 
 
-def test_split_conv_under_cu_contention(dev):
+@pytest.mark.parametrize("c", [64, 192])
+def test_split_conv_under_cu_contention(dev, c):
     """The persistent kernels' tile counter must be back at 0 after every launch
     even when workgroups become resident late because another stream holds the
     CUs (wgrad on its side stream, RCCL under DDP): a late workgroup can draw the
-    launch's last ticket with its very first draw."""
+    launch's last ticket with its very first draw.  c = 192: the ping-pong kernel, whose
+    weight buffers are guarded by COUNTED waits (LDS-DMA pieces waited for with the row
+    gathers still in flight) -- bit-identical results while another stream's GEMMs compete
+    for the memory system is what shows that those waits cover what they must."""
     from msmdfusion_amd import kernels as K
     shape = [21, 128, 128]
     idx = S.random_voxel_indices(40000, 2, shape, seed=3)
@@ -847,9 +851,9 @@ def test_split_conv_under_cu_contention(dev):
     nbr = K.rulebook_subm(t(idx, dev), 2, shape, 3)
     order = K.row_mask_order(nbr)
     nbr_t = K.permute_cols(nbr, order)
-    f = torch.randn(n, 64, device=dev)
-    ws = K.pack_weight_split(torch.randn(27, 64, 64, device=dev) * 0.05, 3)
-    ref = K.conv_forward_split(f, ws, nbr_t, n, 64, 3, row_order=order)
+    f = torch.randn(n, c, device=dev)
+    ws = K.pack_weight_split(torch.randn(27, c, c, device=dev) * 0.05, 3)
+    ref = K.conv_forward_split(f, ws, nbr_t, n, c, 3, row_order=order)
     torch.cuda.synchronize()
     hog = torch.cuda.Stream()
     a = torch.randn(8192, 8192, device=dev)
@@ -857,7 +861,7 @@ def test_split_conv_under_cu_contention(dev):
         with torch.cuda.stream(hog):
             for _ in range(4):
                 a = torch.mm(a, a) * 1e-4        # chip-filling GEMMs on the other stream
-        outs = [K.conv_forward_split(f, ws, nbr_t, n, 64, 3, row_order=order) for _ in range(4)]
+        outs = [K.conv_forward_split(f, ws, nbr_t, n, c, 3, row_order=order) for _ in range(4)]
         for o in outs:
             assert torch.equal(o, ref)
         assert int(K._tile_counter(f.device).abs().sum().item()) == 0    # counter and flags
@@ -865,15 +869,15 @@ def test_split_conv_under_cu_contention(dev):
     # the same under stream-K scheduling: an owner waits only for lower tickets, which are
     # resident by construction -- late workgroups cannot deadlock it, and the counter and
     # every exchange flag are back at 0 after each launch
-    pre = K.tile_prefix(nbr_t, K.split_tile_rows(64))
-    ref_k = K.conv_forward_split(f, ws, nbr_t, n, 64, 3, row_order=order, tile_prefix=pre)
+    pre = K.tile_prefix(nbr_t, K.split_tile_rows(c))
+    ref_k = K.conv_forward_split(f, ws, nbr_t, n, c, 3, row_order=order, tile_prefix=pre)
     assert (ref_k - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
     torch.cuda.synchronize()
     for rep in range(6):
         with torch.cuda.stream(hog):
             for _ in range(4):
                 a = torch.mm(a, a) * 1e-4
-        outs = [K.conv_forward_split(f, ws, nbr_t, n, 64, 3, row_order=order, tile_prefix=pre)
+        outs = [K.conv_forward_split(f, ws, nbr_t, n, c, 3, row_order=order, tile_prefix=pre)
                 for _ in range(4)]
         for o in outs:
             assert torch.equal(o, ref_k)
