@@ -376,7 +376,16 @@ inline int sk_c1() { return kSkC1Default; }
 // for the 12-tile instantiation, whose three 36 KiB weight buffers leave room for one table
 // only -- the next slice is staged at the tile switch (one exposed load per tile of ~100+
 // items).
-template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false, int TB = 2>
+// ILV (ping-pong form only): the load segment's vector-memory instructions are issued BETWEEN
+// the quarters of the conversion instead of in one burst in front of it.  The four waves of
+// a group reach their load segment together (a barrier released them) and a CU's
+// vector-memory path takes a 1-KiB wave instruction every ~32 cycles: 28-36 of them in a
+// burst are ~1000 cycles of issue stall per wave, during which the wave's 88 conversion VALU
+// instructions wait behind them in program order.  The unit's rows were gathered a whole
+// item ago, so the wait for them moves to the segment's top (nothing else is outstanding
+// there: vmcnt(0)) and every memory instruction gets ~100 cycles of conversion behind it.
+template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false, int TB = 2,
+          bool ILV = false>
 __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_kernel(
     const float* __restrict__ in, int n_in, int cin, const u32x4* __restrict__ wp,
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
@@ -637,6 +646,29 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
         MSMD_ADV(mw, kbw);
       }
     };
+    // (the same, one instruction at a time: the interleaved load segment)
+    auto issue_w_piece = [&](int it, int pp) {
+      u32x4* wb = wl + (NB == 2 ? (it & 1) : it % NB) * kWU;
+      const int k = mw ? __builtin_ctz(mw) : 0;
+      const int kw = flip ? kvol - 1 - k : k;
+      const u32x4* g = wp + ((size_t)kw * kbt + kbw) * (NP * nt_total * 64);
+      int piece = wave + WV * pp;
+      if ((NP * NT) % WV != 0 && piece >= NP * NT) piece = 0;
+      const int pl = piece / NT;
+      int tile = mt0 + piece - pl * NT;
+      tile = tile < nt_total ? tile : nt_total - 1;
+      __builtin_amdgcn_global_load_lds((glb_void*)(g + (pl * nt_total + tile) * 64 + lane),
+                                       (lds_void*)(wb + piece * 64), 16, 0, 0);
+    };
+    auto issue_g_row = [&](u32x4 (&raw)[2], int r, int& valid) {
+      const int chan0 = kbg * 32 + q * 8;
+      const unsigned col = (unsigned)chan0 * 4u;
+      const int src = s_next[r];
+      valid = src > valid ? src : valid;
+      const unsigned rowb = __umul24((unsigned)((dbg & 8) ? (src & 4095) : src), row_bytes) + col;
+      const unsigned off = (src < 0 || chan0 >= cin || (dbg & 2)) ? kOobOffset : rowb;
+      gather_row8(raw, off, rs);
+    };
     auto split_all = [&](const u32x4 (&raw)[R][2], u32x4 (&cv)[R][NP]) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -724,40 +756,33 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
       auto multiply = [&](int it, const u32x4 (&b)[R][NP], int valid) {
         if (!__any(valid >= 0) || (dbg & 4)) return;
         const u32x4* wb = wl + (it % NB) * kWU + lane;
-        u32x4 a[2][2][NP];
+        // fragments double-buffered per 16-channel TILE (12 registers a buffer; per PAIR of
+        // tiles, as the 4-wave kernel does, costs 24 more and spills the 12-tile instantiation):
+        // the next tile's three 16-byte reads are requested after the first third of this
+        // tile's MFMAs and have the other two thirds (128 cycles) to land
+        u32x4 a[2][NP];
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-          for (int p = 0; p < NP; ++p) a[0][nn][p] = wb[(p * NT + nn) * 64];
+        for (int p = 0; p < NP; ++p) a[0][p] = wb[(p * NT) * 64];
         constexpr int kHead = P::n >= 3 ? P::n / 3 : 0;
 #pragma unroll
-        for (int st = 0; st < NS; ++st) {
+        for (int n = 0; n < NT; ++n) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int t = 0; t < kHead; ++t)
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-              for (int r = 0; r < R; ++r)
-                acc[r][2 * st + nn] =
-                    mfma_bf16(a[st & 1][nn][P::a[t]], b[r][P::b[t]], acc[r][2 * st + nn]);
+            for (int r = 0; r < R; ++r)
+              acc[r][n] = mfma_bf16(a[n & 1][P::a[t]], b[r][P::b[t]], acc[r][n]);
           __builtin_amdgcn_sched_barrier(0);
-          if (st + 1 < NS) {
+          if (n + 1 < NT) {
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-              for (int p = 0; p < NP; ++p)
-                a[(st + 1) & 1][nn][p] = wb[(p * NT + 2 * (st + 1) + nn) * 64];
+            for (int p = 0; p < NP; ++p) a[(n + 1) & 1][p] = wb[(p * NT + n + 1) * 64];
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int t = kHead; t < P::n; ++t)
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-              for (int r = 0; r < R; ++r)
-                acc[r][2 * st + nn] =
-                    mfma_bf16(a[st & 1][nn][P::a[t]], b[r][P::b[t]], acc[r][2 * st + nn]);
+            for (int r = 0; r < R; ++r)
+              acc[r][n] = mfma_bf16(a[n & 1][P::a[t]], b[r][P::b[t]], acc[r][n]);
         }
         __builtin_amdgcn_sched_barrier(0);
       };
@@ -779,6 +804,31 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
       // Queue at the counted wait (oldest first): rows(g) [4] | weights(g+1) [kPw] | rows(g+1)
       // [4]: "all but the newest kPw + 4" = rows(g); after the MFMAs "all but the newest 4"
       // = this wave's pieces of weights(g+1), a multiply segment after their issue.
+      // The interleaved load segment: the kPw weight pieces and the R row gathers, with the
+      // conversion of one row group (2 x 22 VALU instructions) behind every second memory
+      // instruction.  Each converted row is pinned by an empty asm on its plane registers:
+      // scheduling barriers alone do not hold pure VALU work in place -- the optimiser moves it
+      // behind the last memory instruction (and, unpinned, past the barrier into multiply()).
+      auto load_segment_ilv = [&](int g1, const u32x4 (&raw_c)[R][2], u32x4 (&raw_n)[R][2],
+                                  int& v_n) {
+        constexpr int kOps = kPw + R;
+        constexpr int kStride = kOps / R > 0 ? kOps / R : 1;   // memory instructions per row
+        v_n = -1;
+#pragma unroll
+        for (int i = 0; i < kOps; ++i) {
+          if (i < kPw) issue_w_piece(g1, i);
+          else issue_g_row(raw_n[i - kPw], i - kPw, v_n);
+          if ((i + 1) % kStride == 0 && (i + 1) / kStride <= R) {
+            const int r = (i + 1) / kStride - 1;
+            split_quarter<NP>(raw_c[r][0], 0, cv[r]);
+            split_quarter<NP>(raw_c[r][1], 1, cv[r]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(cv[r][p]));
+          }
+        }
+        MSMD_ADV(mw, kbw);
+        MSMD_ADV(mg, kbg);
+      };
 #define MSMD_PP_ITEM(G, RAW_C, V_C, RAW_N, V_N)                                          \
   {                                                                                     \
     if ((G) == 0 && tid == 0) {                                                         \
@@ -792,19 +842,27 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
       staged = true;                                                                    \
     }                                                                                   \
     KP_MARK(6);                                                                         \
-    issue_w((G) + 1);                                                                   \
-    KP_MARK(2);                                                                         \
-    issue_g(RAW_N, V_N);                                                                \
-    load_src();                                                                         \
-    KP_MARK(3);                                                                         \
-    wait_rows<kGr + kWp>(RAW_C);                                                        \
-    KP_MARK(4);                                                                         \
-    split_all(RAW_C, cv);                                                               \
+    if constexpr (ILV) {                                                                \
+      wait_rows<0>(RAW_C);      /* rows(g): the only ops outstanding (+ the table slice) */ \
+      KP_MARK(4);                                                                       \
+      load_segment_ilv((G) + 1, RAW_C, RAW_N, V_N);                                     \
+      load_src();                                                                       \
+      KP_MARK(8);                                                                       \
+    } else {                                                                            \
+      issue_w((G) + 1);                                                                 \
+      KP_MARK(2);                                                                       \
+      issue_g(RAW_N, V_N);                                                              \
+      load_src();                                                                       \
+      KP_MARK(3);                                                                       \
+      wait_rows<kGr + kWp>(RAW_C);                                                      \
+      KP_MARK(4);                                                                       \
+      split_all(RAW_C, cv);                                                             \
+    }                                                                                   \
     /* (the conversion belongs to THIS segment: left alone the optimiser sinks it below \
        the barrier into multiply()'s branch, where it competes with the MFMAs) */       \
     pin_planes(cv);                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                  \
-    KP_MARK(8);                                                                         \
+    if constexpr (!ILV) KP_MARK(8);                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
     __builtin_amdgcn_s_barrier();                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                  \
@@ -1085,7 +1143,8 @@ int reserved_cus() {
   return n;
 }
 
-template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false, int TB = 2>
+template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false, int TB = 2,
+          bool ILV = false>
 int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                      int ld, int n_out, int kvol, int flip, const int32_t* order,
                      int* tile_counter, float* out, int ldo, int cout, int nt_total, int mt0,
@@ -1106,7 +1165,7 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   if (nblk > slots) nblk = slots;
   // stream-K: sk_grid ranges for (at most) one workgroup per slot
   if (tile_start) nblk = sk_grid < slots ? sk_grid : slots;
-  auto kern = spconv_fwd_split_kernel<NT, UB, NP, WV, NB, PP, TB>;
+  auto kern = spconv_fwd_split_kernel<NT, UB, NP, WV, NB, PP, TB, ILV>;
   static LdsGrant granted;  // per instantiation
   const int lds_rc = optin_dynamic_lds((const void*)kern, smem, granted);
   if (lds_rc != MSMD_OK) return lds_rc;
@@ -1215,22 +1274,27 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
                                                      flip, order, tile_counter, o, cout, width,  \
                                                      nt_total, mt0, ws, flags, tile_start,       \
                                                      sk_grid, bn_part, st)
-#define MSMD_GO12()                                                                              \
-  rc = launch_fwd_split<12, 1, NP, 8, 3, true, 1>(in, n_in, cin, wp, nbr, ld, n_out, kvol, flip, \
-                                                  order, tile_counter, o, cout, width, nt_total, \
-                                                  mt0, ws, flags, tile_start, sk_grid, bn_part,  \
-                                                  st)
-    if (waves == 8) {          // ping-pong; a short last pass computes (and drops) spare tiles
-      if (tiles > 8) { MSMD_GO12(); }
-      else if (tiles > 6) { MSMD_GO(8, 1, 8, 3, true); }
-      else { MSMD_GO(6, 1, 8, 3, true); }
+#define MSMD_GOPP(NT_, TB_, ILV_)                                                                \
+  rc = launch_fwd_split<NT_, 1, NP, 8, 3, true, TB_, ILV_>(in, n_in, cin, wp, nbr, ld, n_out,    \
+                                                           kvol, flip, order, tile_counter, o,   \
+                                                           cout, width, nt_total, mt0, ws, flags, \
+                                                           tile_start, sk_grid, bn_part, st)
+    static const int ilv = env_int2("MSMD_FWD_ILV", 1);
+    if (waves == 8 && ilv) {   // ping-pong; a short last pass computes (and drops) spare tiles
+      if (tiles > 8) { MSMD_GOPP(12, 1, true); }
+      else if (tiles > 6) { MSMD_GOPP(8, 2, true); }
+      else { MSMD_GOPP(6, 2, true); }
+    } else if (waves == 8) {
+      if (tiles > 8) { MSMD_GOPP(12, 1, false); }
+      else if (tiles > 6) { MSMD_GOPP(8, 2, false); }
+      else { MSMD_GOPP(6, 2, false); }
     }
     else if (tiles > 6) { MSMD_GO(8, 1, 4, 2, false); }
     else if (tiles > 4) { MSMD_GO(6, 1, 4, 2, false); }
     else if (tiles > 2) { MSMD_GO(4, 2, 4, 2, false); }
     else { MSMD_GO(2, 4, 4, 2, false); }
 #undef MSMD_GO
-#undef MSMD_GO12
+#undef MSMD_GOPP
     if (rc != MSMD_OK) return rc;
   }
   return MSMD_OK;
