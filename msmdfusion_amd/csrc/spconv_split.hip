@@ -376,14 +376,17 @@ inline int sk_c1() { return kSkC1Default; }
 // for the 12-tile instantiation, whose three 36 KiB weight buffers leave room for one table
 // only -- the next slice is staged at the tile switch (one exposed load per tile of ~100+
 // items).
-// ILV (ping-pong form only): the load segment's vector-memory instructions are issued BETWEEN
-// the quarters of the conversion instead of in one burst in front of it.  The four waves of
-// a group reach their load segment together (a barrier released them) and a CU's
-// vector-memory path takes a 1-KiB wave instruction every ~32 cycles: 28-36 of them in a
-// burst are ~1000 cycles of issue stall per wave, during which the wave's 88 conversion VALU
-// instructions wait behind them in program order.  The unit's rows were gathered a whole
-// item ago, so the wait for them moves to the segment's top (nothing else is outstanding
-// there: vmcnt(0)) and every memory instruction gets ~100 cycles of conversion behind it.
+// ILV (ping-pong form only): rows gathered TWO units ahead, and the weight DMA interleaved
+// with the conversion.  Measured with the one-unit-ahead schedule: a unit's rows, gathered a
+// whole multiply segment (~1800-2400 cycles) before they are needed, are still waited for --
+// 760-820 cycles at the top of the load segment when nothing else is in the way
+// (profiles/r05_fwd_kprof.txt): under this kernel's own load a gathered row takes ~2600 cycles
+// to arrive.  So unit g's rows are converted FIRST in load segment g (they were requested in
+// segment g-2: no wait), each row group's conversion behind one or two of the segment's weight
+// DMA pieces (whose issue stalls it hides), and the registers just freed are refilled with
+// the gathers of unit g+2 -- the two-buffer ring serves a distance of two, no third buffer.
+// Queue (oldest first) when the multiply segment ends: rows(g+1) | weights(g+1) | rows(g+2):
+// "all but the newest 4" = this wave's weight pieces landed (and rows(g+1) with them).
 template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false, int TB = 2,
           bool ILV = false>
 __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_kernel(
@@ -798,35 +801,38 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
       load_src();
       issue_g(raw0, vr0);
       load_src();
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGr) : "memory");
+      if constexpr (ILV) {      // rows two units ahead: unit 1 too, and the indices of unit 2
+        issue_g(raw1, vr1);
+        load_src();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kGr) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGr) : "memory");
+      }
       if (grp_b) __builtin_amdgcn_s_barrier();      // group B runs one segment behind
       // One item: LOAD segment | barrier | MULTIPLY segment | barrier.
       // Queue at the counted wait (oldest first): rows(g) [4] | weights(g+1) [kPw] | rows(g+1)
       // [4]: "all but the newest kPw + 4" = rows(g); after the MFMAs "all but the newest 4"
       // = this wave's pieces of weights(g+1), a multiply segment after their issue.
-      // The interleaved load segment: the kPw weight pieces and the R row gathers, with the
-      // conversion of one row group (2 x 22 VALU instructions) behind every second memory
-      // instruction.  Each converted row is pinned by an empty asm on its plane registers:
-      // scheduling barriers alone do not hold pure VALU work in place -- the optimiser moves it
-      // behind the last memory instruction (and, unpinned, past the barrier into multiply()).
-      auto load_segment_ilv = [&](int g1, const u32x4 (&raw_c)[R][2], u32x4 (&raw_n)[R][2],
-                                  int& v_n) {
-        constexpr int kOps = kPw + R;
-        constexpr int kStride = kOps / R > 0 ? kOps / R : 1;   // memory instructions per row
-        v_n = -1;
+      // The interleaved load segment (ILV): conversion of unit g's row groups, each behind its
+      // share of the weight DMA pieces of item g+1, then the gathers of unit g+2 into the
+      // registers the conversion has just freed.  Each converted row is pinned by an empty asm
+      // on its plane registers: scheduling barriers alone do not hold pure VALU work in place
+      // -- the optimiser moves it behind the last memory instruction (and, unpinned, past the
+      // barrier into multiply()).
+      auto load_segment_ilv = [&](int g1, u32x4 (&raw_c)[R][2], int& v_c) {
 #pragma unroll
-        for (int i = 0; i < kOps; ++i) {
-          if (i < kPw) issue_w_piece(g1, i);
-          else issue_g_row(raw_n[i - kPw], i - kPw, v_n);
-          if ((i + 1) % kStride == 0 && (i + 1) / kStride <= R) {
-            const int r = (i + 1) / kStride - 1;
-            split_quarter<NP>(raw_c[r][0], 0, cv[r]);
-            split_quarter<NP>(raw_c[r][1], 1, cv[r]);
+        for (int r = 0; r < R; ++r) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(cv[r][p]));
-          }
+          for (int pp = r * kPw / R; pp < (r + 1) * kPw / R; ++pp) issue_w_piece(g1, pp);
+          split_quarter<NP>(raw_c[r][0], 0, cv[r]);
+          split_quarter<NP>(raw_c[r][1], 1, cv[r]);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(cv[r][p]));
         }
         MSMD_ADV(mw, kbw);
+        v_c = -1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) issue_g_row(raw_c[r], r, v_c);    // unit g + 2
         MSMD_ADV(mg, kbg);
       };
 #define MSMD_PP_ITEM(G, RAW_C, V_C, RAW_N, V_N)                                          \
@@ -842,10 +848,12 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
       staged = true;                                                                    \
     }                                                                                   \
     KP_MARK(6);                                                                         \
+    const int v_cur = V_C;                                                              \
     if constexpr (ILV) {                                                                \
-      wait_rows<0>(RAW_C);      /* rows(g): the only ops outstanding (+ the table slice) */ \
+      wait_rows<kGr>(RAW_C);    /* rows(g): all but the newest 4 = rows(g+1) (a no-op    \
+                                   after the first item: the multiply segment's wait) */ \
       KP_MARK(4);                                                                       \
-      load_segment_ilv((G) + 1, RAW_C, RAW_N, V_N);                                     \
+      load_segment_ilv((G) + 1, RAW_C, V_C);                                            \
       load_src();                                                                       \
       KP_MARK(8);                                                                       \
     } else {                                                                            \
@@ -868,7 +876,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
     __builtin_amdgcn_sched_barrier(0);                                                  \
     KP_MARK(1);                                                                         \
     if (dbg & 32) __builtin_amdgcn_s_setprio(1);                                        \
-    multiply((G), cv, V_C);                                                             \
+    multiply((G), cv, v_cur);                                                           \
     if (dbg & 32) __builtin_amdgcn_s_setprio(0);                                        \
     KP_MARK(5);                                                                         \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGr) : "memory");                          \

@@ -1,5 +1,5 @@
 # round 5: interleaved load segment of the ping-pong kernel (MSMD_FWD_ILV) -- tests, layer A/B, LC A/B
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_ilv; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_ilv2; mkdir -p $O; cd $R
 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_production.py -q 2>&1 | tail -6 > $O/tests.log
 for ilv in 1 0; do
   MSMD_FWD_ILV=$ilv MSMD_FWD_PP_MIN=97 python tools/split_bench.py --lc --check > $O/layers_lc_ilv$ilv.txt 2>&1
