@@ -376,19 +376,7 @@ inline int sk_c1() { return kSkC1Default; }
 // for the 12-tile instantiation, whose three 36 KiB weight buffers leave room for one table
 // only -- the next slice is staged at the tile switch (one exposed load per tile of ~100+
 // items).
-// ILV (ping-pong form only): rows gathered TWO units ahead, and the weight DMA interleaved
-// with the conversion.  Measured with the one-unit-ahead schedule: a unit's rows, gathered a
-// whole multiply segment (~1800-2400 cycles) before they are needed, are still waited for --
-// 760-820 cycles at the top of the load segment when nothing else is in the way
-// (profiles/r05_fwd_kprof.txt): under this kernel's own load a gathered row takes ~2600 cycles
-// to arrive.  So unit g's rows are converted FIRST in load segment g (they were requested in
-// segment g-2: no wait), each row group's conversion behind one or two of the segment's weight
-// DMA pieces (whose issue stalls it hides), and the registers just freed are refilled with
-// the gathers of unit g+2 -- the two-buffer ring serves a distance of two, no third buffer.
-// Queue (oldest first) when the multiply segment ends: rows(g+1) | weights(g+1) | rows(g+2):
-// "all but the newest 4" = this wave's weight pieces landed (and rows(g+1) with them).
-template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false, int TB = 2,
-          bool ILV = false>
+template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false, int TB = 2>
 __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_kernel(
     const float* __restrict__ in, int n_in, int cin, const u32x4* __restrict__ wp,
     const int32_t* __restrict__ nbr, int ld, int n_out, int kvol, int flip,
@@ -649,29 +637,6 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
         MSMD_ADV(mw, kbw);
       }
     };
-    // (the same, one instruction at a time: the interleaved load segment)
-    auto issue_w_piece = [&](int it, int pp) {
-      u32x4* wb = wl + (NB == 2 ? (it & 1) : it % NB) * kWU;
-      const int k = mw ? __builtin_ctz(mw) : 0;
-      const int kw = flip ? kvol - 1 - k : k;
-      const u32x4* g = wp + ((size_t)kw * kbt + kbw) * (NP * nt_total * 64);
-      int piece = wave + WV * pp;
-      if ((NP * NT) % WV != 0 && piece >= NP * NT) piece = 0;
-      const int pl = piece / NT;
-      int tile = mt0 + piece - pl * NT;
-      tile = tile < nt_total ? tile : nt_total - 1;
-      __builtin_amdgcn_global_load_lds((glb_void*)(g + (pl * nt_total + tile) * 64 + lane),
-                                       (lds_void*)(wb + piece * 64), 16, 0, 0);
-    };
-    auto issue_g_row = [&](u32x4 (&raw)[2], int r, int& valid) {
-      const int chan0 = kbg * 32 + q * 8;
-      const unsigned col = (unsigned)chan0 * 4u;
-      const int src = s_next[r];
-      valid = src > valid ? src : valid;
-      const unsigned rowb = __umul24((unsigned)((dbg & 8) ? (src & 4095) : src), row_bytes) + col;
-      const unsigned off = (src < 0 || chan0 >= cin || (dbg & 2)) ? kOobOffset : rowb;
-      gather_row8(raw, off, rs);
-    };
     auto split_all = [&](const u32x4 (&raw)[R][2], u32x4 (&cv)[R][NP]) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -801,40 +766,12 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
       load_src();
       issue_g(raw0, vr0);
       load_src();
-      if constexpr (ILV) {      // rows two units ahead: unit 1 too, and the indices of unit 2
-        issue_g(raw1, vr1);
-        load_src();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kGr) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGr) : "memory");
-      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGr) : "memory");
       if (grp_b) __builtin_amdgcn_s_barrier();      // group B runs one segment behind
       // One item: LOAD segment | barrier | MULTIPLY segment | barrier.
       // Queue at the counted wait (oldest first): rows(g) [4] | weights(g+1) [kPw] | rows(g+1)
       // [4]: "all but the newest kPw + 4" = rows(g); after the MFMAs "all but the newest 4"
       // = this wave's pieces of weights(g+1), a multiply segment after their issue.
-      // The interleaved load segment (ILV): conversion of unit g's row groups, each behind its
-      // share of the weight DMA pieces of item g+1, then the gathers of unit g+2 into the
-      // registers the conversion has just freed.  Each converted row is pinned by an empty asm
-      // on its plane registers: scheduling barriers alone do not hold pure VALU work in place
-      // -- the optimiser moves it behind the last memory instruction (and, unpinned, past the
-      // barrier into multiply()).
-      auto load_segment_ilv = [&](int g1, u32x4 (&raw_c)[R][2], int& v_c) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-#pragma unroll
-          for (int pp = r * kPw / R; pp < (r + 1) * kPw / R; ++pp) issue_w_piece(g1, pp);
-          split_quarter<NP>(raw_c[r][0], 0, cv[r]);
-          split_quarter<NP>(raw_c[r][1], 1, cv[r]);
-#pragma unroll
-          for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(cv[r][p]));
-        }
-        MSMD_ADV(mw, kbw);
-        v_c = -1;
-#pragma unroll
-        for (int r = 0; r < R; ++r) issue_g_row(raw_c[r], r, v_c);    // unit g + 2
-        MSMD_ADV(mg, kbg);
-      };
 #define MSMD_PP_ITEM(G, RAW_C, V_C, RAW_N, V_N)                                          \
   {                                                                                     \
     if ((G) == 0 && tid == 0) {                                                         \
@@ -848,35 +785,25 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
       staged = true;                                                                    \
     }                                                                                   \
     KP_MARK(6);                                                                         \
-    const int v_cur = V_C;                                                              \
-    if constexpr (ILV) {                                                                \
-      wait_rows<kGr>(RAW_C);    /* rows(g): all but the newest 4 = rows(g+1) (a no-op    \
-                                   after the first item: the multiply segment's wait) */ \
-      KP_MARK(4);                                                                       \
-      load_segment_ilv((G) + 1, RAW_C, V_C);                                            \
-      load_src();                                                                       \
-      KP_MARK(8);                                                                       \
-    } else {                                                                            \
-      issue_w((G) + 1);                                                                 \
-      KP_MARK(2);                                                                       \
-      issue_g(RAW_N, V_N);                                                              \
-      load_src();                                                                       \
-      KP_MARK(3);                                                                       \
-      wait_rows<kGr + kWp>(RAW_C);                                                      \
-      KP_MARK(4);                                                                       \
-      split_all(RAW_C, cv);                                                             \
-    }                                                                                   \
+    issue_w((G) + 1);                                                                   \
+    KP_MARK(2);                                                                         \
+    issue_g(RAW_N, V_N);                                                                \
+    load_src();                                                                         \
+    KP_MARK(3);                                                                         \
+    wait_rows<kGr + kWp>(RAW_C);                                                        \
+    KP_MARK(4);                                                                         \
+    split_all(RAW_C, cv);                                                               \
     /* (the conversion belongs to THIS segment: left alone the optimiser sinks it below \
        the barrier into multiply()'s branch, where it competes with the MFMAs) */       \
     pin_planes(cv);                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                  \
-    if constexpr (!ILV) KP_MARK(8);                                                     \
+    KP_MARK(8);                                                                         \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
     __builtin_amdgcn_s_barrier();                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                  \
     KP_MARK(1);                                                                         \
     if (dbg & 32) __builtin_amdgcn_s_setprio(1);                                        \
-    multiply((G), cv, v_cur);                                                           \
+    multiply((G), cv, V_C);                                                             \
     if (dbg & 32) __builtin_amdgcn_s_setprio(0);                                        \
     KP_MARK(5);                                                                         \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGr) : "memory");                          \
@@ -1151,8 +1078,7 @@ int reserved_cus() {
   return n;
 }
 
-template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false, int TB = 2,
-          bool ILV = false>
+template <int NT, int UB, int NP, int WV, int NB = 2, bool PP = false, int TB = 2>
 int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const int32_t* nbr,
                      int ld, int n_out, int kvol, int flip, const int32_t* order,
                      int* tile_counter, float* out, int ldo, int cout, int nt_total, int mt0,
@@ -1173,7 +1099,7 @@ int launch_fwd_split(const float* in, int n_in, int cin, const void* wp, const i
   if (nblk > slots) nblk = slots;
   // stream-K: sk_grid ranges for (at most) one workgroup per slot
   if (tile_start) nblk = sk_grid < slots ? sk_grid : slots;
-  auto kern = spconv_fwd_split_kernel<NT, UB, NP, WV, NB, PP, TB, ILV>;
+  auto kern = spconv_fwd_split_kernel<NT, UB, NP, WV, NB, PP, TB>;
   static LdsGrant granted;  // per instantiation
   const int lds_rc = optin_dynamic_lds((const void*)kern, smem, granted);
   if (lds_rc != MSMD_OK) return lds_rc;
@@ -1282,20 +1208,15 @@ int dispatch_fwd_split(const float* in, int n_in, int cin, const void* wp, const
                                                      flip, order, tile_counter, o, cout, width,  \
                                                      nt_total, mt0, ws, flags, tile_start,       \
                                                      sk_grid, bn_part, st)
-#define MSMD_GOPP(NT_, TB_, ILV_)                                                                \
-  rc = launch_fwd_split<NT_, 1, NP, 8, 3, true, TB_, ILV_>(in, n_in, cin, wp, nbr, ld, n_out,    \
-                                                           kvol, flip, order, tile_counter, o,   \
-                                                           cout, width, nt_total, mt0, ws, flags, \
-                                                           tile_start, sk_grid, bn_part, st)
-    static const int ilv = env_int2("MSMD_FWD_ILV", 1);
-    if (waves == 8 && ilv) {   // ping-pong; a short last pass computes (and drops) spare tiles
-      if (tiles > 8) { MSMD_GOPP(12, 1, true); }
-      else if (tiles > 6) { MSMD_GOPP(8, 2, true); }
-      else { MSMD_GOPP(6, 2, true); }
-    } else if (waves == 8) {
-      if (tiles > 8) { MSMD_GOPP(12, 1, false); }
-      else if (tiles > 6) { MSMD_GOPP(8, 2, false); }
-      else { MSMD_GOPP(6, 2, false); }
+#define MSMD_GOPP(NT_, TB_)                                                                      \
+  rc = launch_fwd_split<NT_, 1, NP, 8, 3, true, TB_>(in, n_in, cin, wp, nbr, ld, n_out, kvol,    \
+                                                     flip, order, tile_counter, o, cout, width,  \
+                                                     nt_total, mt0, ws, flags, tile_start,       \
+                                                     sk_grid, bn_part, st)
+    if (waves == 8) {          // ping-pong; a short last pass computes (and drops) spare tiles
+      if (tiles > 8) { MSMD_GOPP(12, 1); }
+      else if (tiles > 6) { MSMD_GOPP(8, 2); }
+      else { MSMD_GOPP(6, 2); }
     }
     else if (tiles > 6) { MSMD_GO(8, 1, 4, 2, false); }
     else if (tiles > 4) { MSMD_GO(6, 1, 4, 2, false); }
