@@ -637,6 +637,25 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
         MSMD_ADV(mw, kbw);
       }
     };
+    // pieces [p0, p1) of the weight image of item `it` (UB == 1; the cursor moves with the
+    // last piece): the ping-pong form may issue some of them from the multiply segment
+    auto issue_w_part = [&](int it, int p0, int p1) {
+      u32x4* wb = wl + (NB == 2 ? (it & 1) : it % NB) * kWU;
+      const int k = mw ? __builtin_ctz(mw) : 0;
+      const int kw = flip ? kvol - 1 - k : k;
+      const u32x4* g = wp + ((size_t)kw * kbt + kbw) * (NP * nt_total * 64);
+#pragma unroll
+      for (int pp = p0; pp < p1; ++pp) {
+        int piece = wave + WV * pp;
+        if ((NP * NT) % WV != 0 && piece >= NP * NT) piece = 0;
+        const int pl = piece / NT;
+        int tile = mt0 + piece - pl * NT;
+        tile = tile < nt_total ? tile : nt_total - 1;
+        __builtin_amdgcn_global_load_lds((glb_void*)(g + (pl * nt_total + tile) * 64 + lane),
+                                         (lds_void*)(wb + piece * 64), 16, 0, 0);
+      }
+      if (p1 == kPw) MSMD_ADV(mw, kbw);
+    };
     auto split_all = [&](const u32x4 (&raw)[R][2], u32x4 (&cv)[R][NP]) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -754,6 +773,14 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
         }
         __builtin_amdgcn_sched_barrier(0);
       };
+      // kWM of an item's kPw weight DMA pieces are issued at the head of the MULTIPLY segment
+      // instead of in the load segment (experiment: -DMSMD_PP_WM=n): the load segment is the
+      // longer one for 6 and 8 column tiles.  The pieces then are the newest operations when
+      // the segment ends: its wait drains the queue.
+#ifndef MSMD_PP_WM
+#define MSMD_PP_WM 0
+#endif
+      constexpr int kWM = (MSMD_PP_WM) < kPw ? (MSMD_PP_WM) : kPw - 1;
       auto pin_planes = [&](u32x4 (&c)[R][NP]) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -785,12 +812,12 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
       staged = true;                                                                    \
     }                                                                                   \
     KP_MARK(6);                                                                         \
-    issue_w((G) + 1);                                                                   \
+    issue_w_part((G) + 1, 0, kPw - kWM);                                                \
     KP_MARK(2);                                                                         \
     issue_g(RAW_N, V_N);                                                                \
     load_src();                                                                         \
     KP_MARK(3);                                                                         \
-    wait_rows<kGr + kWp>(RAW_C);                                                        \
+    wait_rows<kGr + kPw - kWM>(RAW_C);                                                  \
     KP_MARK(4);                                                                         \
     split_all(RAW_C, cv);                                                               \
     /* (the conversion belongs to THIS segment: left alone the optimiser sinks it below \
@@ -802,11 +829,12 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void spconv_fwd_split_ker
     __builtin_amdgcn_s_barrier();                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                  \
     KP_MARK(1);                                                                         \
+    if (kWM > 0) issue_w_part((G) + 1, kPw - kWM, kPw);                                 \
     if (dbg & 32) __builtin_amdgcn_s_setprio(1);                                        \
     multiply((G), cv, V_C);                                                             \
     if (dbg & 32) __builtin_amdgcn_s_setprio(0);                                        \
     KP_MARK(5);                                                                         \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGr) : "memory");                          \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWM > 0 ? 0 : kGr) : "memory");            \
     KP_MARK(0);                                                                         \
     __builtin_amdgcn_s_barrier();                                                       \
     KP_MARK(9);                                                                         \
