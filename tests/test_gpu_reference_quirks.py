@@ -81,6 +81,31 @@ def test_float_key_split_kernel_matches_the_oracle(dev, batch):
         assert stats["c3_mixed"][b] == stats["c2_mixed"][b]
 
 
+@pytest.mark.parametrize("tag,batch", [("b1", 1), ("b2", 2), ("b3", 3)])
+def test_float_key_split_kernel_vs_the_references_own_function(dev, tag, batch):
+    """tests/golden/modality_split_vectors.npz holds what the REFERENCE's voxel_modality_split +
+    type_assign returned (make_modality_split_golden.py executes MSMDFusion.py:251-325,27-45
+    as they stand) for voxel sets whose float32 keys collide across the sets but never inside
+    one (so the reference's unspecified tie order plays no part): msmd_modality_split_float_keys
+    with the reference's batch offsets == those flags and syn_mix lists, bit for bit -- at
+    batch 3 the reference's own (non-cumulative, i.e. wrong) rows included."""
+    import os
+    from msmdfusion_amd import kernels as K
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                             "modality_split_vectors.npz"))
+    i3, i2 = g[tag + "_idx3"], g[tag + "_idx2"]
+    m3, m2, p3, p2 = K.modality_split(torch.from_numpy(i3).to(dev), torch.from_numpy(i2).to(dev),
+                                      batch, SHAPE0, float_keys=True, reference_offsets=True)
+    assert np.array_equal(_np(m3), g[tag + "_mix3"]) and np.array_equal(_np(m2), g[tag + "_mix2"])
+    assert np.array_equal(_np(p3).astype(np.int64), g[tag + "_syn3"])
+    assert np.array_equal(_np(p2).astype(np.int64), g[tag + "_syn2"])
+    if batch <= 2:      # global rows there: the false matches are visible as unequal coordinates
+        assert int((i3[_np(p3)] != i2[_np(p2)]).any(1).sum()) > 500
+    x3 = K.modality_split(torch.from_numpy(i3).to(dev), torch.from_numpy(i2).to(dev), batch,
+                          SHAPE0)[0]
+    assert int(x3.sum()) < int(g[tag + "_mix3"].sum())
+
+
 def test_float_key_split_kernel_edges(dev):
     from msmdfusion_amd import kernels as K
     from msmdfusion_amd._lib import MsmdError

@@ -270,3 +270,32 @@ def test_nn_assign_last_write_wins_and_fps_tie_order():
     xyz = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0]]], np.float32)
     assert O.fps_block_size(5) == 4
     assert O.furthest_point_sample(xyz, 2).tolist() == [[0, 4]]   # k=4 shares thread 0 with k=0
+
+
+def test_modality_split_vs_the_references_own_function():
+    """tests/golden/modality_split_vectors.npz = what the reference's voxel_modality_split +
+    type_assign (MSMDFusion.py:251-325, 27-45, executed by make_modality_split_golden.py)
+    returned for voxel sets whose float32 keys alias across the sets: the oracle's float-key
+    restatement reproduces the flags and the syn_mix lists -- false matches and the
+    non-cumulative batch offsets (:288-289,313-314) included -- and the exact-key mode does not."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                             "modality_split_vectors.npz"))
+    shape = [41, 1440, 1440]
+    for tag, batch in (("b1", 1), ("b2", 2), ("b3", 3)):
+        i3, i2 = g[tag + "_idx3"], g[tag + "_idx2"]
+        e3, e2, p3, p2 = [], [], [], []
+        last3 = last2 = 0
+        for b in range(batch):
+            r3, r2 = np.flatnonzero(i3[:, 0] == b), np.flatnonzero(i2[:, 0] == b)
+            m3, m2, q3, q2 = O.modality_split(i3[r3, 1:], i2[r2, 1:], shape, float_keys=True)
+            e3.append(m3); e2.append(m2)
+            p3.append(q3.astype(np.int64) + last3); p2.append(q2.astype(np.int64) + last2)
+            last3, last2 = len(r3), len(r2)
+        assert np.array_equal(np.concatenate(e3), g[tag + "_mix3"]), tag
+        assert np.array_equal(np.concatenate(e2), g[tag + "_mix2"]), tag
+        assert np.array_equal(np.concatenate(p3), g[tag + "_syn3"]), tag
+        assert np.array_equal(np.concatenate(p2), g[tag + "_syn2"]), tag
+        x3 = np.concatenate([O.modality_split(i3[i3[:, 0] == b][:, 1:], i2[i2[:, 0] == b][:, 1:],
+                                              shape)[0] for b in range(batch)])
+        assert not np.array_equal(x3, g[tag + "_mix3"])          # exact keys: fewer "mixed"
+        assert x3.sum() < g[tag + "_mix3"].sum()
