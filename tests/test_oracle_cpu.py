@@ -299,3 +299,29 @@ def test_modality_split_vs_the_references_own_function():
                                               shape)[0] for b in range(batch)])
         assert not np.array_equal(x3, g[tag + "_mix3"])          # exact keys: fewer "mixed"
         assert x3.sum() < g[tag + "_mix3"].sum()
+
+
+def test_sparse_add_equals_torch_coo_add_and_coalesce():
+    """spconv-2.x is not in the tree; its functional.sparse_add (call site
+    sparse_multimodal_encoder_painting.py:455) adds the operands as COO tensors and coalesces
+    -- rows in ascending linear index, features summed where coordinates coincide.  The
+    oracle's restatement against torch's own `torch.sparse_coo_tensor(...) + ...` followed by
+    `.coalesce()` on the same operands (coordinates repeated INSIDE an operand included, which
+    the fusion stack's unified sets can produce in reference mode)."""
+    import torch
+    shape, batch = [5, 24, 24], 2
+    a = S.random_voxel_indices(400, batch, shape, seed=3)
+    b = np.concatenate([a[::3], S.random_voxel_indices(300, batch, shape, seed=4)])
+    b = np.concatenate([b, b[:7]])                         # a few repeated rows inside b
+    rng = np.random.RandomState(1)
+    fa = rng.randn(a.shape[0], 6).astype(np.float32)
+    fb = rng.randn(b.shape[0], 6).astype(np.float32)
+    oi, of, ma, mb = O.sparse_add(fa, a, fb, b, shape)
+    size = (batch, *shape, 6)
+    ta = torch.sparse_coo_tensor(torch.from_numpy(a.T.astype(np.int64)), torch.from_numpy(fa), size)
+    tb = torch.sparse_coo_tensor(torch.from_numpy(b.T.astype(np.int64)), torch.from_numpy(fb), size)
+    tc = (ta + tb).coalesce()
+    assert np.array_equal(tc.indices().numpy().T.astype(np.int32), oi)
+    np.testing.assert_allclose(tc.values().numpy(), of, rtol=1e-6, atol=1e-6)
+    # the row maps point every operand row at its coordinate's output row
+    assert np.array_equal(oi[ma], a) and np.array_equal(oi[mb], b)
