@@ -83,6 +83,15 @@ WORKLOADS = {
         name="configs[2] at configs[3]'s per-GPU batch (batch_size=4/GPU): MSMDFusion-LC sparse "
              "path, fwd+bwd+AdamW, 4 x (28.7k LiDAR + 50k virtual pts)/GPU, 0.075 m voxels, fp32",
         spg=4, bev_channels=640, settle=16),
+    "lc_quirks": dict(
+        metric="samples/sec MSMDFusion fwd+bwd nuScenes 0.075m voxel (MSMDFusion-LC sparse "
+               "fusion path, reference_quirks=True)",
+        name="configs[2] with reference_quirks=True: the same step with the reference's float32 "
+             "voxel keys in voxel_modality_split (MSMDFusion.py:251-325,27-45: false 'mixed' "
+             "voxels where keys alias) and its non-cumulative batch offsets -- the mode that "
+             "matches a checkpoint trained with the reference; 2 x (28.7k LiDAR + 50k virtual "
+             "pts)/GPU, fwd+bwd+AdamW, fp32",
+        spg=MSMDFUSION_LC["samples_per_gpu"], bev_channels=640, settle=16),
     "lc_tail": dict(
         metric="samples/sec MSMDFusion fwd+bwd nuScenes 0.075m voxel (MSMDFusion-LC sparse "
                "fusion path + dense BEV tail)",
@@ -166,10 +175,12 @@ class FusionBackbone(torch.nn.Module):
     dict, its sparse section (MSMDFusion.py:421-443): LiDAR encoder frozen
     (freeze_lidar_components, tools/train.py:185-219), fusion stack trained."""
 
-    def __init__(self, tail=False, head=False):
+    def __init__(self, tail=False, head=False, reference_quirks=False):
         super().__init__()
         from msmdfusion_amd.detector import build_detector, freeze_lidar_components
         cfg = dict(MSMDFUSION_LC["model"]) if tail else _sparse_only(MSMDFUSION_LC["model"])
+        if reference_quirks:
+            cfg["reference_quirks"] = True
         if head:
             from msmdfusion_amd.configs import _PTS_BBOX_HEAD, _TEST_CFG_PTS, _TRAIN_CFG_PTS
             cfg.update(pts_bbox_head=dict(_PTS_BBOX_HEAD), train_cfg=dict(pts=dict(_TRAIN_CFG_PTS)),
@@ -287,6 +298,47 @@ def image_glue_kernel_times(model, batch, reps=10):
             out["fg_gather"].append({"map": list(f.shape), "points": int(n), "us": round(ms * 1e3, 1),
                                      "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
                                      "frac_hbm": round(nbytes / (ms * 1e-3) / 1e12 / HBM_PEAK_TBPS, 4)})
+    return out
+
+
+def modality_split_times(model, batch, reps=10):
+    """voxel_modality_split of the four scales of this batch (one modality_split_many call,
+    as prepare() makes it), alone on the chip: the reference's float32 keys + two-pointer
+    merge + reference batch offsets (csrc/modality_float.hip) beside the exact-key bitmap
+    split of the default mode; and how many voxels the float keys match falsely."""
+    from msmdfusion_amd import kernels as K
+    path = model.det._path
+    with torch.no_grad():
+        p = path.prepare(batch[0], [batch[1]] * 4, nn_side_stream=False)
+    torch.cuda.synchronize()
+    B = len(batch[0])
+    jobs = []
+    for i in range(4):
+        idx3 = p["stages"][i][0]
+        i2 = p["v2"][i].indices
+        idx2 = torch.cat([i2[:, :1], i2[:, 2:]], 1).contiguous()
+        shape = [max(a, b) for a, b in zip(p["stages"][i][1], p["v2"][i].spatial_shape)]
+        jobs.append((idx3, idx2, shape))
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps * 1e3
+    out = {"call": "kernels.modality_split_many over the 4 scales (incl. its one host read)",
+           "float_keys_us": round(timed(lambda: K.modality_split_many(
+               jobs, B, float_keys=True, reference_offsets=True)), 1),
+           "exact_keys_us": round(timed(lambda: K.modality_split_many(jobs, B)), 1)}
+    fk = K.modality_split_many(jobs, B, float_keys=True, reference_offsets=True)
+    ex = K.modality_split_many(jobs, B)
+    out["mixed_voxels_float_keys"] = [int((a[0] > 0).sum().item()) for a in fk]
+    out["mixed_voxels_exact_keys"] = [int((a[0] > 0).sum().item()) for a in ex]
     return out
 
 
@@ -453,13 +505,15 @@ def run_workload(workload, args, dev, rank, world, profile):
     from msmdfusion_amd.prefetch import IndexPrefetcher
 
     wl = WORKLOADS[workload]
-    lc = workload in ("lc", "lc_tail", "lc_b4", "lc_full", "lc_img")
+    lc = workload in ("lc", "lc_tail", "lc_b4", "lc_full", "lc_img", "lc_quirks")
     spg = wl["spg"]
     torch.manual_seed(0)
     ids = D.shard_sample_ids(rank, world, spg)      # disjoint samples per rank (weak scaling)
     model = (FusionDetector(ids) if workload == "lc_full" else
              FusionTailBackbone() if workload == "lc_tail" else
-             FusionImageBackbone() if workload == "lc_img" else FusionBackbone() if lc
+             FusionImageBackbone() if workload == "lc_img" else
+             FusionBackbone(reference_quirks=True) if workload == "lc_quirks" else
+             FusionBackbone() if lc
              else Backbone()).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     net = D.wrap_data_parallel(model, device_ids=[dev.index])
@@ -583,6 +637,8 @@ def run_workload(workload, args, dev, rank, world, profile):
                       "trainable_params": sum(p.numel() for p in params)}}
     if workload == "lc_img":
         res["image_glue"] = image_glue_kernel_times(model, batch)
+    if workload == "lc_quirks":
+        res["modality_split"] = modality_split_times(model, batch)
     res["roofline"] = roofline(prof, workload, marks) if prof else None
     if res["roofline"]:
         r = res["roofline"]
@@ -659,6 +715,7 @@ def main():
 
         leg("configs[1]", "transfusion_l", profile=not args.no_profile, cpu=not args.no_cpu_baseline)
         if os.environ.get("MSMD_BENCH_TAIL", "1") == "1":
+            leg("configs[2] reference_quirks", "lc_quirks")
             leg("configs[2]+image glue", "lc_img")
             leg("configs[2]+f1", "lc_tail")
             leg("configs[2]+f1+f3", "lc_full")

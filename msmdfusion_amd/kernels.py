@@ -480,6 +480,21 @@ def _prof_end(kind, start, **meta):
         PROFILE.append((kind, start, end, meta))
 
 
+# tools/split_bench.py --lc-b2 sets this to a list: every conv launch of a step is kept as
+# (kind, meta, relaunch) -- relaunch() issues the same library call on the same operands
+# again, alone on the chip -- to separate a layer's own time from what the step costs it.
+CAPTURE = None
+
+
+def _launch(kind, call, **meta):
+    """One conv library call, bracketed by PROFILE's events and kept for CAPTURE."""
+    ev = _prof_begin()
+    call()
+    _prof_end(kind, ev, **meta)
+    if CAPTURE is not None:
+        CAPTURE.append((kind, meta, call))
+
+
 TILE_ROWS = 128     # rows per workgroup tile of the conv kernels
 
 
@@ -684,12 +699,11 @@ def conv_forward(feat, packed_weight, nbr, n_out, c_out, weight_flip=False, row_
     out = torch.empty((n_out, c_out), dtype=torch.float32, device=f.device)
     # persistent tile scheduler whenever a (heaviest-first) order is supplied
     counter = _tile_counter(f.device) if row_order is not None else None
-    ev = _prof_begin()
-    check(lib.msmd_spconv_fwd_f32(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld, int(n_out),
-                                  kvol, int(bool(weight_flip)), _p(row_order), _p(counter),
-                                  _p(out), int(c_out), _stream()),
-          "msmd_spconv_fwd_f32")
-    _prof_end("spconv_fwd", ev, nbr=nbr, c_in=c_in, c_out=int(c_out), n_in=n_in, n_out=int(n_out))
+    _launch("spconv_fwd", lambda: check(
+        lib.msmd_spconv_fwd_f32(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld, int(n_out),
+                                kvol, int(bool(weight_flip)), _p(row_order), _p(counter),
+                                _p(out), int(c_out), _stream()), "msmd_spconv_fwd_f32"),
+            nbr=nbr, c_in=c_in, c_out=int(c_out), n_in=n_in, n_out=int(n_out))
     return out
 
 
@@ -855,17 +869,15 @@ def conv_forward_split(feat, packed_weight, nbr, n_out, c_out, planes=3, weight_
     if bn_stats and int(n_out) > 0:
         part = torch.empty((int(lib.msmd_spconv_fwd_split_stats_blocks(int(n_out), int(c_out))), 2,
                             int(c_out)), dtype=torch.float32, device=f.device)
-    ev = _prof_begin()
-    check(lib.msmd_spconv_fwd_split_stats(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld,
-                                          int(n_out), kvol, int(bool(weight_flip)),
-                                          _p(row_order), _p(counter), counter.numel(), _p(out),
-                                          int(c_out), int(planes), _p(ws),
-                                          0 if ws is None else ws.numel(),
-                                          _p(tile_prefix) if split_tiles else None, _p(part),
-                                          _stream()),
-          "msmd_spconv_fwd_split_stats")
-    _prof_end("spconv_fwd_split", ev, nbr=nbr, c_in=c_in, c_out=int(c_out), n_in=n_in,
-              n_out=int(n_out))
+    _launch("spconv_fwd_split", lambda: check(
+        lib.msmd_spconv_fwd_split_stats(_p(f), n_in, c_in, _p(packed_weight), _p(nbr), ld,
+                                        int(n_out), kvol, int(bool(weight_flip)),
+                                        _p(row_order), _p(counter), counter.numel(), _p(out),
+                                        int(c_out), int(planes), _p(ws),
+                                        0 if ws is None else ws.numel(),
+                                        _p(tile_prefix) if split_tiles else None, _p(part),
+                                        _stream()), "msmd_spconv_fwd_split_stats"),
+            nbr=nbr, c_in=c_in, c_out=int(c_out), n_in=n_in, n_out=int(n_out))
     return (out, part) if bn_stats else out
 
 
@@ -880,12 +892,11 @@ def conv_wgrad(feat, d_out, pairs, num, krsc_shape=None):
                      dtype=torch.float32, device=f.device)
     nbytes = lib.msmd_spconv_wgrad_workspace_bytes(kvol, ld, c_in, c_out)
     ws = _ws(nbytes, f.device)
-    ev = _prof_begin()
-    check(lib.msmd_spconv_wgrad_f32(_p(f), c_in, _p(g), c_out, _p(pairs), _p(num), ld, kvol,
-                                    _p(dw), int(krsc_shape is not None), _p(ws), nbytes,
-                                    _stream()), "msmd_spconv_wgrad_f32")
-    _prof_end("spconv_wgrad", ev, num=num, c_in=c_in, c_out=c_out, n_in=f.shape[0],
-              n_out=g.shape[0])
+    _launch("spconv_wgrad", lambda: check(
+        lib.msmd_spconv_wgrad_f32(_p(f), c_in, _p(g), c_out, _p(pairs), _p(num), ld, kvol,
+                                  _p(dw), int(krsc_shape is not None), _p(ws), nbytes,
+                                  _stream()), "msmd_spconv_wgrad_f32"),
+            num=num, c_in=c_in, c_out=c_out, n_in=f.shape[0], n_out=g.shape[0])
     return dw
 
 
@@ -943,14 +954,13 @@ def conv_wgrad_split(feat, d_out, pairs, num, planes=3, krsc_shape=None, segment
     table, n_chunks = segments if segments is not None else (None, 1)
     nbytes = lib.msmd_spconv_wgrad_segments_workspace_bytes(kvol, ld, c_in, c_out, n_chunks)
     ws = _ws(nbytes, f.device)
-    ev = _prof_begin()
-    check(lib.msmd_spconv_wgrad_split_segments(_p(f), c_in, _p(g), c_out, _p(pairs), _p(num), ld,
-                                               kvol, int(planes), _p(dw),
-                                               int(krsc_shape is not None), _p(table),
-                                               int(n_chunks), _p(ws), nbytes, _stream()),
-          "msmd_spconv_wgrad_split_segments")
-    _prof_end("spconv_wgrad_split", ev, num=num, c_in=c_in, c_out=c_out, n_in=f.shape[0],
-              n_out=g.shape[0])
+    _launch("spconv_wgrad_split", lambda: check(
+        lib.msmd_spconv_wgrad_split_segments(_p(f), c_in, _p(g), c_out, _p(pairs), _p(num), ld,
+                                             kvol, int(planes), _p(dw),
+                                             int(krsc_shape is not None), _p(table),
+                                             int(n_chunks), _p(ws), nbytes, _stream()),
+        "msmd_spconv_wgrad_split_segments"),
+            num=num, c_in=c_in, c_out=c_out, n_in=f.shape[0], n_out=g.shape[0])
     return dw
 
 
@@ -1455,6 +1465,9 @@ def modality_split_many(jobs, batch_size, float_keys=False, reference_offsets=Fa
     return res
 
 
+CHECK_COUNTS = os.environ.get("MSMD_CHECK_COUNTS", "0") == "1"
+
+
 def rows_where_eq(flags, value, count):
     """Row numbers i (int64, ascending) with flags[i] == value for a 1-D int32 tensor (any
     stride: a column of an index tensor) whose number of such rows the host already knows:
@@ -1465,11 +1478,21 @@ def rows_where_eq(flags, value, count):
     if not flags.is_cuda or flags.dtype != torch.int32 or flags.dim() != 1:
         return rows_where(flags == value, count)
     n = flags.shape[0]
+    # `count` is the host's number (msmd_modality_split_stats).  The kernel never leaves a
+    # row of the output unwritten: rows past the device's own total are set to -1
+    # (rows_tail_fill, csrc/dense.hip), so a stale host count cannot hand uninitialised row
+    # ids to index_select -- it hands it -1, which torch's bounds check rejects.
+    # MSMD_CHECK_COUNTS=1 (tests, debugging) reads the device total back and compares.
     rows = torch.empty((count,), dtype=torch.long, device=flags.device)
     nbytes = lib.msmd_rows_where_workspace_bytes(n)
     ws = _ws(nbytes, flags.device)
+    total = torch.empty((1,), dtype=torch.int32, device=flags.device) if CHECK_COUNTS else None
     check(lib.msmd_rows_where_eq(_p(flags), int(flags.stride(0)), n, int(value), _p(rows), count,
-                                 None, _p(ws), nbytes, _stream()), "msmd_rows_where_eq")
+                                 _p(total), _p(ws), nbytes, _stream()), "msmd_rows_where_eq")
+    if total is not None and int(total.item()) != count:
+        raise RuntimeError("rows_where_eq: the host expects %d rows with flag %d, the device "
+                           "found %d (stale per-sample statistics?)"
+                           % (count, int(value), int(total.item())))
     return rows
 
 

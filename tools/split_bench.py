@@ -3,6 +3,9 @@
 sets: time, and error of both against an fp64 evaluation of the same sum.
 
     python tools/split_bench.py [--planes 3] [--wgrad]
+    python tools/split_bench.py --lc-b2     every conv launch of the LC step (configs[2],
+                                            2 samples per GPU) alone on the chip vs inside the
+                                            pipelined step: under-fill vs co-tenancy
 """
 import argparse
 import os
@@ -37,13 +40,120 @@ def ref64(f, w, nbr):
     return out
 
 
+def lc_b2(reps=10, sampled_steps=5):
+    """Every conv launch of one LC training step at its B = 2 shape: (a) replayed ALONE on
+    an otherwise idle chip (kernels.CAPTURE keeps each launch's closure), (b) inside the
+    pipelined step (index prefetch + neighbour search on their own queues, as bench.py runs
+    it), timed by HIP events on the launch stream.  One line per launch, then the sums per
+    template instantiation."""
+    import statistics
+    import torch
+    import bench
+    from msmdfusion_amd import distributed as D
+    from msmdfusion_amd import kernels as K
+    from msmdfusion_amd import synthetic as S
+    from msmdfusion_amd.prefetch import IndexPrefetcher
+    from msmdfusion_amd.spconv.functional import conv_planes
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    spg = bench.WORKLOADS["lc"]["spg"]
+    ids = list(range(spg))
+    model = bench.FusionBackbone().to(dev).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+    batch = ([torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in ids],
+             [torch.from_numpy(S.virtual_points(i)).to(dev) for i in ids])
+    target = torch.randn(spg, 640, 180, 180, device=dev).contiguous(
+        memory_format=torch.channels_last)
+    loss_fn = lambda bev: bench.mean_of_product(bev, target)    # noqa: E731
+    plain = D.TrainStep(model, params, opt, loss_fn, None, 10.0)
+    for _ in range(30):             # clocks + allocator
+        plain(batch)
+    torch.cuda.synchronize()
+    K.CAPTURE = []
+    plain(batch)
+    cap, K.CAPTURE = K.CAPTURE, None
+    torch.cuda.synchronize()
+    alone = []
+    for kind, meta, call in cap:
+        alone.append(timed(call, reps))
+    # (b) the same launches inside the pipelined step
+    pf = IndexPrefetcher(model.prepare, dev, threaded=True, priority=-1, depth=2, workers=1)
+    sys.setswitchinterval(0.0005)
+    step = D.TrainStep(model, params, opt, loss_fn, pf, 10.0)
+    step.prime(batch)
+    for _ in range(60):
+        step(batch)
+    torch.cuda.synchronize()
+    insitu = [[] for _ in cap]
+    for s_ in range(sampled_steps):
+        for _ in range(4):
+            step(batch)
+        K.PROFILE = []
+        step(batch)
+        prof, K.PROFILE = K.PROFILE, None
+        torch.cuda.synchronize()
+        assert len(prof) == len(cap), (len(prof), len(cap))
+        for i, (kind, s, e, meta) in enumerate(prof):
+            assert kind == cap[i][0] and meta["c_out"] == cap[i][1]["c_out"]
+            insitu[i].append(s.elapsed_time(e) * 1e3)
+    step.drain()
+    groups = {}
+    pair_cache = {}
+    print("%-48s %9s %8s %9s | %8s %8s | %6s %6s" % (
+        "kernel", "cin->cout", "rows", "pairs", "alone us", "step us", "TF al", "TF st"))
+    for i, (kind, meta, _) in enumerate(cap):
+        if "nbr" in meta:
+            nbr = meta["nbr"]
+            key = (nbr.data_ptr(), nbr.shape[1])
+            if key not in pair_cache:
+                pair_cache[key] = int((nbr >= 0).sum().item())
+            pairs = pair_cache[key]
+        else:
+            pairs = int(meta["num"].sum().item())
+        if kind == "spconv_fwd_split":
+            name, _n = bench.split_instantiation(meta["c_out"], conv_planes())
+        elif kind == "spconv_wgrad_split":
+            name = "spconv_wgrad_block_kernel" if K.wgrad_split_supported(
+                meta["c_in"], meta["c_out"]) else "spconv_wgrad_split_var_kernel"
+        else:
+            name = kind
+        flops = 2.0 * pairs * meta["c_in"] * meta["c_out"]
+        st = statistics.median(insitu[i])
+        print("%-48s %4d->%-4d %8d %9d | %8.1f %8.1f | %6.1f %6.1f" % (
+            name, meta["c_in"], meta["c_out"], meta["n_out"], pairs, alone[i], st,
+            flops / alone[i] / 1e6, flops / st / 1e6), flush=True)
+        g = groups.setdefault(name, [0, 0.0, 0.0, 0.0])
+        g[0] += 1
+        g[1] += alone[i]
+        g[2] += st
+        g[3] += flops
+    print()
+    print("%-48s %5s %10s %10s %8s %8s %7s" % ("per instantiation", "n", "alone us", "step us",
+                                                 "TF alone", "TF step", "step/al"))
+    tot = [0.0, 0.0, 0.0]
+    for name, (n, a, st, fl) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
+        print("%-48s %5d %10.1f %10.1f %8.1f %8.1f %7.2f" % (name, n, a, st, fl / a / 1e6,
+                                                            fl / st / 1e6, st / a))
+        tot[0] += a
+        tot[1] += st
+        tot[2] += fl
+    print("%-48s %5d %10.1f %10.1f %8.1f %8.1f %7.2f" % (
+        "all conv launches of a step", len(cap), tot[0], tot[1], tot[2] / tot[0] / 1e6,
+        tot[2] / tot[1] / 1e6, tot[1] / tot[0]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--planes", type=int, default=3)
     ap.add_argument("--wgrad", action="store_true")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--lc", action="store_true", help="the fusion stack's channel widths")
+    ap.add_argument("--lc-b2", action="store_true",
+                    help="every conv launch of the LC step alone vs inside the pipelined step")
     args = ap.parse_args()
+    if args.lc_b2:
+        return lc_b2()
     import torch
     import torch.nn.functional as F
     from msmdfusion_amd import kernels as K
