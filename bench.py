@@ -783,26 +783,41 @@ def pmc_entry(kernel_name, workload):
     return key, kernels.get(key, {}), os.path.relpath(path, ROOT)
 
 
+def rocprof_entry(kernel_name, workload):
+    """(average launch us, calls, file, head) of `kernel_name` in the newest committed rocprofv3
+    kernel-stats summary of this workload (profiles/rNN_<wl>_kernel_stats.csv, written by
+    tools/prof_bench.sh from `rocprofv3 --kernel-trace --stats` of this command); head = the
+    commit the summary was taken at (profiles/rNN_<wl>_kernel_stats.head, when recorded)."""
+    import csv
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_stats.csv" % workload)))
+    if not found:
+        return None
+    path = found[-1]
+    want = kernel_name.replace(" ", "")
+    for row in csv.DictReader(open(path)):
+        # "void msmd::(anonymous namespace)::spconv_fwd_split_kernel<8, 1, 3, 4, 2, false, 2>(float const*, ..."
+        name = row["Name"].split("(anonymous namespace)::")[-1].replace(" ", "")
+        if name.startswith(want + "("):
+            head_file = path[:-4] + ".head"
+            head = open(head_file).read().strip() if os.path.exists(head_file) else None
+            return float(row["AverageNs"]) / 1e3, int(row["Calls"]), os.path.relpath(path, ROOT), head
+    return None
+
+
 def split_instantiation(c_out, planes):
     """The template instantiation msmd_spconv_fwd_split runs for a layer with c_out output
-    channels (csrc/spconv_split.hip: dispatch_fwd_split): passes of <= 8 tiles of 16 channels,
-    a pass's tile count rounded up to 2, 4, 6 or 8.  -> (name as rocprofv3 prints it, kernel
-    launches per call).  80, 96 and 192 output channels all run `<6, 1, ..>`; above 64
-    channels the 8-wave ping-pong instantiation."""
+    channels -> (name as rocprofv3 prints it, kernel launches per call).  Asked of the library
+    (msmd_spconv_fwd_split_instantiation: csrc/spconv_split.hip's own dispatch under the
+    current environment), not re-derived here: 4 waves / 128-row tiles below
+    MSMD_FWD_PP_MIN = 161 output channels (80 and 96 channels run `<6, 1, ..>`, 128 runs
+    `<8, 1, ..>`), the 8-wave ping-pong form from there up, 161..192 channels as one 12-tile
+    pass."""
     from msmdfusion_amd import kernels as K
-    nt_total = (c_out + 15) // 16
-    waves = K.split_tile_rows(c_out) // 32
-    n_pass = (nt_total + 7) // 8
-    if waves == 8 and nt_total in (11, 12) and os.environ.get("MSMD_FWD_NT12", "1") != "0":
-        n_pass = 1          # 161..192 channels: one 12-tile pass (csrc/spconv_split.hip)
-    per = (nt_total + n_pass - 1) // n_pass
-    nt = 12 if per > 8 else 8 if per > 6 else 6 if per > 4 else 4 if per > 2 else 2
-    if waves == 8:      # the ping-pong form: 6, 8 or 12 tiles, 3 weight buffers
-        nt = max(nt, 6)
-        return "spconv_fwd_split_kernel<%d, 1, %d, 8, 3, true, %d>" % (
-            nt, planes, 1 if nt == 12 else 2), n_pass
-    ub = {8: 1, 6: 1, 4: 2, 2: 4}[nt]
-    return "spconv_fwd_split_kernel<%d, %d, %d, %d, 2, false, 2>" % (nt, ub, planes, waves), n_pass
+    i = K.split_instantiation(c_out)
+    return "spconv_fwd_split_kernel<%d, %d, %d, %d, %d, %s, %d>" % (
+        i["nt"], i["ub"], planes, i["waves"], i["buffers"], "true" if i["pingpong"] else "false",
+        i["tables"]), i["passes"]
 
 
 HBM_PEAK_TBPS = 8.0     # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy rate)
@@ -930,6 +945,11 @@ def roofline(prof, workload, marks=None):
            "l2_hit_rate_pmc": pmc.get("l2_hit_rate"),
            "mfma_pipe_busy_frac_pmc": pmc.get("mfma_pipe_busy_frac"),
            "avg_launch_us": round(avg_us, 2), "launches": g["launches"],
+           "avg_launch_us_clock": "HIP events on the launch stream around each launch, inside the "
+                                  "pipelined step (queue gaps and co-running index kernels "
+                                  "included); frac / frac_mfma are priced with it.  "
+                                  "frac_rocprof prices the same algorithmic work with the "
+                                  "kernel's own duration from the committed rocprofv3 summary",
            "sampling": "HIP events around every conv call of %d sampled steps of the timed "
                        "region (a call on > 128 output channels is two launches of the kernel: "
                        "time and flops are per launch); figures of the median step (TF of "
@@ -941,6 +961,15 @@ def roofline(prof, workload, marks=None):
            "all_conv_kernels": {k: {"ms": round(v["ms"], 3),
                                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 3),
                                     "launches": v["launches"]} for k, v in groups.items()}}
+    rp = rocprof_entry(name, workload)
+    if rp is not None:      # the same algorithmic flops / bytes per launch over rocprof's duration
+        us, calls, rfile, rhead = rp
+        fl_per_launch = g["flops"] / g["launches"]
+        f_mfma = fl_per_launch / (us * 1e-6) / 1e12 / peak
+        f_bytes = algo_per_launch / (us * 1e-6) / 1e12 / HBM_PEAK_TBPS
+        out.update(frac_rocprof=round(max(f_mfma, f_bytes), 4),
+                   rocprof_avg_launch_us=round(us, 2), rocprof_calls=calls, rocprof_file=rfile,
+                   rocprof_head=rhead)
     return out
 
 

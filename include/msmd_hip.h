@@ -143,6 +143,11 @@ int msmd_rulebook_subm3d_many(const msmd_subm_desc* descs, int n_desc, void* wor
  * output cells and counts them (*n_out, device); the caller reads it,
  * allocates, then phase 2 fills out_indices / nbr_fwd / nbr_bwd.  The same
  * workspace must be passed, untouched, to both phases.
+ * An input set that repeats a coordinate (only the reference_quirks unified sets can): the
+ * table is output-stationary, one input row per (offset, output row) -- the LAST row of the
+ * coordinate, deterministically, as every SubM look-up; nbr_bwd still lists the output row
+ * for every input row (the earlier rows receive the gradient of a contribution the forward
+ * pass did not take from them: INTEGRATION.md).
  * ------------------------------------------------------------------------ */
 size_t msmd_rulebook_conv_workspace_bytes(int batch_size,
                                           const int* out_shape /* host[3] */);
@@ -329,6 +334,14 @@ int msmd_spconv_fwd_split_stats_blocks(int n_out, int c_out);
  * tile_prefix with.  Environment: MSMD_FWD_PP_MIN moves the threshold, MSMD_FWD_PP=0 = 128
  * everywhere. */
 int msmd_spconv_fwd_split_tile_rows(int c_out);
+
+/* Which instantiation of the split kernel msmd_spconv_fwd_split launches for a layer of c_out
+ * output channels (under the current environment): params[7] = {NT column tiles per pass,
+ * UB units per item, waves per workgroup, weight buffers, ping-pong 0|1, table buffers,
+ * column passes = kernel launches per call}.  rocprofv3 names the kernel
+ * spconv_fwd_split_kernel<NT, UB, planes, waves, buffers, pingpong, tables>.  For tools
+ * (bench.py's roofline grouping, tools/split_bench.py); replaces nothing in the reference. */
+int msmd_spconv_fwd_split_instantiation(int c_out, int* params);
 
 /* Stream-K work table of a neighbour table (in the order the conv kernel tiles it):
  * prefix[t] = number of (row tile, active offset) work items before tile t, prefix[n_tiles]
@@ -737,8 +750,11 @@ int msmd_modality_split_stats(const int32_t* idx_3d, int n3,
  * reference_offsets != 0: pair rows numbered as the reference does (:288-289,313-314:
  * position in the sample + the PREVIOUS sample's count only; identical to global rows for
  * batch <= 2; needs each set's rows grouped by sample, ascending).  sample_stats (or NULL) as
- * msmd_modality_split_stats.  Grids whose largest key reaches 2^26, or batch_size > 64:
- * MSMD_ERR_RANGE. */
+ * msmd_modality_split_stats.  Grids whose largest key (in the kernel's own float32
+ * arithmetic) reaches 2^26, or batch_size > 64: MSMD_ERR_RANGE.  Checked on the device, as the
+ * rows are keyed: a row outside the grid or the batch (negative coordinates included), and --
+ * with reference_offsets -- a row whose sample id is below its predecessor's; either sets
+ * *n_mixed = -1 (every other output is then unspecified) instead of a count. */
 size_t msmd_modality_split_float_keys_workspace_bytes(int n3, int n2, int batch_size);
 int msmd_modality_split_float_keys(const int32_t* idx_3d, int n3, const int32_t* idx_2d, int n2,
                                    int batch_size, const int* spatial_shape, int32_t* mix3d,

@@ -83,6 +83,7 @@ SIGNATURES = {
     "msmd_spconv_fwd_split_stats": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "msmd_rulebook_tile_prefix": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "msmd_spconv_fwd_split_tile_rows": (_i, [_i]),
+    "msmd_spconv_fwd_split_instantiation": (_i, [_i, _ip]),
     "msmd_spconv_fwd_split_stats_blocks": (_i, [_i, _i]),
     "msmd_spconv_wgrad_split_supported": (_i, [_i, _i]),
     "msmd_spconv_wgrad_split": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),

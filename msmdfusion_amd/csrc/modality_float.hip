@@ -41,14 +41,28 @@ __device__ __forceinline__ uint32_t float_key(int z, int y, int x) {
   return (uint32_t)k;     // integer-valued, < 2^26 (checked on the host from the grid shape)
 }
 
+// `bad` (one int, zeroed by the entry point) is raised for a row outside the grid / the batch
+// (its key would spill into the sample bits; a negative float -> unsigned is undefined) and,
+// with `grouped`, for a row whose sample id is below its predecessor's (reference_offsets
+// finds each sample's first row by binary search).  Such a row gets key 0; the entry point's
+// last kernel then reports the call as failed through *n_mixed = -1.
 __global__ __launch_bounds__(256) void fkey_kernel(const int32_t* __restrict__ idx, int n,
+                                                   int batch, int sz, int sy, int sx, int grouped,
                                                    uint32_t* __restrict__ keys,
-                                                   int32_t* __restrict__ rows) {
+                                                   int32_t* __restrict__ rows,
+                                                   int32_t* __restrict__ bad) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int4 r = ((const int4*)idx)[i];
-  keys[i] = ((uint32_t)r.x << kKeyBits) | float_key(r.y, r.z, r.w);
+  const bool in = (unsigned)r.x < (unsigned)batch && (unsigned)r.y < (unsigned)sz &&
+                  (unsigned)r.z < (unsigned)sy && (unsigned)r.w < (unsigned)sx;
+  const bool order_ok = !grouped || i == 0 || idx[(size_t)(i - 1) * 4] <= r.x;
+  if (!in || !order_ok) *bad = 1;      // (same value from every writer)
+  keys[i] = in ? ((uint32_t)r.x << kKeyBits) | float_key(r.y, r.z, r.w) : 0u;
   rows[i] = i;
+}
+__global__ void fkey_report_kernel(const int32_t* __restrict__ bad, int32_t* __restrict__ n_mixed) {
+  if (*bad) *n_mixed = -1;
 }
 
 // first row of every sample (rows grouped by sample, ascending): start[b], b = 0 .. batch
@@ -144,7 +158,7 @@ struct EmitPair {
 
 struct FkWs {
   uint32_t *k3, *k3s, *k2, *k2s;
-  int32_t *r3, *r3s, *r2, *r2s, *flag, *partner, *start3, *start2;
+  int32_t *r3, *r3s, *r2, *r2s, *flag, *partner, *start3, *start2, *bad;
   int* tiles;
   void* cub;
   size_t cub_bytes;
@@ -170,6 +184,7 @@ void carve_fk(A& a, FkWs* w, int n3, int n2, int batch) {
   v.partner = a.template take<int32_t>(m3);
   v.start3 = a.template take<int32_t>(batch + 1);
   v.start2 = a.template take<int32_t>(batch + 1);
+  v.bad = a.template take<int32_t>(1);
   v.tiles = a.template take<int>(scan_num_tiles(m3) + 1);
   v.cub_bytes = b3 > b2 ? b3 : b2;
   v.cub = a.template take<char>(v.cub_bytes);
@@ -201,15 +216,20 @@ MSMD_EXPORT int msmd_modality_split_float_keys(const int32_t* idx_3d, int n3,
   if (n3 > 0 && n2 > 0 && (!pair_3d || !pair_2d)) return MSMD_ERR_INVALID_ARG;
   for (int d = 0; d < 3; ++d)
     if (spatial_shape[d] < 1) return MSMD_ERR_INVALID_ARG;
-  // largest key of the grid below 2^26, sample id in the 6 bits above it
-  const double kmax = (spatial_shape[0] - 1) * 1e6 + (spatial_shape[1] - 1) * 1e3 +
-                      (spatial_shape[2] - 1);
-  if (kmax >= (double)(1u << kKeyBits) || batch_size > 64) return MSMD_ERR_RANGE;
+  // largest key of the grid below 2^26 (sample id in the 6 bits above it), in the SAME float32
+  // arithmetic the kernel keys with: a bound evaluated in double can sit just under 2^26 while
+  // the float32 sum (spacing 4 up there) rounds up to it.  volatile: no contraction, no
+  // excess precision on the host.
+  volatile float kmax = (float)(spatial_shape[0] - 1) * 1e6f;
+  kmax = kmax + (float)(spatial_shape[1] - 1) * 1e3f;
+  kmax = kmax + (float)(spatial_shape[2] - 1);
+  if (!(kmax < (float)(1u << kKeyBits)) || batch_size > 64) return MSMD_ERR_RANGE;
   Arena a(workspace, workspace_bytes);
   FkWs w;
   carve_fk(a, &w, n3, n2, batch_size);
   if (!a.ok()) return MSMD_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(w.bad, 0, sizeof(int32_t), st);
   if (sample_stats) hipMemsetAsync(sample_stats, 0, sizeof(int32_t) * 4 * batch_size, st);
   if (n3 == 0 || n2 == 0) {        // nothing can match: flags 0, no pairs, plain counts only
     hipMemsetAsync(n_mixed, 0, sizeof(int32_t), st);
@@ -219,14 +239,18 @@ MSMD_EXPORT int msmd_modality_split_float_keys(const int32_t* idx_3d, int n3,
   int end_bit = kKeyBits;
   while ((1 << (end_bit - kKeyBits)) < batch_size) ++end_bit;
   if (n3 > 0) {
-    MSMD_LAUNCH(fkey_kernel, dim3(ceil_div(n3, 256)), dim3(256), 0, st, idx_3d, n3, w.k3, w.r3);
+    MSMD_LAUNCH(fkey_kernel, dim3(ceil_div(n3, 256)), dim3(256), 0, st, idx_3d, n3, batch_size,
+                spatial_shape[0], spatial_shape[1], spatial_shape[2], reference_offsets ? 1 : 0,
+                w.k3, w.r3, w.bad);
     size_t cb = w.cub_bytes;
     if (hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.k3, w.k3s, w.r3, w.r3s, n3, 0, end_bit,
                                            st) != hipSuccess)
       return MSMD_ERR_LAUNCH;
   }
   if (n2 > 0) {
-    MSMD_LAUNCH(fkey_kernel, dim3(ceil_div(n2, 256)), dim3(256), 0, st, idx_2d, n2, w.k2, w.r2);
+    MSMD_LAUNCH(fkey_kernel, dim3(ceil_div(n2, 256)), dim3(256), 0, st, idx_2d, n2, batch_size,
+                spatial_shape[0], spatial_shape[1], spatial_shape[2], reference_offsets ? 1 : 0,
+                w.k2, w.r2, w.bad);
     size_t cb = w.cub_bytes;
     if (hipcub::DeviceRadixSort::SortPairs(w.cub, cb, w.k2, w.k2s, w.r2, w.r2s, n2, 0, end_bit,
                                            st) != hipSuccess)
@@ -255,5 +279,7 @@ MSMD_EXPORT int msmd_modality_split_float_keys(const int32_t* idx_3d, int n3,
                 EmitPair{w.k3s, w.r3s, w.partner, s3, s2, pair_3d, pair_2d, cap}, n3, w.tiles,
                 n_mixed, -1, st);
   }
+  // a row outside the grid / batch, or (reference_offsets) rows not grouped by sample
+  MSMD_LAUNCH(fkey_report_kernel, dim3(1), dim3(1), 0, st, (const int32_t*)w.bad, n_mixed);
   return launch_status();
 }

@@ -462,7 +462,12 @@ __global__ __launch_bounds__(256) void conv_fill(const int32_t* __restrict__ idx
       out_coord(r.w, kx, g.pd[2], g.st[2], g.shape[2], &x)) {
     o = bitmap_rank(bits, prefix, cell_id(r.x, z, y, x, g.shape));
     if (o < n_out) {
-      nbr_fwd[(size_t)k * n_out + o] = i;  // (k,o) has exactly one source row
+      // (k,o) has exactly one source COORDINATE; when the input set repeats a coordinate
+      // (reference_quirks: a false "mixed" voxel on an only-3D voxel's cell) its LAST row
+      // feeds the output, as in every SubM look-up -- a max instead of a plain store, so the
+      // table does not depend on which of the two threads writes last (result unused: a
+      // fire-and-forget atomic to an address no other thread of the launch touches otherwise)
+      atomicMax(&nbr_fwd[(size_t)k * n_out + o], i);
       ((int4*)out_idx)[o] = make_int4(r.x, z, y, x);  // same value from every writer
     } else {
       o = -1;

@@ -1622,6 +1622,35 @@ MSMD_EXPORT int msmd_spconv_fwd_split_supported(int cin, int cout, int kvol) {
 
 MSMD_EXPORT int msmd_spconv_fwd_split_tile_rows(int cout) { return 32 * fwd_waves(cout); }
 
+// The template arguments dispatch_fwd_split picks for a layer (its first pass; a short last
+// pass of the 4-wave form may run a narrower instantiation): what rocprofv3 prints between
+// the angle brackets of spconv_fwd_split_kernel, so that tools do not re-derive it.
+MSMD_EXPORT int msmd_spconv_fwd_split_instantiation(int cout, int* params /* [7] */) {
+  if (cout < 1 || !params) return MSMD_ERR_INVALID_ARG;
+  const int nt_total = (cout + 15) / 16;
+  const int n_pass = fwd_passes(cout);
+  const int per = (nt_total + n_pass - 1) / n_pass;
+  const int waves = fwd_waves(cout);
+  int nt, ub = 1, nb = 2, pp = 0, tb = 2;
+  if (waves == 8) {
+    nt = per > 8 ? 12 : per > 6 ? 8 : 6;
+    nb = 3;
+    pp = 1;
+    tb = nt == 12 ? 1 : 2;
+  } else {
+    nt = per > 6 ? 8 : per > 4 ? 6 : per > 2 ? 4 : 2;
+    ub = nt == 4 ? 2 : nt == 2 ? 4 : 1;
+  }
+  params[0] = nt;
+  params[1] = ub;
+  params[2] = waves;
+  params[3] = nb;
+  params[4] = pp;
+  params[5] = tb;
+  params[6] = n_pass;
+  return MSMD_OK;
+}
+
 MSMD_EXPORT size_t msmd_spconv_fwd_split_workspace_bytes(int n_out, int cout) {
   return fwd_sk_ws_bytes(n_out, kMaxK, cout);
 }

@@ -21,6 +21,9 @@ are INJECTED: `img_backbone` / `img_neck` may be any nn.Module / callable produc
 multi-scale feature list the reference's FPN yields; without them the detector takes the
 per-scale virtual points directly (`virtual_points=`), which is what bench.py feeds it.
 """
+import logging
+import warnings
+
 import torch
 from torch import nn
 
@@ -180,6 +183,27 @@ class TransFusionDetector(nn.Module):
         return self.extract_pts_feat(points, *extra, prepared=prepared, **kw)
 
 
+_WARNED = {}
+
+
+def _notice_split_mode(reference_quirks):
+    """One line per process and mode, when a detector is built from a config: which
+    voxel_modality_split the unchanged reference config gets here (logger `msmdfusion_amd`,
+    level INFO; the load-time warning above is the loud one)."""
+    key = ("mode", bool(reference_quirks))
+    if _WARNED.get(key):
+        return
+    _WARNED[key] = True
+    logging.getLogger("msmdfusion_amd").info(
+        "MSMDFusionDetector: reference_quirks=%s -- voxel_modality_split uses %s",
+        bool(reference_quirks),
+        "the reference's float32 keys and non-cumulative batch offsets (bit for bit the "
+        "reference, MSMDFusion.py:251-325)" if reference_quirks else
+        "exact integer keys and cumulative batch offsets (differs from the reference where "
+        "its float32 keys alias: z >= 17 or x >= 1000 on the scale-1 grid; set "
+        "reference_quirks=True in the model config to reproduce the reference)")
+
+
 @DETECTORS.register_module()
 class MSMDFusionDetector(TransFusionDetector):
     """LiDAR + camera detector (configs/MSMDFusion_nusc_voxel_LC.py): the LiDAR encoder's
@@ -194,6 +218,7 @@ class MSMDFusionDetector(TransFusionDetector):
         (fusion.SparseFusionPath, INTEGRATION.md)."""
         super().__init__(**kwargs)
         self.reference_quirks = bool(reference_quirks)
+        _notice_split_mode(self.reference_quirks)
         from .bev import SPPModule
         from .image_glue import DepthAwareChannelCompression, ScoreNet
         self.spatial_shapes = [list(s) for s in spatial_shapes]
@@ -222,6 +247,23 @@ class MSMDFusionDetector(TransFusionDetector):
             self.max_cluster_samples_list, self.dist_thresh_list,
             base_voxel_size=self.pts_voxel_layer.voxel_size,
             reference_quirks=self.reference_quirks))
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """A checkpoint trained with the reference has seen the float32-key split's false
+        'mixed' voxels on every frame (MSMDFusion.py:271-272); loading weights into a detector
+        built with reference_quirks=False (the exact-key split) runs them on a different voxel
+        partition than they were trained with.  Said once per process, at load time."""
+        if not self.reference_quirks and not _WARNED.get("load"):
+            _WARNED["load"] = True
+            warnings.warn(
+                "MSMDFusionDetector.load_state_dict: reference_quirks=False -- "
+                "voxel_modality_split keys voxels exactly.  A checkpoint trained with the "
+                "reference (float32 keys: false 'mixed' voxels wherever keys alias, on every "
+                "nuScenes frame at the 0.075 m scale) was trained on a different partition; "
+                "build the detector with reference_quirks=True to reproduce it "
+                "(INTEGRATION.md, 'Which mode reproduces a published checkpoint').",
+                stacklevel=2)
+        return super().load_state_dict(state_dict, *args, **kwargs)
 
     # ---- image side --------------------------------------------------------------------
     def virtual_points_from_images(self, img_feats, img_metas):

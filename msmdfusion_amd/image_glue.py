@@ -164,10 +164,11 @@ def get_foreground2D(img_feats, img_metas, score_net, pack=None, check=True,
     Returns batch_fg_pcd_cams: B tensors [n_b, pts_dim + C], rows in (camera,
     point) order, the C image channels scaled by score_net.
 
-    Default: every sample's channels are scaled.  The reference copies the scaled channels
-    back for samples 0 and 1 only ("only suit for bs = 2", :229-234): identical for B <= 2,
-    the only sizes it trains with; reference_quirks=True reproduces it for larger batches too
-    (samples 2.. keep their unscaled channels)."""
+    Default: every sample's channels are scaled.  The reference scales a torch.cat COPY
+    (:226-228) and copies the scaled channels back for sample 0 always and for sample 1
+    `if B == 2` only ("only suit for bs = 2", :229-234): identical for B <= 2, the only
+    sizes it trains with; reference_quirks=True reproduces it for larger batches too
+    (B >= 3: samples 1.. keep their unscaled channels)."""
     if pack is None:
         pack = pack_foreground(img_metas, img_feats.device)
     downscale = img_feats.shape[-1] / img_metas[0]["input_shape"][-1]
@@ -180,7 +181,7 @@ def get_foreground2D(img_feats, img_metas, score_net, pack=None, check=True,
     scaled = torch.cat([fg[:, :-C], fg[:, -C:] * scores], 1)
     out = list(torch.split(scaled, pack.sample_counts, 0))
     if reference_quirks and len(out) > 2:
-        out[2:] = list(torch.split(fg, pack.sample_counts, 0))[2:]
+        out[1:] = list(torch.split(fg, pack.sample_counts, 0))[1:]
     return out
 
 

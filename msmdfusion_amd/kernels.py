@@ -662,7 +662,7 @@ def rulebook_plan_many(jobs):
 _TILE_COUNTERS = {}
 
 
-_SYNC_INTS = 1 + 8192       # tile counter + one exchange flag per 128-row tile (1 M rows)
+_SYNC_INTS = 1 + 8192       # tile counter + one stream-K exchange flag per workgroup ticket
 
 
 def _tile_counter(device):
@@ -824,6 +824,17 @@ def split_tile_rows(c_out):
     if v is None:
         v = _TILE_ROWS[c_out] = int(lib.msmd_spconv_fwd_split_tile_rows(int(c_out)))
     return v
+
+
+def split_instantiation(c_out):
+    """dict(nt, ub, waves, buffers, pingpong, tables, passes): the template arguments
+    msmd_spconv_fwd_split runs a layer of c_out output channels with (asked of the library:
+    msmd_spconv_fwd_split_instantiation)."""
+    p = (C.c_int * 7)()
+    check(lib.msmd_spconv_fwd_split_instantiation(int(c_out), p),
+          "msmd_spconv_fwd_split_instantiation")
+    return dict(nt=p[0], ub=p[1], waves=p[2], buffers=p[3], pingpong=bool(p[4]), tables=p[5],
+                passes=p[6])
 
 
 def tile_prefix(nbr, rows=TILE_ROWS):
@@ -1433,15 +1444,27 @@ def _modality_split_launch(idx_3d, idx_2d, batch_size, spatial_shape, float_keys
     return mix3, mix2, p3, p2, out, (a, b, ws)
 
 
+def _check_split_count(m):
+    """msmd_modality_split_float_keys reports bad input through a count of -1."""
+    if m < 0:
+        raise ValueError("modality_split(float_keys=True): a voxel row lies outside the grid / "
+                         "the batch, or (reference_offsets) the rows are not grouped by sample "
+                         "in ascending order (include/msmd_hip.h)")
+
+
 def modality_split(idx_3d, idx_2d, batch_size, spatial_shape, float_keys=False,
                    reference_offsets=False):
     """-> (mix3d[n3], mix2d[n2], pair_3d[m], pair_2d[m]).
     float_keys: the reference's float32 keys and two-pointer merge (csrc/modality_float.hip;
     MSMDFusion.py:271-272, 27-45) instead of exact integer keys; reference_offsets: pair rows
-    numbered with the reference's non-cumulative batch offsets (:288-289,313-314)."""
+    numbered with the reference's non-cumulative batch offsets (:288-289,313-314) -- this
+    needs each set's rows grouped by sample in ascending order (what voxelize() returns; the
+    reference selects by mask and has no such requirement, nor has the exact-key path).
+    Rows outside the grid and ungrouped rows raise ValueError (checked on the device)."""
     mix3, mix2, p3, p2, out, _keep = _modality_split_launch(
         idx_3d, idx_2d, batch_size, spatial_shape, float_keys, reference_offsets, False)
     m = int(out[0].item())
+    _check_split_count(m)
     return mix3, mix2, p3[:m], p2[:m]
 
 
@@ -1459,6 +1482,7 @@ def modality_split_many(jobs, batch_size, float_keys=False, reference_offsets=Fa
     res = []
     for (mix3, mix2, p3, p2, _, _), h in zip(pending, host):
         m = h[0]
+        _check_split_count(m)
         stats = dict(c3_plain=h[1:1 + B], c3_mixed=h[1 + B:1 + 2 * B],
                      c2_plain=h[1 + 2 * B:1 + 3 * B], c2_mixed=h[1 + 3 * B:1 + 4 * B])
         res.append((mix3, mix2, p3[:m], p2[:m], stats))

@@ -152,17 +152,23 @@ def _pack_f32(weight, transpose, krsc):
 
 
 def invalidate_packed_weights(weight=None):
-    """Forget the cached packed images -- all of them, or those of one parameter.  Writes
-    through `.data` (mmcv's Fp16OptimizerHook.copy_params_to_fp16, EMAHook's parameter swap,
-    `param.data.copy_` in custom loops) do not move `_version`; call this after them.
-    SparseConvolution calls it from its state-dict load hook and from train() / eval()
-    (EMA swaps sit at those boundaries); distributed.TrainStep calls it when its optimizer
-    is not one of torch's in-place ones."""
+    """Mark the cached packed images stale -- all of them, or those of one parameter: the
+    next conv that uses a weight repacks it (together with every other stale one) INTO THE
+    BUFFERS IT ALREADY HAS.  Writes through `.data` (mmcv's Fp16OptimizerHook.
+    copy_params_to_fp16, which runs every iteration; EMAHook's parameter swap; `param.data.
+    copy_` in custom loops) do not move `_version`: hooks that write that way must call this
+    after the write.  SparseConvolution calls it from its state-dict load hook and from
+    train() / eval() (EMA swaps sit at those boundaries -- a per-epoch or per-iteration
+    toggle costs one pack launch, no allocation); distributed.TrainStep calls it when its
+    optimizer is not one of torch's in-place ones."""
     if weight is None:
-        _PACKS.clear()
-        _F32_PACKS.clear()
+        for e in _PACKS.values():
+            e["version"] = None
+        _F32_PACKS.clear()          # (27 KB images of the 5- / 16-channel layers)
         return
-    _PACKS.pop(id(weight), None)
+    e = _PACKS.get(id(weight))
+    if e is not None:
+        e["version"] = None
     for t in (False, True):
         _F32_PACKS.pop((id(weight), t), None)
 

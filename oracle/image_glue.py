@@ -19,11 +19,14 @@ def foreground_cells(fg_pixels, downscale):
     return cells[:, 1], cells[:, 0]
 
 
-def get_foreground2d(img_feats, metas, w_score, b_score):
+def get_foreground2d(img_feats, metas, w_score, b_score, reference_write_back=False):
     """MSMDFusionDetector.get_foreground2D (MSMDFusion.py:169-238).
     img_feats [B*N, C, H, W]; metas as the reference's img_metas (fg_points entries
     are arrays here); score_net = ReLU(Linear(C+17 -> 1)) with weight w_score
-    [1, C+17], bias b_score [1].  Returns B arrays [n_b, 15 + C]."""
+    [1, C+17], bias b_score [1].  Returns B arrays [n_b, 15 + C].
+    reference_write_back: the scaled channels are computed on a torch.cat COPY
+    (:226-228) and copied back for sample 0 always and for sample 1 `if B == 2` only
+    (:230-234, "only suit for bs = 2"): every other sample keeps its unscaled channels."""
     B = len(metas)
     BN, C, H, W = img_feats.shape
     N = BN // B
@@ -44,7 +47,8 @@ def get_foreground2d(img_feats, metas, w_score, b_score):
             score_in = np.concatenate([fg_feat, depth, np.repeat(trans, pxl.shape[0], 0)], 1)
             score = np.maximum(score_in.astype(np.float32) @ w_score.T.astype(np.float32)
                                + b_score.astype(np.float32), 0)       # :227
-            rows.append(np.concatenate([pts, fg_feat * score], 1))    # :221, :228
+            scaled = b == 0 or (b == 1 and B == 2) or not reference_write_back   # :230-234
+            rows.append(np.concatenate([pts, fg_feat * score if scaled else fg_feat], 1))  # :221, :228
         out.append(np.concatenate(rows, 0).astype(np.float32))
     return out
 

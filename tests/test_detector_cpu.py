@@ -73,3 +73,32 @@ def test_detector_needs_virtual_points_or_images():
     with pytest.raises(ValueError, match="virtual_points"):
         lc.extract_pts_feat([torch.zeros(4, 5)])
     assert lc.extract_img_feat(None, []) is None
+
+
+def test_detector_says_which_modality_split_it_runs(caplog):
+    """The unchanged reference config builds the exact-key split (reference_quirks=False);
+    the detector names the mode once when it is built (logger `msmdfusion_amd`) and warns
+    when weights are loaded into the non-reference mode -- a checkpoint trained with the
+    reference saw the float32 keys' false 'mixed' voxels (MSMDFusion.py:271-272)."""
+    import logging
+    import warnings
+    from msmdfusion_amd import detector as D
+    cfg = {k: v for k, v in FX["MSMDFusion_nusc_voxel_LC"]["model"].items()
+           if k not in ("pts_backbone", "pts_neck")}
+    D._WARNED.clear()
+    with caplog.at_level(logging.INFO, logger="msmdfusion_amd"):
+        plain = D.build_detector(cfg)
+        D.build_detector(cfg)                                   # (once per process and mode)
+        quirks = D.build_detector(dict(cfg, reference_quirks=True))
+    said = [r.getMessage() for r in caplog.records if "reference_quirks" in r.getMessage()]
+    assert len(said) == 2
+    assert "reference_quirks=False" in said[0] and "exact integer keys" in said[0]
+    assert "reference_quirks=True" in said[1] and "float32 keys" in said[1]
+    sd = plain.state_dict()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        quirks.load_state_dict(sd)                              # the reference mode: silent
+        assert not [x for x in w if "reference_quirks" in str(x.message)]
+        plain.load_state_dict(sd)
+        plain.load_state_dict(sd)                               # said once
+        assert len([x for x in w if "reference_quirks=False" in str(x.message)]) == 1

@@ -17,7 +17,7 @@ Tolerances (stated, fp32 against fp32 in another summation order): a single conv
 1e-4 elsewhere (test_gpu_kernels / test_gpu_production); here whole compositions -- up to 21
 conv + BatchNorm layers for the encoder, ~35 for the last fusion stage -- are held to
 2e-4 * (1 + |expected|) element-wise ... measured worst errors are written to
-gpurun_out/r05_workload_parity.txt when that directory exists.
+gpurun_out/r06_workload_parity.txt when that directory exists.
 """
 import os
 
@@ -32,14 +32,16 @@ from test_gpu_modules import OracleSparse, _np, oracle_forward
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOL = 2e-4            # composed layers: |got - exp| <= TOL * (1 + |exp|)
+TOL = 1e-4            # north_star's fp32 bound, composed layers included:
+#                       |got - exp| <= TOL * (1 + |exp|); measured worst case 7.6e-5 (the
+#                       fifth encode_features of configs[1], 21 convs + 21 BatchNorms deep)
 TOL_DW = 1e-4         # weight gradients: of the tensor's largest entry (a sum over ~10^5 pairs)
 
 
 def _record(lines):
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
-        with open(os.path.join(out, "r05_workload_parity.txt"), "a") as f:
+        with open(os.path.join(out, "r06_workload_parity.txt"), "a") as f:
             f.write("\n".join(lines) + "\n")
 
 

@@ -65,6 +65,37 @@ def _random_metas(rng, B, cams, H, W, n_per_cam, dtype=np.float32, n_real=None):
     return metas
 
 
+@pytest.mark.parametrize("B", [1, 2, 3, 4])
+def test_get_foreground2d_reference_write_back(dev, B):
+    """reference_quirks=True: the score-scaled channels reach sample 0 always and sample 1
+    only when B == 2 (MSMDFusion.py:226-234 scales a torch.cat copy and writes back
+    `[0]` and `if B == 2: [1]`); every other sample keeps the unscaled gather.  Against the
+    oracle's transcription of those lines; the default mode scales every sample."""
+    from msmdfusion_amd.image_glue import ScoreNet, get_foreground2D
+    rng = np.random.RandomState(40 + B)
+    cams, H, W = 3, 64, 96
+    metas = _random_metas(rng, B, cams, H, W, 200)
+    feat = rng.randn(B * cams, 49, H // 4, W // 4).astype(np.float32)
+    torch.manual_seed(2)
+    net = ScoreNet().to(dev)
+    with torch.no_grad():
+        net[0].bias.fill_(0.7)
+        f = torch.from_numpy(feat).to(dev)
+        quirk = get_foreground2D(f, metas, net, reference_quirks=True)
+        plain = get_foreground2D(f, metas, net)
+    w, b = net[0].weight.detach().cpu().numpy(), net[0].bias.detach().cpu().numpy()
+    want_q = OI.get_foreground2d(feat, metas, w, b, reference_write_back=True)
+    want_p = OI.get_foreground2d(feat, metas, w, b)
+    raw = OI.get_foreground2d(feat, metas, np.zeros_like(w), np.ones_like(b))
+    for bi in range(B):
+        np.testing.assert_allclose(plain[bi].cpu().numpy(), want_p[bi], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(quirk[bi].cpu().numpy(), want_q[bi], rtol=1e-4, atol=1e-5)
+        if bi == 0 or (bi == 1 and B == 2):
+            assert not np.array_equal(want_q[bi], raw[bi])
+        else:       # the unscaled gather, bit for bit
+            np.testing.assert_array_equal(quirk[bi].cpu().numpy(), raw[bi])
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_get_foreground2d_production_size_vs_oracle(dev, dtype):
     """nuScenes LC shape: 2 samples x 6 cameras, 448x800 input, stride-8 map

@@ -369,10 +369,16 @@ def test_packed_parameter_images_follow_the_optimizer(dev):
     y3 = forward()
     assert not torch.equal(y3, y2) and torch.equal(y3, reference())
     forward()
+    entry = Fsp._PACKS[id(convs[0].weight)]
+    buf = entry["packed"].data_ptr()
     convs[0].weight.data.mul_(2.0)
     convs[0].eval()
     convs[0].train()
-    assert torch.equal(forward(), reference())
+    # the toggle marks the image stale; it is repacked into the allocation it already has
+    assert entry["version"] is None
+    y4 = forward()
+    assert Fsp._PACKS[id(convs[0].weight)] is entry and entry["packed"].data_ptr() == buf
+    assert torch.equal(y4, reference())
 
 
 def test_plan_batch_equals_table_by_table_planning(dev, monkeypatch):

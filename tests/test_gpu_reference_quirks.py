@@ -123,6 +123,23 @@ def test_float_key_split_kernel_edges(dev):
     # a grid whose largest key does not fit 26 bits is refused, not mangled
     with pytest.raises(MsmdError):
         K.modality_split(i3, i3, 1, [80, 1440, 1440], float_keys=True)
+    # ... judged in the kernel's own float32 arithmetic: [68, 109, 863] has its largest key at
+    # 2^26 - 2 in double but exactly 2^26 in float32 (spacing 4 up there, ties to even)
+    with pytest.raises(MsmdError):
+        K.modality_split(i3[:1] * 0, i3[:1] * 0, 1, [68, 109, 863], float_keys=True)
+    # rows outside the grid (negative ones included) are refused on the device
+    for bad_row in ([0, 41, 0, 0], [0, 0, -1, 0], [1, 0, 0, 0]):
+        bad = torch.cat([i3, torch.tensor([bad_row], dtype=torch.int32, device=dev)])
+        with pytest.raises(ValueError):
+            K.modality_split(bad, i3, 1, SHAPE0, float_keys=True)
+        with pytest.raises(ValueError):
+            K.modality_split_many([(i3, bad, SHAPE0)], 1, float_keys=True)
+    # reference_offsets numbers rows inside their sample: ungrouped rows are refused
+    mixed_up = torch.from_numpy(np.concatenate([_aliasing_cloud(rng, 50, 1),
+                                                _aliasing_cloud(rng, 50, 0)])).to(dev)
+    with pytest.raises(ValueError):
+        K.modality_split(mixed_up, mixed_up, 2, SHAPE0, float_keys=True, reference_offsets=True)
+    K.modality_split(mixed_up, mixed_up, 2, SHAPE0, float_keys=True)     # fine without them
     # where the keys cannot alias (z <= 15, x < 1000) both modes agree
     a = S.random_voxel_indices(3000, 2, [16, 300, 300], seed=3)
     b = np.concatenate([a[::3], S.random_voxel_indices(2000, 2, [16, 300, 300], seed=4)])
@@ -262,3 +279,92 @@ def test_reference_batch_offsets_of_the_nearest_voxel_rows(dev):
         assert np.array_equal(ref[rows][hit], local + (c3[b - 1] if b else 0))
         assert np.array_equal(ref[rows][~hit], cum[rows][~hit])
     assert np.array_equal(ref[q[:, 0] < 2], cum[q[:, 0] < 2]) and not np.array_equal(ref, cum)
+
+
+def test_repeated_coordinate_through_subm_sparse_add_and_downscale(dev):
+    """What reference mode can produce on real frames and the stage test above avoids: a false
+    match puts a mixed voxel ON an only-3D voxel's coordinate, so the unified set of a GMA-Conv
+    stage REPEATS a coordinate.  (spconv-2.x's result then depends on which of two racing hash
+    inserts wins; the package is not in the tree.  The in-tree spconv-1.x CPU code,
+    geometry.h:247-297, is input-stationary: both rows scatter into the last row's output and
+    the earlier row's output keeps its centre product only -- yet another answer.)  The
+    documented, deterministic behaviour of this product -- the conv tables are
+    output-stationary, one input row per (output row, offset), and every look-up of a
+    coordinate finds its LAST row -- pinned through the ops such a set meets on its way down
+    the stack, each against the oracle on the equivalent duplicate-free problem:
+
+      * SubM conv == the conv over the set with only the last row of every coordinate kept,
+        its outputs handed to EVERY row of the coordinate (each row gets its own, equal,
+        output; the earlier rows' features are never read);
+      * sparse_add with the previous stage: rows sharing a coordinate are summed (COO add +
+        coalesce, as torch's and spconv's) -- three rows on one coordinate included;
+      * the strided down-scaling conv straight on the repeating set (stage 0 has no
+        sparse_add in front) == the conv over the last rows; after sparse_add the set is
+        duplicate-free and the plain oracle walk applies."""
+    from msmdfusion_amd import spconv
+    from msmdfusion_amd.spconv import functional as Fsp
+    from test_gpu_modules import OracleSparse, oracle_forward
+    rng = np.random.RandomState(21)
+    batch, shape, c = 2, [21, 64, 64], 32
+    base = S.random_voxel_indices(3000, batch, shape, seed=7)
+    twice = rng.choice(base.shape[0], 60, replace=False)       # "only-3D" rows hit again
+    idx = np.concatenate([base, base[twice]]).astype(np.int32)  # ... by later ("mixed") rows
+    n = idx.shape[0]
+    feat = rng.randn(n, c).astype(np.float32)
+    first, last = twice, np.arange(base.shape[0], n)
+    keep = np.setdiff1d(np.arange(n), first)                    # the last row of every coordinate
+    where = {tuple(r): j for j, r in enumerate(idx[keep])}
+    to_kept = np.array([where[tuple(r)] for r in idx])           # row -> its coordinate's kept row
+    torch.manual_seed(3)
+    subm = spconv.SubMConv3d(c, c, 3, padding=1, bias=False).to(dev)
+    down = spconv.SparseConv3d(c, 64, 3, stride=2, padding=1, bias=False).to(dev)
+
+    def tensor(f, i):
+        return spconv.SparseConvTensor(torch.from_numpy(np.ascontiguousarray(f)).to(dev),
+                                       torch.from_numpy(np.ascontiguousarray(i)).to(dev),
+                                       shape, batch)
+    with torch.no_grad():
+        y = subm(tensor(feat, idx))
+        exp_kept = oracle_forward(subm, OracleSparse(feat[keep], idx[keep], shape, batch))
+        assert np.array_equal(_np(y.indices), idx)
+        yf = _np(y.features)
+        np.testing.assert_allclose(yf, exp_kept.feat[to_kept], rtol=1e-4, atol=1e-4)
+        # own output each, the same sums (in another tile: equal to the last bit or two)
+        np.testing.assert_allclose(yf[first], yf[last], rtol=1e-5, atol=1e-6)
+        other = feat.copy()
+        other[first] = rng.randn(first.shape[0], c)             # the earlier rows are never read
+        assert torch.equal(subm(tensor(other, idx)).features, y.features)
+        later = feat.copy()
+        later[last] += 1.0                                      # ... the last rows are
+        assert not torch.equal(subm(tensor(later, idx)).features, y.features)
+
+        # sparse_add with a previous-stage tensor that shares some of those coordinates
+        prev_idx = np.concatenate([base[twice[:20]], base[rng.choice(base.shape[0], 500, False)],
+                                   S.random_voxel_indices(800, batch, shape, seed=8)])
+        prev_idx = prev_idx[np.sort(np.unique(prev_idx, axis=0, return_index=True)[1])].astype(np.int32)
+        prev = rng.randn(prev_idx.shape[0], c).astype(np.float32)
+        z = Fsp.sparse_add(y, tensor(prev, prev_idx))
+        ei, ef, _, _ = O.sparse_add(yf, idx, prev, prev_idx, shape)
+        assert np.array_equal(_np(z.indices), ei)
+        assert np.unique(ei, axis=0).shape[0] == ei.shape[0]     # the union repeats nothing
+        np.testing.assert_allclose(_np(z.features), ef, rtol=1e-5, atol=1e-5)
+        key = {tuple(r): j for j, r in enumerate(ei)}
+        for a, b_ in zip(first[:20], last[:20]):                # three rows on one coordinate
+            p = np.where((prev_idx == idx[a]).all(1))[0][0]
+            np.testing.assert_allclose(_np(z.features)[key[tuple(idx[a])]],
+                                       yf[a] + yf[b_] + prev[p], rtol=1e-5, atol=1e-5)
+
+        # the down-scaling conv after the union: plain oracle walk
+        got = down(z)
+        exp = oracle_forward(down, OracleSparse(ef, ei, shape, batch))
+        assert np.array_equal(_np(got.indices), exp.idx)
+        np.testing.assert_allclose(_np(got.features), exp.feat, rtol=1e-4, atol=1e-4)
+        # ... and straight on the repeating set: the last row of a coordinate feeds its outputs
+        got = down(tensor(yf, idx))
+        exp = oracle_forward(down, OracleSparse(yf[keep], idx[keep], shape, batch))
+        assert np.array_equal(_np(got.indices), exp.idx)
+        np.testing.assert_allclose(_np(got.features), exp.feat, rtol=1e-4, atol=1e-4)
+        moved = yf.copy()
+        moved[first] += 1.0        # (yf[first] == yf[last] so far: now the two rows differ)
+        for _ in range(3):         # the earlier rows are not read -- whichever thread fills last
+            assert torch.equal(down(tensor(moved, idx)).features, got.features)

@@ -8,6 +8,10 @@ for wl in lc transfusion_l; do
   P=$G/prof_$wl
   [ -d $P ] || continue
   cp $P/kernel_stats.csv profiles/${R}_${wl}_kernel_stats.csv
+  # the commit the profiled tree was at (bench.py's roofline.rocprof_head; the GPU box has no
+  # .git): the tree as it is NOW -- commit before profiling, copy before editing
+  echo "$(git rev-parse --short=12 HEAD)$(git diff --quiet HEAD -- msmdfusion_amd bench.py || echo -dirty)" \
+    > profiles/${R}_${wl}_kernel_stats.head
   cp $P/summary.txt profiles/${R}_${wl}_kernel_summary.txt
   cp $P/stream_summary.txt profiles/${R}_${wl}_stream_summary.txt
   grep "^{" $P/bench.json | tail -1 > profiles/${R}_${wl}_bench_under_rocprof.json
