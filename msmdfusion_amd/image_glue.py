@@ -16,6 +16,8 @@ them, because their output goes straight into `voxelize`, which is
 "unused parameters" (configs/MSMDFusion_nusc_voxel_LC.py:309 sets
 find_unused_parameters=True for that reason).
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -200,6 +202,9 @@ def sparse_depth_canvas(img_metas, H, W, device, pack=None, check=True):
     return canvas.view(planes, 1, H, W)
 
 
+_GLUE_NHWC = int(os.environ.get("MSMD_GLUE_NHWC", "1"))
+
+
 class DepthAwareChannelCompression(nn.Module):
     """conv1x1_blocks of MSMDFusionDetector (MSMDFusion.py:106-123): three
     Conv2d(256+1 -> 49, k 5/5/3, bias=False) + BN2d(eps 1e-3, momentum 0.01) +
@@ -221,10 +226,28 @@ class DepthAwareChannelCompression(nn.Module):
         H, W = img_metas[0]["pad_shape"][:2]
         canvas = sparse_depth_canvas(img_metas, H, W, feat_list[0].device, pack, check)
         out = []
+        # Memory format of the compressed maps.  get_foreground2D's gather reads, per virtual
+        # point, the C = 49 channels of ONE pixel: 49 floats H*W*4 bytes apart in an NCHW map
+        # (49 separate sectors per point), 196 contiguous bytes in a pixel-major
+        # (channels-last) one.  MSMD_GLUE_NHWC: 1 (default) = NCHW convs + ONE conversion pass
+        # per map, 0 = NCHW maps as in rounds 2-5, 2 = the block itself channels-last.
+        # Measured (MI355X, lc_img, profiles/r06_image_glue_formats.txt): gather on the 112 x
+        # 200 / 56 x 100 / 28 x 50 maps 75.5 / 39.3 / 31.7 us (0.13 / 0.25 / 0.31 of HBM) ->
+        # 24.9 / 24.0 / 22.4 us (0.40 / 0.41 / 0.44) with pixel-major maps; whole glue 5.21 ->
+        # 5.02 ms, step 106.1 -> 110.0 samples/s; MIOpen's fp32 NHWC kernels (mode 2) take
+        # 7.10 ms for the three blocks (101.6 samples/s).  Same values in any format
+        # (K.fg_gather takes the map's strides).
+        mode = _GLUE_NHWC
         for i, block in enumerate(self.conv1x1_blocks):
             feat = feat_list[i]
             depth = F.interpolate(canvas, feat.shape[-2:], mode="bilinear")
-            out.append(block(torch.cat([feat, depth], 1)))
+            x = torch.cat([feat, depth], 1)
+            if mode == 2:
+                x = x.contiguous(memory_format=torch.channels_last)
+            y = block(x)
+            if mode >= 1:
+                y = y.contiguous(memory_format=torch.channels_last)
+            out.append(y)
         return out
 
 
