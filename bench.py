@@ -298,6 +298,16 @@ def image_glue_kernel_times(model, batch, reps=10):
             out["fg_gather"].append({"map": list(f.shape), "points": int(n), "us": round(ms * 1e3, 1),
                                      "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
                                      "frac_hbm": round(nbytes / (ms * 1e-3) / 1e12 / HBM_PEAK_TBPS, 4)})
+            # the launch the step actually makes (no gradient: gather + score_net + scaling
+            # fused, msmd_fg_gather_scored_f32): per point C floats read + one row written
+            lin = det.score_net[0]
+            ms = timed(lambda: K.fg_gather_scored(f, pack.pixels, pack.plane, ds, pack.points,
+                                                  pack.lidar2img, lin.weight, lin.bias))
+            nbytes = n * 4 * (c + 3 + 15 + (15 + c) + 1)
+            out.setdefault("fg_gather_scored", []).append(
+                {"map": list(f.shape), "points": int(n), "us": round(ms * 1e3, 1),
+                 "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                 "frac_hbm": round(nbytes / (ms * 1e-3) / 1e12 / HBM_PEAK_TBPS, 4)})
     return out
 
 

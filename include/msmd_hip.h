@@ -583,6 +583,22 @@ int msmd_fg_gather_f32(const float* img_feat, const int64_t* strides,
                        int pts_dim, const float* lidar2img /* [planes,16] */,
                        int n, float* fg_pcd, float* score_in, int32_t* cells,
                        int32_t* n_bad, msmd_stream_t stream);
+/* The same gather with get_foreground2D's tail folded in, for the no-gradient case (the
+ * reference's own training step: the result feeds voxelize(), which is @torch.no_grad(),
+ * MSMDFusion.py:462): score = ReLU([feat | depth | lidar2img[plane]] . score_weight +
+ * score_bias) (score_net = Linear(c + 17, 1) + ReLU, :125-128, :225-227) and
+ *   fg_pcd [n, pts_dim + c] = [pts | feat * score]   for points [0, n_scaled),
+ *                             [pts | feat]           for the rest (:229-234 copies the
+ * scaled channels back for sample 0, and sample 1 when B == 2, only: reference_quirks).
+ * score_in is never materialised.  c <= 64.  The dot product is summed in a fixed order. */
+int msmd_fg_gather_scored_f32(const float* img_feat, const int64_t* strides,
+                              int planes, int c, int h, int w, const void* pixels,
+                              int pixel_is_f64, const int32_t* plane /* [n] */,
+                              double downscale, const float* pts /* [n,pts_dim] */,
+                              int pts_dim, const float* lidar2img /* [planes,16] */,
+                              const float* score_weight /* [c + 17] */,
+                              const float* score_bias /* [1] */, int n, int n_scaled,
+                              float* fg_pcd, int32_t* n_bad, msmd_stream_t stream);
 /* grad_img[plane, :, h, w] += grad[i, col0 : col0 + c]   (atomic fp32 adds: the
  * order, hence the last bit, is not fixed -- as index_put(accumulate) on a GPU) */
 int msmd_fg_scatter_add_f32(const float* grad, int grad_stride, int col0,

@@ -106,6 +106,8 @@ SIGNATURES = {
     "msmd_bev_gather_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _ip, _vp, _i, _i, _vp]),
     "msmd_fg_gather_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, C.c_double, _vp, _i, _vp, _i,
                                 _vp, _vp, _vp, _vp, _vp]),
+    "msmd_fg_gather_scored_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, C.c_double, _vp, _i, _vp,
+                                       _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "msmd_fg_scatter_add_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "msmd_depth_canvas_workspace_bytes": (_sz, [_i, _i, _i]),
     "msmd_boxes_overlap_bev_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp]),

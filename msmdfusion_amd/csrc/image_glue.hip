@@ -71,6 +71,56 @@ __global__ __launch_bounds__(256) void fg_gather_kernel(
   }
 }
 
+// The inference form of get_foreground2D's whole tail (MSMDFusion.py:213-228): gather, the
+// score_net row [feat | depth | lidar2img] . w + b, ReLU, and fg_pcd = [pts | feat * score]
+// in ONE pass -- score_in (264 B per point written, read back by the Linear, and the cat /
+// multiply passes over fg_pcd after it) never exists.  Points [0, n_scaled) are scaled, the
+// rest keep the plain gather (reference_quirks: :229-234 writes the scaled channels back for
+// sample 0 -- and 1 when B == 2 -- only).  16 lanes per point; the 66-term dot product is
+// summed per lane over its channels (c = sub, sub + 16, ...), then across the 16 lanes by
+// xor-shuffles: a fixed order, fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void fg_gather_scored_kernel(
+    const float* __restrict__ img, Strides4 st, int P, int C, int H, int W,
+    const T* __restrict__ pix, const int32_t* __restrict__ plane, double scale,
+    const float* __restrict__ pts, int pts_dim, const float* __restrict__ lidar2img,
+    const float* __restrict__ sw /* [C + 17] */, const float* __restrict__ sb /* [1] */,
+    int n, int n_scaled, float* __restrict__ fg_pcd, int* __restrict__ bad) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int i = (int)(t >> 4), sub = (int)(t & 15);
+  const bool live = i < n;
+  const int ii = live ? i : 0;
+  const int pl = live ? plane[ii] : 0;
+  long w = wrap_index(cell_of_pixel(pix[(size_t)ii * 3 + 0], scale), W);
+  long h = wrap_index(cell_of_pixel(pix[(size_t)ii * 3 + 1], scale), H);
+  const bool ok = live && pl >= 0 && pl < P && w >= 0 && h >= 0;
+  if (live && !ok && sub == 0) atomicAdd(bad, 1);
+  const float* src = img + (ok ? pl * st.p + h * st.h + w * st.w : 0);
+  float v[4];           // C <= 64: this lane's channels sub, sub + 16, sub + 32, sub + 48
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = sub + 16 * q;
+    v[q] = (ok && c < C) ? src[c * st.c] : 0.f;
+    acc = (c < C) ? fmaf(v[q], sw[c], acc) : acc;
+  }
+  if (sub == 0) acc = fmaf((float)pix[(size_t)ii * 3 + 2], sw[C], acc);
+  const float m = (pl >= 0 && pl < P) ? lidar2img[(size_t)pl * 16 + sub] : 0.f;
+  acc = fmaf(m, sw[C + 1 + sub], acc);
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 16);
+  float score = fmaxf(acc + sb[0], 0.f);
+  if (i >= n_scaled) score = 1.f;
+  if (!live) return;
+  float* o0 = fg_pcd + (size_t)i * (pts_dim + C);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = sub + 16 * q;
+    if (c < C) o0[pts_dim + c] = i < n_scaled ? v[q] * score : v[q];
+  }
+  for (int c = sub; c < pts_dim; c += 16) o0[c] = pts[(size_t)i * pts_dim + c];
+}
+
 // grad_img[plane,c,h,w] += grad[i, col0 + c]   (cells from the forward)
 __global__ __launch_bounds__(256) void fg_scatter_add_kernel(
     const float* __restrict__ grad, int grad_stride, int col0, const int32_t* __restrict__ cells,
@@ -166,6 +216,36 @@ MSMD_EXPORT int msmd_fg_gather_f32(const float* img_feat, const int64_t* strides
     MSMD_LAUNCH(fg_gather_kernel<float>, dim3(grid), dim3(256), 0, st, img_feat, s, planes, c, h,
                 w, (const float*)pixels, plane, downscale, pts, pts_dim, lidar2img, n, fg_pcd,
                 score_in, cells, n_bad);
+  return launch_status();
+}
+
+MSMD_EXPORT int msmd_fg_gather_scored_f32(const float* img_feat, const int64_t* strides, int planes,
+                                          int c, int h, int w, const void* pixels,
+                                          int pixel_is_f64, const int32_t* plane,
+                                          double downscale, const float* pts, int pts_dim,
+                                          const float* lidar2img, const float* score_weight,
+                                          const float* score_bias, int n, int n_scaled,
+                                          float* fg_pcd, int32_t* n_bad, msmd_stream_t stream) {
+  if (n < 0 || planes < 1 || c < 1 || c > 64 || h < 1 || w < 1 || pts_dim < 0 ||
+      !strides_ok(strides) || !n_bad || n_scaled < 0)
+    return MSMD_ERR_INVALID_ARG;
+  if ((double)planes * h * w >= 2147483647.0) return MSMD_ERR_RANGE;
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(n_bad, 0, sizeof(int32_t), st);
+  if (n == 0) return MSMD_OK;
+  if (!img_feat || !pixels || !plane || !lidar2img || !fg_pcd || !score_weight || !score_bias ||
+      (pts_dim && !pts))
+    return MSMD_ERR_INVALID_ARG;
+  Strides4 s{strides[0], strides[1], strides[2], strides[3]};
+  const int grid = ceil_div((long)n * 16, 256);
+  if (pixel_is_f64)
+    MSMD_LAUNCH(fg_gather_scored_kernel<double>, dim3(grid), dim3(256), 0, st, img_feat, s, planes,
+                c, h, w, (const double*)pixels, plane, downscale, pts, pts_dim, lidar2img,
+                score_weight, score_bias, n, n_scaled, fg_pcd, n_bad);
+  else
+    MSMD_LAUNCH(fg_gather_scored_kernel<float>, dim3(grid), dim3(256), 0, st, img_feat, s, planes,
+                c, h, w, (const float*)pixels, plane, downscale, pts, pts_dim, lidar2img,
+                score_weight, score_bias, n, n_scaled, fg_pcd, n_bad);
   return launch_status();
 }
 

@@ -178,6 +178,22 @@ def get_foreground2D(img_feats, img_metas, score_net, pack=None, check=True,
     if img_feats.shape[0] != pack.batch_size * pack.cameras:
         raise ValueError("img_feats has %d maps for %d samples x %d cameras"
                          % (img_feats.shape[0], pack.batch_size, pack.cameras))
+    lin = score_net[0] if isinstance(score_net, nn.Sequential) and len(score_net) == 2 else None
+    if (_FG_FUSED and not torch.is_grad_enabled() and isinstance(lin, nn.Linear)
+            and isinstance(score_net[1], nn.ReLU) and lin.out_features == 1
+            and lin.bias is not None and lin.in_features == C + 17 and C <= 64):
+        # no gradient wanted (the training step itself: this feeds voxelize(), which is
+        # @torch.no_grad(), MSMDFusion.py:462): gather, score_net and the scaling in one launch
+        n_scaled = None
+        if reference_quirks and pack.batch_size > 2:        # :229-234: sample 0 only
+            n_scaled = pack.sample_counts[0]
+        fg, bad = K.fg_gather_scored(img_feats.float(), pack.pixels, pack.plane, downscale,
+                                     pack.points, pack.lidar2img, lin.weight, lin.bias, n_scaled)
+        if isinstance(check, list):
+            check.append((bad, "get_foreground2D"))
+        elif check:
+            _raise_if_bad(bad, "get_foreground2D")
+        return list(torch.split(fg, pack.sample_counts, 0))
     fg, score_in = _ForegroundGather.apply(img_feats.float(), pack, downscale, check)
     scores = score_net(score_in)                             # [n,1], Linear(66,1)+ReLU
     scaled = torch.cat([fg[:, :-C], fg[:, -C:] * scores], 1)
@@ -202,6 +218,7 @@ def sparse_depth_canvas(img_metas, H, W, device, pack=None, check=True):
     return canvas.view(planes, 1, H, W)
 
 
+_FG_FUSED = os.environ.get("MSMD_FG_FUSED", "1") == "1"
 _GLUE_NHWC = int(os.environ.get("MSMD_GLUE_NHWC", "1"))
 
 

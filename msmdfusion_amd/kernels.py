@@ -1140,6 +1140,39 @@ def fg_gather(img_feat, pixels, plane, downscale, pts, lidar2img, want_cells=Tru
     return fg, sc, cells, bad
 
 
+def fg_gather_scored(img_feat, pixels, plane, downscale, pts, lidar2img, score_weight,
+                     score_bias, n_scaled=None):
+    """get_foreground2D without gradients, one launch: -> (fg_pcd [n, pts_dim+C] = [pts |
+    feat * ReLU(score_net row)] for the first n_scaled points (default all), [pts | feat]
+    for the rest; n_bad [1]).  score_weight [C+17] (or [1, C+17]), score_bias [1]."""
+    _need_cuda(img_feat, pixels, plane, pts, lidar2img, score_weight, score_bias)
+    if img_feat.dim() != 4 or img_feat.dtype != torch.float32:
+        raise ValueError("img_feat must be float32 [planes, C, H, W]")
+    px, is64 = _pixels(pixels)
+    n = px.shape[0]
+    planes, c, h, w = img_feat.shape
+    pts = pts.contiguous().float()
+    if pts.shape[0] != n or plane.shape[0] != n:
+        raise ValueError("pixels / points / plane ids disagree on the number of points")
+    l2i = lidar2img.contiguous().float().view(-1, 16)
+    if l2i.shape[0] != planes:
+        raise ValueError("need one 4x4 lidar2img per (sample, camera) plane")
+    sw = score_weight.detach().contiguous().float().view(-1)
+    sb = score_bias.detach().contiguous().float().view(-1)
+    if sw.numel() != c + 17 or sb.numel() != 1:
+        raise ValueError("score_net is Linear(%d, 1): got weight %s, bias %s"
+                         % (c + 17, tuple(score_weight.shape), tuple(score_bias.shape)))
+    dev = img_feat.device
+    fg = torch.empty((n, pts.shape[1] + c), dtype=torch.float32, device=dev)
+    bad = torch.empty((1,), dtype=torch.int32, device=dev)
+    check(lib.msmd_fg_gather_scored_f32(_p(img_feat), _strides4(img_feat), planes, c, h, w, _p(px),
+                                        is64, _p(plane.contiguous().int()), float(downscale),
+                                        _p(pts), int(pts.shape[1]), _p(l2i), _p(sw), _p(sb), n,
+                                        n if n_scaled is None else int(n_scaled), _p(fg), _p(bad),
+                                        _stream()), "msmd_fg_gather_scored_f32")
+    return fg, bad
+
+
 def fg_scatter_add(grad, col0, c, cells, like):
     """Backward of fg_gather w.r.t. the feature map: zeros_like(like) + scatter."""
     _need_cuda(grad, cells, like)

@@ -96,6 +96,49 @@ def test_get_foreground2d_reference_write_back(dev, B):
             np.testing.assert_array_equal(quirk[bi].cpu().numpy(), raw[bi])
 
 
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_fused_scored_gather_equals_the_op_chain(dev, layout, monkeypatch):
+    """msmd_fg_gather_scored_f32 (no-gradient path: gather + score_net + scaling in one launch)
+    == the differentiable chain gather -> Linear + ReLU -> cat / multiply: point block and
+    channels of a zero score bit for bit, scaled channels to fp32 rounding of the 66-term dot
+    product; bad pixels counted the same; n_scaled leaves the tail unscaled."""
+    from msmdfusion_amd import image_glue as G
+    from msmdfusion_amd import kernels as K
+    rng = np.random.RandomState(77)
+    B, cams, H, W = 3, 4, 96, 160
+    metas = _random_metas(rng, B, cams, H, W, 700)
+    feat = torch.from_numpy(rng.randn(B * cams, 49, H // 4, W // 4).astype(np.float32)).to(dev)
+    if layout == "nhwc":
+        feat = feat.contiguous(memory_format=torch.channels_last)
+    torch.manual_seed(4)
+    net = G.ScoreNet().to(dev)
+    with torch.no_grad():
+        net[0].bias.fill_(0.3)
+        pack = G.pack_foreground(metas, dev)
+        fused = G.get_foreground2D(feat, metas, net, pack=pack)
+        monkeypatch.setattr(G, "_FG_FUSED", False)
+        chain = G.get_foreground2D(feat, metas, net, pack=pack)
+        monkeypatch.setattr(G, "_FG_FUSED", True)
+        for a, b in zip(fused, chain):
+            assert a.shape == b.shape and torch.equal(a[:, :15], b[:, :15])
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+            zero = (b[:, 15:] == 0).all(1)                   # ReLU cut the score to 0
+            assert torch.equal(a[zero], b[zero])
+        assert sum(int(((b[:, 15:] == 0).all(1)).sum()) for b in chain) > 10
+        # n_scaled: the tail keeps the plain gather
+        n0 = pack.sample_counts[0]
+        part, bad = K.fg_gather_scored(feat, pack.pixels, pack.plane, 0.25, pack.points,
+                                       pack.lidar2img, net[0].weight, net[0].bias, n_scaled=n0)
+        raw = K.fg_gather(feat, pack.pixels, pack.plane, 0.25, pack.points, pack.lidar2img)[0]
+        assert int(bad) == 0
+        assert torch.equal(part[n0:], raw[n0:])
+        torch.testing.assert_close(part[:n0], torch.cat(chain)[:n0], rtol=1e-5, atol=1e-6)
+        # an out-of-map pixel is counted (and raises through the module path)
+        metas[1]["foreground2D_info"]["fg_pixels"][2][5, 0] = W + 40.0
+        with pytest.raises(IndexError):
+            G.get_foreground2D(feat, metas, net)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_get_foreground2d_production_size_vs_oracle(dev, dtype):
     """nuScenes LC shape: 2 samples x 6 cameras, 448x800 input, stride-8 map
