@@ -573,6 +573,17 @@ def run_workload(workload, args, dev, rank, world, profile):
         calls[0] += 1
         return train_step(b)
     step.prime = train_step.prime
+    # experiment (MSMD_CU_PARTITION="i,s"): the feature pass on the CUs the index / search
+    # streams do not own -- this thread's current stream becomes a CU-masked one
+    from msmdfusion_amd.prefetch import cu_partition, masked_stream
+    part = cu_partition()
+    if part is not None and sum(part) > 0 and not getattr(run_workload, "_masked_main", None):
+        run_workload._masked_main = masked_stream(dev, range(sum(part), 256))
+    main_ctx = torch.cuda.stream(run_workload._masked_main) \
+        if getattr(run_workload, "_masked_main", None) is not None else None
+    if main_ctx is not None:
+        torch.cuda.synchronize()
+        main_ctx.__enter__()
     step.prime(batch)
 
     # Setup, untimed: let torch's caching allocator reach its steady state before
@@ -619,6 +630,8 @@ def run_workload(workload, args, dev, rank, world, profile):
     D.barrier()
     elapsed = time.perf_counter() - t0
     K.PROFILE = None
+    if main_ctx is not None:
+        main_ctx.__exit__(None, None, None)
     elapsed = D.global_max(elapsed, device=dev)
     assert torch.isfinite(loss).item()
     # untimed sanity step: every parameter and every gradient of the trained modules is

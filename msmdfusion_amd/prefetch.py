@@ -33,7 +33,55 @@ def side_stream(device, priority=-1, slot=0):
            int(priority), int(slot))
     s = _SIDE_STREAMS.get(key)
     if s is None:
-        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
+        cus = cu_partition()
+        if cus is not None and cus[0 if slot < 8 else 1] > 0:
+            # experiment (MSMD_CU_PARTITION): the index / search queues
+            # on CUs of their own -- [0, index CUs) for the prefetcher's slots, the next
+            # `search CUs` for the neighbour-search slots (8..11)
+            lo = 0 if slot < 8 else cus[0]
+            s = masked_stream(device, range(lo, lo + cus[0 if slot < 8 else 1]))
+        else:
+            s = torch.cuda.Stream(device=device, priority=priority)
+        _SIDE_STREAMS[key] = s
+    return s
+
+
+def cu_partition():
+    """MSMD_CU_PARTITION="i,s": CUs given to the index stream(s) and to the neighbour-search
+    streams (either may be 0 = unmasked, high priority as usual); None when unset."""
+    import os
+    v = os.environ.get("MSMD_CU_PARTITION")
+    if not v:
+        return None
+    a = [int(x) for x in v.split(",")]
+    return (a[0], a[1] if len(a) > 1 else 0)
+
+
+_HIP = None
+_MASKED = []      # (handle, ExternalStream): kept alive for the life of the process
+
+
+def masked_stream(device, cu_bits, total_cus=256):
+    """A stream whose kernels run on the given CUs only (hipExtStreamCreateWithCUMask).  Bit i
+    of the mask is CU i / 8 of XCD i % 8 on MI300-class parts (the driver deals the mask's bits
+    round robin over the XCDs), so a contiguous range of bits is spread evenly over the eight
+    XCDs.  Default priority (the extension has no priority argument)."""
+    import ctypes as C
+    global _HIP
+    device = torch.device(device)
+    if _HIP is None:
+        _HIP = C.CDLL("libamdhip64.so")      # the runtime torch has loaded already
+    words = (total_cus + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for b in cu_bits:
+        mask[b // 32] |= 1 << (b % 32)
+    handle = C.c_void_p()
+    with torch.cuda.device(device):
+        rc = _HIP.hipExtStreamCreateWithCUMask(C.byref(handle), C.c_uint32(words), mask)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    s = torch.cuda.ExternalStream(handle.value, device=device)
+    _MASKED.append((handle, s))
     return s
 
 
