@@ -40,7 +40,7 @@ def ref64(f, w, nbr):
     return out
 
 
-def lc_b2(reps=10, sampled_steps=5):
+def lc_b2(reps=10, sampled_steps=5, tail=False):
     """Every conv launch of one LC training step at its B = 2 shape: (a) replayed ALONE on
     an otherwise idle chip (kernels.CAPTURE keeps each launch's closure), (b) inside the
     pipelined step (index prefetch + neighbour search on their own queues, as bench.py runs
@@ -58,12 +58,12 @@ def lc_b2(reps=10, sampled_steps=5):
     torch.manual_seed(0)
     spg = bench.WORKLOADS["lc"]["spg"]
     ids = list(range(spg))
-    model = bench.FusionBackbone().to(dev).train()
+    model = (bench.FusionTailBackbone() if tail else bench.FusionBackbone()).to(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
     batch = ([torch.from_numpy(S.lidar_sweep(i)).to(dev) for i in ids],
              [torch.from_numpy(S.virtual_points(i)).to(dev) for i in ids])
-    target = torch.randn(spg, 640, 180, 180, device=dev).contiguous(
+    target = torch.randn(spg, 512 if tail else 640, 180, 180, device=dev).contiguous(
         memory_format=torch.channels_last)
     loss_fn = lambda bev: bench.mean_of_product(bev, target)    # noqa: E731
     plain = D.TrainStep(model, params, opt, loss_fn, None, 10.0)
@@ -151,9 +151,11 @@ def main():
     ap.add_argument("--lc", action="store_true", help="the fusion stack's channel widths")
     ap.add_argument("--lc-b2", action="store_true",
                     help="every conv launch of the LC step alone vs inside the pipelined step")
+    ap.add_argument("--tail", action="store_true",
+                    help="with --lc-b2: the step with the dense BEV tail (row f1) behind it")
     args = ap.parse_args()
     if args.lc_b2:
-        return lc_b2()
+        return lc_b2(tail=args.tail)
     import torch
     import torch.nn.functional as F
     from msmdfusion_amd import kernels as K
