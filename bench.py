@@ -715,22 +715,44 @@ def main():
                         "device_schedule_flags": sched_flags},
                "config": head["config"],
                "roofline": head["roofline"]}
-        if "image_glue" in head:
-            out["image_glue"] = head["image_glue"]
+        for extra in ("image_glue", "modality_split"):
+            if extra in head:
+                out[extra] = head[extra]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            out["cpu_baseline"] = cpu_baseline(
+                args.workload, budget_s=float(os.environ.get("MSMD_BENCH_CPU_BUDGET", "14.0")))
     if world == 1 and not args.no_also and args.workload == "lc":
         # secondary lines: a leg that fails reports its error instead of costing the headline
         out["also"] = {}
 
         def leg(key, wl, profile=False, dtype=None, cpu=False):
+            """One secondary workload in a process of its own (this script again, `--workload
+            wl --no-also`): what an earlier leg leaves behind in the process -- allocator
+            pools, cached dense-grid tables, worker threads, packed-weight images -- costs the
+            later B = 2 legs up to 20 % (round 6: the same leg read 214, 194 or 174 samples/s
+            depending on how many legs had run before it; 205-213 in a fresh process), so
+            every line is measured the way the headline is: first in its process."""
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--no-also",
+                   "--steps", str(args.steps), "--warmup", str(args.warmup)]
+            if not profile:
+                cmd.append("--no-profile")
+            if not cpu:
+                cmd.append("--no-cpu-baseline")
+            env = dict(os.environ, MSMD_BENCH_CPU_BUDGET="8.0")
             try:
-                r = run_workload(wl, args, dev, rank, world, profile)
-                r["metric"] = WORKLOADS[wl]["metric"]
+                p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                   text=True, timeout=900)
+                sys.stderr.write(p.stderr[-4000:])
+                lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+                if p.returncode != 0 or not lines:
+                    raise RuntimeError("exit code %d: %s" % (p.returncode, p.stderr[-300:]))
+                d = json.loads(lines[-1])
+                r = {k: d[k] for k in ("value", "unit", "ms_per_step", "config", "roofline",
+                                       "metric", "image_glue", "modality_split", "cpu_baseline")
+                     if k in d}
                 if dtype:
                     r["dtype"] = dtype
-                if cpu:
-                    r["cpu_baseline"] = cpu_baseline(wl, budget_s=8.0)
             except Exception as e:      # noqa: BLE001 -- reported in the JSON line
                 r = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
                 print("[bench] also[%s] failed: %s" % (key, r["error"]), file=sys.stderr)
@@ -738,7 +760,6 @@ def main():
 
         leg("configs[1]", "transfusion_l", profile=not args.no_profile, cpu=not args.no_cpu_baseline)
         if os.environ.get("MSMD_BENCH_TAIL", "1") == "1":
-            leg("configs[2] reference_quirks", "lc_quirks")
             leg("configs[2]+image glue", "lc_img")
             leg("configs[2]+f1", "lc_tail")
             leg("configs[2]+f1+f3", "lc_full")
@@ -764,6 +785,9 @@ def main():
                 leg("configs[2] @ 4/GPU two bf16 planes", "lc_b4", dtype=two)
             finally:
                 os.environ.pop("MSMD_CONV_PLANES", None)
+            # the reference-exact mode (float32-key modality split + the reference's batch
+            # offsets): the headline step with reference_quirks=True, and the split alone
+            leg("configs[2] reference_quirks", "lc_quirks")
     if rank == 0:
         print(json.dumps(out))
     D.shutdown()
