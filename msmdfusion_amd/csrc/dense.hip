@@ -317,8 +317,8 @@ static int modality_split_impl(const int32_t* idx_3d, int n3, const int32_t* idx
   carve_set(a, &w, batch_size, spatial_shape, true);
   if (!a.ok()) return MSMD_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(w.bits, 0, sizeof(uint32_t) * w.words, st);
-  hipMemsetAsync(w.bits2, 0, sizeof(uint32_t) * w.words, st);
+  // (the two bitmaps lie next to each other in the arena: one fill)
+  hipMemsetAsync(w.bits, 0, (size_t)((char*)(w.bits2 + w.words) - (char*)w.bits), st);
   if (stats) hipMemsetAsync(stats, 0, sizeof(int32_t) * 4 * batch_size, st);
   if (n3 > 0)
     MSMD_LAUNCH(mark_rows, dim3(ceil_div(n3, 256)), dim3(256), 0, st, idx_3d, n3, sh,

@@ -30,7 +30,8 @@ namespace msmd {
 namespace {
 
 constexpr uint32_t kNoCell = 0xFFFFFFFFu;
-constexpr int kNoPoint = 0x7F7F7F7F;  // hipMemsetAsync(0x7F) pattern
+constexpr uint32_t kNoPoint = 0xFFFFFFFFu;  // the 0xFF fill the hash table takes too: ONE memset
+                                            // covers both (point indices compare as unsigned)
 
 struct VoxGeom {
   float vs[3], lo[3];
@@ -40,9 +41,11 @@ struct VoxGeom {
 __global__ __launch_bounds__(256) void vox_insert(const float* __restrict__ points, int n, int c,
                                                   VoxGeom g, uint32_t* __restrict__ key,
                                                   uint32_t* __restrict__ slot,
-                                                  unsigned long long* table, int bits) {
+                                                  unsigned long long* table, int bits,
+                                                  int* __restrict__ istar) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  if (i == 0) *istar = n;      // "no point dropped" until the scan finds i* (a launch of its own before)
   const float* p = points + (size_t)i * c;
   int q[3];
   bool ok = true;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void vox_assign(int n, VoxGeom g,
                                                   const unsigned long long* __restrict__ table,
                                                   const int* __restrict__ rank,
                                                   const int* __restrict__ istar,
-                                                  int* __restrict__ win, int max_points,
+                                                  uint32_t* __restrict__ win, int max_points,
                                                   int32_t* __restrict__ coors) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -108,10 +111,10 @@ __global__ __launch_bounds__(256) void vox_assign(int n, VoxGeom g,
     coors[(size_t)v * 3 + 1] = y;
     coors[(size_t)v * 3 + 2] = x;
   }
-  int* w = win + (size_t)v * max_points;
-  int carry = i;
+  uint32_t* w = win + (size_t)v * max_points;
+  uint32_t carry = (uint32_t)i;
   for (int r = 0; r < max_points; ++r) {
-    const int old = atomicMin(&w[r], carry);
+    const uint32_t old = atomicMin(&w[r], carry);
     if (old == kNoPoint) break;          // the slot was empty: nothing displaced
     carry = old > carry ? old : carry;
   }
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void vox_assign(int n, VoxGeom g,
 
 // step 5: one thread per (voxel, channel); slots walked in order.
 __global__ __launch_bounds__(256) void vox_gather(const float* __restrict__ points, int c,
-                                                  const int* __restrict__ win, int max_points,
+                                                  const uint32_t* __restrict__ win, int max_points,
                                                   const int* __restrict__ voxel_num,
                                                   float* __restrict__ voxels,
                                                   int32_t* __restrict__ num_points,
@@ -127,11 +130,11 @@ __global__ __launch_bounds__(256) void vox_gather(const float* __restrict__ poin
   const long total = (long)(*voxel_num) * c;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     int v = (int)(t / c), ch = (int)(t % c);
-    const int* w = win + (size_t)v * max_points;
+    const uint32_t* w = win + (size_t)v * max_points;
     float sum = 0.f;
     int cnt = 0;
     for (int s = 0; s < max_points; ++s) {
-      int src = w[s];
+      const uint32_t src = w[s];
       float val = 0.f;
       if (src != kNoPoint) {
         val = points[(size_t)src * c + ch];
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(256) void vox_gather(const float* __restrict__ poin
 __global__ void vox_init_scalars(int* istar, int n) { *istar = n; }
 
 struct VoxWs {
-  uint32_t *key, *slot;
-  int *rank, *win, *tiles, *istar;
+  uint32_t *key, *slot, *win;
+  int *rank, *tiles, *istar;
   unsigned long long* table;
   int bits;
 };
@@ -167,9 +170,10 @@ void carve(A& a, VoxWs* w, int n, int max_voxels, int max_points) {
   TAKE(key, uint32_t, n);
   TAKE(slot, uint32_t, n);
   TAKE(rank, int, n);
-  TAKE(win, int, (size_t)max_voxels * max_points);
   TAKE(tiles, int, scan_num_tiles(n) + 1);
   TAKE(istar, int, 64);
+  // win and table next to each other: both start as all-ones, filled by one memset
+  TAKE(win, uint32_t, (size_t)max_voxels * max_points);
   TAKE(table, unsigned long long, (size_t)1 << bits);
 #undef TAKE
 }
@@ -213,13 +217,14 @@ MSMD_EXPORT int msmd_hard_voxelize(const float* points, int num_points, int num_
   if (!a.ok()) return MSMD_ERR_WORKSPACE;
 
   const int n = num_points;
-  hipMemsetAsync(w.table, 0xFF, sizeof(unsigned long long) << w.bits, st);
-  hipMemsetAsync(w.win, 0x7F, sizeof(int) * (size_t)max_voxels * max_points, st);
-  MSMD_LAUNCH(vox_init_scalars, dim3(1), dim3(1), 0, st, w.istar, n);
+  hipMemsetAsync(w.win, 0xFF,
+                 (size_t)((char*)(w.table + ((size_t)1 << w.bits)) - (char*)w.win), st);
   const int nb = ceil_div(n, 256);
   if (n > 0)
     MSMD_LAUNCH(vox_insert, dim3(nb), dim3(256), 0, st, points, n, num_features, g, w.key,
-                       w.slot, w.table, w.bits);
+                       w.slot, w.table, w.bits, w.istar);
+  else
+    MSMD_LAUNCH(vox_init_scalars, dim3(1), dim3(1), 0, st, w.istar, n);
   device_scan(FirstFlag{w.key, w.slot, w.table}, RankEmit{w.rank, w.istar, max_voxels}, n,
               w.tiles, voxel_num, max_voxels, st);
   if (n > 0) {
