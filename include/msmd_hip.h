@@ -78,6 +78,27 @@ int msmd_hard_voxelize(const float* points, int num_points, int num_features,
                        int32_t* voxel_num /* [1] */, void* workspace,
                        size_t workspace_bytes, msmd_stream_t stream);
 
+/* The same for SEVERAL clouds in one launch set (the B LiDAR sweeps of a batch and the
+ * virtual points of its four image scales: MSMDFusion.py:462-491 calls the voxel layer once
+ * per sample and scale, each call its own voxel size): blocks find their cloud, the scan
+ * restarts per cloud, one fill initialises every cloud's tables.  Results per cloud as
+ * msmd_hard_voxelize's, bit for bit.  The workspace is shared by the descriptors of a call. */
+typedef struct msmd_voxelize_desc {
+  const float* points;             /* [num_points, num_features] */
+  int32_t num_points, num_features;
+  float voxel_size[3];
+  float coors_range[6];
+  int32_t max_points, max_voxels;
+  float* voxels;                   /* [max_voxels, max_points, num_features] or NULL */
+  int32_t* coors;                  /* [max_voxels, 3] (z, y, x) */
+  int32_t* num_points_per_voxel;   /* [max_voxels] */
+  float* voxel_mean;               /* [max_voxels, num_features] or NULL */
+  int32_t* voxel_num;              /* [1], device */
+} msmd_voxelize_desc;
+size_t msmd_hard_voxelize_many_workspace_bytes(const msmd_voxelize_desc* descs, int n_desc);
+int msmd_hard_voxelize_many(const msmd_voxelize_desc* descs /* host */, int n_desc,
+                            void* workspace, size_t workspace_bytes, msmd_stream_t stream);
+
 /* HardSimpleVFE on an already materialised voxel tensor (unfused form). */
 int msmd_voxel_mean(const float* voxels /* [M,max_points,C] */,
                     const int32_t* num_points_per_voxel, int num_voxels,

@@ -43,6 +43,8 @@ SIGNATURES = {
     "msmd_device_ok": (_i, []),
     "msmd_voxelize_workspace_bytes": (_sz, [_i, _i, _i]),
     "msmd_hard_voxelize": (_i, [_vp, _i, _i, _fp, _fp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "msmd_hard_voxelize_many_workspace_bytes": (_sz, [_vp, _i]),
+    "msmd_hard_voxelize_many": (_i, [_vp, _i, _vp, _sz, _vp]),
     "msmd_voxel_mean": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "msmd_rulebook_subm_workspace_bytes": (_sz, [_i]),
     "msmd_rulebook_subm3d": (_i, [_vp, _i, _i, _ip, _ip, _vp, _vp, _sz, _vp]),

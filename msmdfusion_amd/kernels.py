@@ -103,6 +103,9 @@ def kernel_volume(ksize):
 
 
 # ------------------------------------------------------------------ voxelization
+VOXELIZE_MANY = os.environ.get("MSMD_VOXELIZE_MANY", "1") == "1"
+
+
 def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels,
                   want_voxels=True, want_mean=False):
     """voxel_layer.hard_voxelize (mmdet3d/ops/voxel/src/voxelization.h:51-69).
@@ -131,41 +134,69 @@ def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels,
             mean[:m] if want_mean else None)
 
 
+class _VoxDesc(C.Structure):        # include/msmd_hip.h: msmd_voxelize_desc
+    _fields_ = [("points", C.c_void_p), ("num_points", C.c_int32), ("num_features", C.c_int32),
+                ("voxel_size", C.c_float * 3), ("coors_range", C.c_float * 6),
+                ("max_points", C.c_int32), ("max_voxels", C.c_int32), ("voxels", C.c_void_p),
+                ("coors", C.c_void_p), ("num_points_per_voxel", C.c_void_p),
+                ("voxel_mean", C.c_void_p), ("voxel_num", C.c_void_p)]
+
+
 def hard_voxelize_batch(points_list, voxel_size, coors_range, max_points, max_voxels,
                         want_voxels=True, want_mean=False):
-    """hard_voxelize for every sample of a batch with ONE host read: all
-    launches are enqueued first, the B voxel counts come back together (the
-    reference syncs 4 times per sample, voxelization_cuda.cu:231-323).
+    """hard_voxelize for every sample of a batch in ONE launch set and with ONE host read
+    (msmd_hard_voxelize_many: the reference syncs 4 times per sample,
+    voxelization_cuda.cu:231-323, and is called once per sample and scale).
     voxel_size: one size for all clouds, or one size per cloud (the LiDAR sweep
-    and the four scales of virtual points of a step go out in a single call)."""
+    and the four scales of virtual points of a step go out in a single call).
+    MSMD_VOXELIZE_MANY=0: one msmd_hard_voxelize call per cloud (rounds 1-5)."""
     per_cloud = len(voxel_size) > 0 and isinstance(voxel_size[0], (list, tuple))
     if per_cloud and len(voxel_size) != len(points_list):
         raise ValueError("need one voxel size per cloud")
+    if not points_list:
+        return []
+    many = VOXELIZE_MANY and len(points_list) > 1
     pending = []
+    descs = (_VoxDesc * len(points_list))() if many else None
+    counts_all = None
     for ci, points in enumerate(points_list):
         _need_cuda(points)
         pts = points.contiguous().float()
         n, c = pts.shape
         dev = pts.device
+        if counts_all is None:
+            counts_all = torch.empty((len(points_list),), dtype=torch.int32, device=dev)
         voxels = torch.empty((max_voxels, max_points, c), dtype=torch.float32, device=dev) \
             if want_voxels else None
         mean = torch.empty((max_voxels, c), dtype=torch.float32, device=dev) if want_mean else None
         coors = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
         npv = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
-        count = torch.empty((1,), dtype=torch.int32, device=dev)
-        nbytes = lib.msmd_voxelize_workspace_bytes(n, max_voxels, max_points)
-        ws = _ws(nbytes, dev)
-        check(lib.msmd_hard_voxelize(_p(pts), n, c,
-                                     float_arr(voxel_size[ci] if per_cloud else voxel_size),
-                                     float_arr(coors_range), int(max_points), int(max_voxels),
-                                     _p(voxels), _p(coors), _p(npv), _p(mean), _p(count), _p(ws),
-                                     nbytes, _stream()), "msmd_hard_voxelize")
-        pending.append((voxels, coors, npv, mean, count, pts, ws))
-    if not pending:
-        return []
-    counts = torch.cat([p[4] for p in pending]).tolist()
+        count = counts_all[ci:ci + 1]
+        vs = voxel_size[ci] if per_cloud else voxel_size
+        if many:
+            d = descs[ci]
+            d.points, d.num_points, d.num_features = _p(pts), n, c
+            d.voxel_size = (C.c_float * 3)(*[float(v) for v in vs])
+            d.coors_range = (C.c_float * 6)(*[float(v) for v in coors_range])
+            d.max_points, d.max_voxels = int(max_points), int(max_voxels)
+            d.voxels, d.coors, d.num_points_per_voxel = _p(voxels), _p(coors), _p(npv)
+            d.voxel_mean, d.voxel_num = _p(mean), _p(count)
+        else:
+            nbytes = lib.msmd_voxelize_workspace_bytes(n, max_voxels, max_points)
+            ws = _ws(nbytes, dev)
+            check(lib.msmd_hard_voxelize(_p(pts), n, c, float_arr(vs), float_arr(coors_range),
+                                         int(max_points), int(max_voxels), _p(voxels), _p(coors),
+                                         _p(npv), _p(mean), _p(count), _p(ws), nbytes, _stream()),
+                  "msmd_hard_voxelize")
+        pending.append((voxels, coors, npv, mean, pts))
+    if many:
+        nbytes = lib.msmd_hard_voxelize_many_workspace_bytes(descs, len(points_list))
+        ws = _ws(nbytes, counts_all.device)
+        check(lib.msmd_hard_voxelize_many(descs, len(points_list), _p(ws), nbytes, _stream()),
+              "msmd_hard_voxelize_many")
+    counts = counts_all.tolist()
     return [(v[:m] if want_voxels else None, c[:m], n[:m], mu[:m] if want_mean else None)
-            for (v, c, n, mu, _, _, _), m in zip(pending, counts)]
+            for (v, c, n, mu, _), m in zip(pending, counts)]
 
 
 def voxel_mean(voxels, num_points, out_features=None):

@@ -1204,3 +1204,52 @@ def test_pack_weight_split_pair(dev, cin, cout, krsc):
         a, b = K.pack_weight_split_pair(w, planes, krsc=krsc)
         assert torch.equal(a, K.pack_weight_split(w, planes, krsc=krsc))
         assert torch.equal(b, K.pack_weight_split(w, planes, transpose=True, krsc=krsc))
+
+
+def test_hard_voxelize_many_equals_cloud_by_cloud(dev, monkeypatch):
+    """msmd_hard_voxelize_many (every cloud of a batch in one launch set: blocks find their
+    cloud, the scan restarts per cloud, one fill for all tables) == msmd_hard_voxelize called
+    cloud by cloud, bit for bit: mixed channel counts and voxel sizes (the LiDAR sweeps + the
+    four virtual-point scales of an LC step), a cloud below one scan tile, an EMPTY cloud, a
+    cloud that hits max_voxels (the reference loop's `break`), 14 clouds = two launch sets;
+    and against the oracle for one of them."""
+    from msmdfusion_amd import kernels as K
+    rng = np.random.RandomState(12)
+    rg = S.POINT_CLOUD_RANGE
+    base = S.VOXEL_SIZE
+
+    def cloud(n, c, spread=1.0):
+        p = rng.randn(n, c).astype(np.float32)
+        p[:, 0] = rng.uniform(rg[0] * spread, rg[3] * spread, n)
+        p[:, 1] = rng.uniform(rg[1] * spread, rg[4] * spread, n)
+        p[:, 2] = rng.uniform(rg[2], rg[5], n)
+        return p
+    clouds = [S.lidar_sweep(0, n_az=400), S.lidar_sweep(1, n_az=300), cloud(5000, 64),
+              cloud(1500, 64, 0.2), cloud(100, 5), np.zeros((0, 5), np.float32),
+              cloud(30000, 5, 0.05)]
+    sizes = [list(base), list(base), [v * 2 for v in base], [v * 4 for v in base],
+             [v * 8 for v in base], list(base), list(base)]
+    # 14 clouds: a second launch set (12 per set)
+    clouds = clouds + [c[::-1].copy() for c in clouds]
+    sizes = sizes + sizes
+    d = [t(c, dev) for c in clouds]
+    for max_voxels in (20000, 700):        # 700: several clouds run into the cap
+        for want_voxels, want_mean in ((True, False), (False, True), (True, True)):
+            monkeypatch.setattr(K, "VOXELIZE_MANY", True)
+            got = K.hard_voxelize_batch(d, sizes, rg, 10, max_voxels, want_voxels, want_mean)
+            monkeypatch.setattr(K, "VOXELIZE_MANY", False)
+            ref = K.hard_voxelize_batch(d, sizes, rg, 10, max_voxels, want_voxels, want_mean)
+            assert len(got) == len(ref) == len(clouds)
+            for ci, (a, b) in enumerate(zip(got, ref)):
+                for x, y in zip(a, b):
+                    assert (x is None) == (y is None), ci
+                    if x is not None:
+                        assert x.shape == y.shape and torch.equal(x, y), (ci, max_voxels)
+            assert got[5][1].shape[0] == 0                       # the empty cloud
+        if max_voxels == 700:
+            assert sum(int(g[1].shape[0] == 700) for g in got) >= 4
+    monkeypatch.setattr(K, "VOXELIZE_MANY", True)
+    got = K.hard_voxelize_batch(d, sizes, rg, 10, 20000, True, False)
+    ev, ec, en = O.hard_voxelize(clouds[2], sizes[2], rg, 10, 20000)
+    assert np.array_equal(got[2][1].cpu().numpy(), ec) and np.array_equal(got[2][2].cpu().numpy(), en)
+    assert np.array_equal(got[2][0].cpu().numpy(), ev)
