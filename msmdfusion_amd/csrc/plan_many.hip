@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kScanBlock) void pair_sums_many_kernel(const PlanTa
 // strided convs, whose input side is the longer one -- was a memset of the whole tensor)
 __global__ __launch_bounds__(kScanBlock) void pairs_apply_many_kernel(
     const PlanTab tab, const int* __restrict__ tile_sums_all) {
-  __shared__ int smem[kScanBlock / 64];
+  __shared__ int smem[kScanSmem];
   const int s = table_of(tab.pblk0, tab.n, blockIdx.x);
   const msmd_plan_desc& d = tab.d[s];
   const int n_rows = d.n_rows, ld = d.ld;
@@ -196,17 +196,21 @@ __global__ __launch_bounds__(kScanBlock) void pairs_apply_many_kernel(
   int32_t* __restrict__ pout = pin + ld;
   const int32_t* __restrict__ nbr = d.nbr + (size_t)k * n_rows;
   const int base = tile_in_k * kScanTile;
+  int src[kScanItems], v[kScanItems], ex[kScanItems];
 #pragma unroll
   for (int j = 0; j < kScanItems; ++j) {
     const int o = base + j * kScanBlock + threadIdx.x;
-    const int src = o < n_rows ? nbr[o] : -1;
-    const int v = src >= 0;
-    int tot;
-    const int ex = block_excl_scan<kScanBlock>(v, smem, &tot);
-    const int pos = carry + ex;
-    if (v) {
+    src[j] = o < n_rows ? nbr[o] : -1;
+    v[j] = src[j] >= 0;
+  }
+  tile_excl_scan(v, ex, smem);
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    const int o = base + j * kScanBlock + threadIdx.x;
+    const int pos = carry + ex[j];
+    if (v[j]) {
       if (pos < ld) {
-        pin[pos] = src;
+        pin[pos] = src[j];
         pout[pos] = o;
       }
     } else {
@@ -216,7 +220,6 @@ __global__ __launch_bounds__(kScanBlock) void pairs_apply_many_kernel(
         pout[tail] = -1;
       }
     }
-    carry += tot;
   }
   if (ld > rows_pad) {
     const int per = (ld - rows_pad + tpk - 1) / tpk;

@@ -501,7 +501,7 @@ struct PairCount {
 __global__ __launch_bounds__(kScanBlock) void pairs_apply_kernel(
     const int32_t* __restrict__ nbr, int n_rows, int rows_pad, int ld, int kvol,
     const int* __restrict__ tile_sums, int32_t* __restrict__ pairs, int32_t* __restrict__ num) {
-  __shared__ int smem[kScanBlock / 64];
+  __shared__ int smem[kScanSmem];
   const int tpk = rows_pad / kScanTile;
   const int k = blockIdx.x / tpk, tile_in_k = blockIdx.x - k * tpk;
   // pairs of this offset in front of this tile, and in the whole offset
@@ -511,17 +511,21 @@ __global__ __launch_bounds__(kScanBlock) void pairs_apply_kernel(
   int32_t* pin = pairs + ((size_t)k * 2 + 0) * ld;
   int32_t* pout = pin + ld;
   const int base = tile_in_k * kScanTile;
+  int src[kScanItems], v[kScanItems], ex[kScanItems];
 #pragma unroll
   for (int j = 0; j < kScanItems; ++j) {
     const int o = base + j * kScanBlock + threadIdx.x;
-    const int src = o < n_rows ? nbr[(size_t)k * n_rows + o] : -1;
-    const int v = src >= 0;
-    int tot;
-    const int ex = block_excl_scan<kScanBlock>(v, smem, &tot);
-    const int pos = carry + ex;            // pairs of offset k in front of entry o
-    if (v) {
+    src[j] = o < n_rows ? nbr[(size_t)k * n_rows + o] : -1;
+    v[j] = src[j] >= 0;
+  }
+  tile_excl_scan(v, ex, smem);
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    const int o = base + j * kScanBlock + threadIdx.x;
+    const int pos = carry + ex[j];         // pairs of offset k in front of entry o
+    if (v[j]) {
       if (pos < ld) {
-        pin[pos] = src;
+        pin[pos] = src[j];
         pout[pos] = o;
       }
     } else {
@@ -531,7 +535,6 @@ __global__ __launch_bounds__(kScanBlock) void pairs_apply_kernel(
         pout[tail] = -1;
       }
     }
-    carry += tot;
   }
 }
 
@@ -753,20 +756,23 @@ __global__ __launch_bounds__(kScanBlock) void subm_bm_sums_many(const SubmTab ta
 
 __global__ __launch_bounds__(kScanBlock) void subm_bm_prefix_many(
     const SubmTab tab, const int* __restrict__ tile_sums) {
-  __shared__ int smem[kScanBlock / 64];
+  __shared__ int smem[kScanSmem];
   const int s = subm_table_of(tab.sblk0, tab.n, blockIdx.x);
   const SubmJob& J = tab.j[s];
   const BmBlockCount count{J.bits, J.coarse};
-  int carry = block_range_sum<kScanBlock>(tile_sums, tab.sblk0[s], (int)blockIdx.x, smem);
   const int base = (blockIdx.x - tab.sblk0[s]) * kScanTile;
+  int v[kScanItems], ex[kScanItems];
 #pragma unroll
   for (int q = 0; q < kScanItems; ++q) {
     const int i = base + q * kScanBlock + threadIdx.x;
-    const int v = i < J.nblocks ? count(i) : 0;
-    int tot;
-    const int ex = block_excl_scan<kScanBlock>(v, smem, &tot);
-    if (v) J.block_prefix[i] = carry + ex;       // (occupied blocks only)
-    carry += tot;
+    v[q] = i < J.nblocks ? count(i) : 0;
+  }
+  const int carry = block_range_sum<kScanBlock>(tile_sums, tab.sblk0[s], (int)blockIdx.x, smem);
+  tile_excl_scan(v, ex, smem);
+#pragma unroll
+  for (int q = 0; q < kScanItems; ++q) {
+    const int i = base + q * kScanBlock + threadIdx.x;
+    if (v[q]) J.block_prefix[i] = carry + ex[q];       // (occupied blocks only)
   }
 }
 

@@ -62,6 +62,40 @@ __device__ __forceinline__ int block_range_sum(const int* __restrict__ a, int lo
   return t;
 }
 
+// Exclusive prefixes of a tile: kScanItems values per thread, item-major (item j of every
+// thread precedes item j + 1 of any thread, the order of the coalesced loads), across the
+// block with ONE barrier pair for all items -- the values are loaded up front (kScanItems
+// independent loads in flight instead of a load -> two barriers -> load chain per item: the
+// index pass runs ~50 of these scans per LC step as short kernels whose time is that chain).
+// smem: kScanItems * kScanBlock / 64 ints.  ex[j] <- prefix inside the tile; returns the total.
+constexpr int kScanSmem = kScanItems * (kScanBlock / 64);
+__device__ __forceinline__ int tile_excl_scan(const int (&v)[kScanItems], int (&ex)[kScanItems],
+                                              int* smem) {
+  constexpr int NW = kScanBlock / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    ex[j] = wave_excl_scan(v[j], lane);
+    if (lane == 63) smem[j * NW + w] = ex[j] + v[j];
+  }
+  __syncthreads();
+  int run = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int s = smem[j * NW + i];
+      base += i < w ? s : 0;
+      tot += s;
+    }
+    ex[j] += run + base;
+    run += tot;
+  }
+  __syncthreads();      // smem may be written again
+  return run;
+}
+
 // total <- 0 for an empty input
 static __global__ void scan_empty_total(int* __restrict__ total) {
   if (total) *total = 0;
@@ -71,18 +105,22 @@ template <typename Count, typename Emit>
 __global__ __launch_bounds__(kScanBlock) void scan_apply(Count count, Emit emit, int n,
                                                          const int* __restrict__ tile_sums,
                                                          int* __restrict__ total, int clamp) {
-  __shared__ int smem[kScanBlock / 64];
+  __shared__ int smem[kScanSmem];
   const int base = blockIdx.x * kScanTile;
-  int carry = block_range_sum<kScanBlock>(tile_sums, 0, blockIdx.x, smem);
+  int v[kScanItems], ex[kScanItems];
 #pragma unroll
   for (int j = 0; j < kScanItems; ++j) {
-    int i = base + j * kScanBlock + threadIdx.x;
-    int v = i < n ? count(i) : 0;
-    int tot;
-    int ex = block_excl_scan<kScanBlock>(v, smem, &tot);
-    if (i < n) emit(i, carry + ex, v);
-    carry += tot;
+    const int i = base + j * kScanBlock + threadIdx.x;
+    v[j] = i < n ? count(i) : 0;
   }
+  int carry = block_range_sum<kScanBlock>(tile_sums, 0, blockIdx.x, smem);
+  const int tot = tile_excl_scan(v, ex, smem);
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    const int i = base + j * kScanBlock + threadIdx.x;
+    if (i < n) emit(i, carry + ex[j], v[j]);
+  }
+  carry += tot;
   if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
     *total = (clamp >= 0 && carry > clamp) ? clamp : carry;
 }

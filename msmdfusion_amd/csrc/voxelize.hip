@@ -332,22 +332,26 @@ __global__ __launch_bounds__(kScanBlock) void vox_sums_many(const VoxTab tab,
 
 __global__ __launch_bounds__(kScanBlock) void vox_rank_many(const VoxTab tab,
                                                            const int* __restrict__ tile_sums) {
-  __shared__ int smem[kScanBlock / 64];
+  __shared__ int smem[kScanSmem];
   const int s = vox_job_of(tab.tile0, tab.n, blockIdx.x);
   const VoxJob& J = tab.j[s];
   const FirstFlag count{J.key, J.slot, J.table};
   const RankEmit emit{J.rank, J.istar, J.max_voxels, J.win, J.max_points};
-  int carry = block_range_sum<kScanBlock>(tile_sums, tab.tile0[s], (int)blockIdx.x, smem);
   const int base = (blockIdx.x - tab.tile0[s]) * kScanTile;
+  int v[kScanItems], ex[kScanItems];
 #pragma unroll
   for (int q = 0; q < kScanItems; ++q) {
     const int i = base + q * kScanBlock + threadIdx.x;
-    const int v = i < J.n ? count(i) : 0;
-    int tot;
-    const int ex = block_excl_scan<kScanBlock>(v, smem, &tot);
-    if (i < J.n) emit(i, carry + ex, v);
-    carry += tot;
+    v[q] = i < J.n ? count(i) : 0;
   }
+  int carry = block_range_sum<kScanBlock>(tile_sums, tab.tile0[s], (int)blockIdx.x, smem);
+  const int tot = tile_excl_scan(v, ex, smem);
+#pragma unroll
+  for (int q = 0; q < kScanItems; ++q) {
+    const int i = base + q * kScanBlock + threadIdx.x;
+    if (i < J.n) emit(i, carry + ex[q], v[q]);
+  }
+  carry += tot;
   if ((int)blockIdx.x == tab.tile0[s + 1] - 1 && threadIdx.x == 0)
     *J.voxel_num = carry > J.max_voxels ? J.max_voxels : carry;
 }
