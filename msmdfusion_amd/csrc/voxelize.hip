@@ -89,6 +89,24 @@ struct RankEmit {  // rank[i] = voxel id if first point; records i* (step 3)
   }
 };
 
+// The atomicMin cascade of step 4 for one point.  Slot values only ever DECREASE, so a plain
+// (possibly stale, i.e. too high) read that is already below the value carried in decides
+// what the atomic would: the slot keeps its value and the carried one moves on -- no atomic.
+// A voxel of a coarse virtual-point scale holds hundreds of points: without the reads every
+// one of them did max_points same-line atomics (191 us for the 10 clouds of an LC step).
+__device__ __forceinline__ void slot_cascade(uint32_t* w, int max_points, uint32_t carry) {
+  const volatile uint32_t* wv = w;
+  const uint32_t last = wv[max_points - 1];
+  if (last != kNoPoint && last < carry) return;     // ten smaller indices are in already
+  for (int r = 0; r < max_points; ++r) {
+    const uint32_t cur = wv[r];
+    if (cur != kNoPoint && cur < carry) continue;   // would lose here: next slot
+    const uint32_t old = atomicMin(&w[r], carry);
+    if (old == kNoPoint) break;          // the slot was empty: nothing displaced
+    carry = old > carry ? old : carry;
+  }
+}
+
 // step 4 + coordinates: every kept point learns its voxel id and inserts its index
 // into the voxel's `max_points` slots, which end up holding the smallest indices in
 // ascending order -- one pass.  Slot r is an atomicMin cell: a point (or the value it
@@ -119,12 +137,7 @@ __global__ __launch_bounds__(256) void vox_assign(int n, VoxGeom g,
     coors[(size_t)v * 3 + 2] = x;
   }
   uint32_t* w = win + (size_t)v * max_points;
-  uint32_t carry = (uint32_t)i;
-  for (int r = 0; r < max_points; ++r) {
-    const uint32_t old = atomicMin(&w[r], carry);
-    if (old == kNoPoint) break;          // the slot was empty: nothing displaced
-    carry = old > carry ? old : carry;
-  }
+  slot_cascade(w, max_points, (uint32_t)i);
 }
 
 // step 5: one thread per (voxel, channel); slots walked in order.
@@ -373,13 +386,7 @@ __global__ __launch_bounds__(256) void vox_assign_many(const VoxTab tab) {
     J.coors[(size_t)v * 3 + 1] = y;
     J.coors[(size_t)v * 3 + 2] = x;
   }
-  uint32_t* w = J.win + (size_t)v * J.max_points;
-  uint32_t carry = (uint32_t)i;
-  for (int r = 0; r < J.max_points; ++r) {
-    const uint32_t old = atomicMin(&w[r], carry);
-    if (old == kNoPoint) break;
-    carry = old > carry ? old : carry;
-  }
+  slot_cascade(J.win + (size_t)v * J.max_points, J.max_points, (uint32_t)i);
 }
 
 __global__ __launch_bounds__(256) void vox_gather_many(const VoxTab tab) {
