@@ -70,7 +70,18 @@ def masked_stream(device, cu_bits, total_cus=256):
     global _HIP
     device = torch.device(device)
     if _HIP is None:
-        _HIP = C.CDLL("libamdhip64.so")      # the runtime torch has loaded already
+        # the HIP runtime THIS process already runs on (torch's bundled copy): opening
+        # "libamdhip64.so" by name could map /opt/rocm's as a second runtime instance whose
+        # streams torch's would not know
+        path = None
+        with open("/proc/self/maps") as maps:
+            for line in maps:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+        if path is None:
+            raise RuntimeError("no HIP runtime is mapped into this process")
+        _HIP = C.CDLL(path)
     words = (total_cus + 31) // 32
     mask = (C.c_uint32 * words)()
     for b in cu_bits:
