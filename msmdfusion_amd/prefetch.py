@@ -166,6 +166,15 @@ class IndexPrefetcher:
         done.record(torch.cuda.current_stream(self.device))
         self._retired.append((done, ticket))
 
+    def close(self):
+        """Stop the worker thread(s) (idle threads of discarded prefetchers otherwise live as
+        long as the process) and drop the retired batches.  The side streams are process-wide
+        and stay."""
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        self._retired.clear()
+
     def _collect(self):
         # the side stream's host reads do not throttle the host to the MAIN stream's
         # pace: without a bound it runs many steps ahead and every retired batch
