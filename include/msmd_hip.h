@@ -809,6 +809,14 @@ size_t msmd_rows_where_workspace_bytes(int n);
 int msmd_rows_where_eq(const int32_t* flags, int stride, int n, int value, int64_t* rows,
                        int capacity, int32_t* total, void* workspace, size_t workspace_bytes,
                        msmd_stream_t stream);
+/* The same for n_lists (flag vector, value) pairs in one scan: the only-3D and only-2D row lists
+ * of all four image scales of a step (host arrays of n_lists pointers / ints).  Per list as
+ * msmd_rows_where_eq, the -1 tail included; a list of capacity 0 is skipped. */
+size_t msmd_rows_where_eq_many_workspace_bytes(const int* lens, int n_lists);
+int msmd_rows_where_eq_many(const int32_t* const* flags, const int* strides, const int* lens,
+                            const int* values, int64_t* const* rows, const int* capacities,
+                            int n_lists, void* workspace, size_t workspace_bytes,
+                            msmd_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * a15  GMA-Conv neighbour search helpers

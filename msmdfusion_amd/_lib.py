@@ -143,6 +143,8 @@ SIGNATURES = {
                                             _vp, _sz, _vp]),
     "msmd_rows_where_workspace_bytes": (_sz, [_i]),
     "msmd_rows_where_eq": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "msmd_rows_where_eq_many_workspace_bytes": (_sz, [_vp, _i]),
+    "msmd_rows_where_eq_many": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "msmd_furthest_point_sample": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "msmd_furthest_point_sample_ragged": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "msmd_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp]),

@@ -492,3 +492,114 @@ MSMD_EXPORT int msmd_rows_where_eq(const int32_t* flags, int stride, int n, int 
   return launch_status();
 }
 
+// Several lists in ONE scan (the only-3D / only-2D row lists of the four image scales of an LC
+// step: 8 calls = 16 scan launches + 8 tail fills before): blocks find their list from tile
+// prefixes, the scan restarts per list, the block holding a list's last tile fills its tail.
+namespace msmd {
+namespace {
+constexpr int kRowsMany = 16;
+struct RowsTab {
+  int n;
+  int tile0[kRowsMany + 1];
+  const int32_t* flags[kRowsMany];
+  int64_t* rows[kRowsMany];
+  int stride[kRowsMany], len[kRowsMany], value[kRowsMany], cap[kRowsMany];
+};
+__device__ __forceinline__ int rows_list_of(const int* __restrict__ first, int n, int b) {
+  int s = 0;
+  while (s + 1 < n && b >= first[s + 1]) ++s;
+  return s;
+}
+__global__ __launch_bounds__(kScanBlock) void rows_sums_many(const RowsTab tab,
+                                                            int* __restrict__ tile_sums) {
+  __shared__ int smem[kScanBlock / 64];
+  const int s = rows_list_of(tab.tile0, tab.n, blockIdx.x);
+  const FlagEq count{tab.flags[s], tab.stride[s], tab.value[s]};
+  const int base = (blockIdx.x - tab.tile0[s]) * kScanTile, n = tab.len[s];
+  int c = 0;
+#pragma unroll
+  for (int q = 0; q < kScanItems; ++q) {
+    const int i = base + q * kScanBlock + threadIdx.x;
+    if (i < n) c += count(i);
+  }
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int i = 0; i < kScanBlock / 64; ++i) t += smem[i];
+    tile_sums[blockIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(kScanBlock) void rows_emit_many(const RowsTab tab,
+                                                            const int* __restrict__ tile_sums) {
+  __shared__ int smem[kScanSmem];
+  const int s = rows_list_of(tab.tile0, tab.n, blockIdx.x);
+  const FlagEq count{tab.flags[s], tab.stride[s], tab.value[s]};
+  const EmitRow emit{tab.rows[s], tab.cap[s]};
+  const int base = (blockIdx.x - tab.tile0[s]) * kScanTile, n = tab.len[s];
+  int v[kScanItems], ex[kScanItems];
+#pragma unroll
+  for (int q = 0; q < kScanItems; ++q) {
+    const int i = base + q * kScanBlock + threadIdx.x;
+    v[q] = i < n ? count(i) : 0;
+  }
+  int carry = block_range_sum<kScanBlock>(tile_sums, tab.tile0[s], (int)blockIdx.x, smem);
+  const int tot = tile_excl_scan(v, ex, smem);
+#pragma unroll
+  for (int q = 0; q < kScanItems; ++q) {
+    const int i = base + q * kScanBlock + threadIdx.x;
+    if (i < n) emit(i, carry + ex[q], v[q]);
+  }
+  if ((int)blockIdx.x == tab.tile0[s + 1] - 1)       // the list's last tile: -1 past its total
+    for (int i = carry + tot + (int)threadIdx.x; i < tab.cap[s]; i += kScanBlock) tab.rows[s][i] = -1;
+}
+}  // namespace
+}  // namespace msmd
+
+MSMD_EXPORT size_t msmd_rows_where_eq_many_workspace_bytes(const int* lens, int n_lists) {
+  if (!lens || n_lists < 1) return 0;
+  long tiles = 0;
+  for (int i = 0; i < n_lists; ++i) tiles += scan_num_tiles(lens[i] > 0 ? lens[i] : 1);
+  return align_up(sizeof(int) * (size_t)(tiles + 1)) + 256;
+}
+
+MSMD_EXPORT int msmd_rows_where_eq_many(const int32_t* const* flags, const int* strides,
+                                        const int* lens, const int* values,
+                                        int64_t* const* rows, const int* capacities, int n_lists,
+                                        void* workspace, size_t workspace_bytes,
+                                        msmd_stream_t stream) {
+  if (!flags || !strides || !lens || !values || !rows || !capacities || n_lists < 1)
+    return MSMD_ERR_INVALID_ARG;
+  if (workspace_bytes < msmd_rows_where_eq_many_workspace_bytes(lens, n_lists) ||
+      ((uintptr_t)workspace & 255))
+    return MSMD_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  for (int g0 = 0; g0 < n_lists; g0 += kRowsMany) {
+    RowsTab tab;
+    tab.n = 0;
+    tab.tile0[0] = 0;
+    for (int i = g0; i < n_lists && i < g0 + kRowsMany; ++i) {
+      if (lens[i] < 0 || strides[i] < 1 || capacities[i] < 0 || (lens[i] > 0 && !flags[i]) ||
+          (capacities[i] > 0 && !rows[i]))
+        return MSMD_ERR_INVALID_ARG;
+      if (capacities[i] == 0) continue;
+      const int s = tab.n++;
+      tab.flags[s] = flags[i];
+      tab.rows[s] = rows[i];
+      tab.stride[s] = strides[i];
+      tab.len[s] = lens[i];
+      tab.value[s] = values[i];
+      tab.cap[s] = capacities[i];
+      // (an empty flag vector still owns one tile: its block writes the -1 tail)
+      tab.tile0[s + 1] = tab.tile0[s] + scan_num_tiles(lens[i] > 0 ? lens[i] : 1);
+    }
+    if (tab.n == 0) continue;
+    for (int s = tab.n + 1; s <= kRowsMany; ++s) tab.tile0[s] = 0x7fffffff;
+    int* tile_sums = (int*)workspace;
+    MSMD_LAUNCH(rows_sums_many, dim3(tab.tile0[tab.n]), dim3(kScanBlock), 0, st, tab, tile_sums);
+    MSMD_LAUNCH(rows_emit_many, dim3(tab.tile0[tab.n]), dim3(kScanBlock), 0, st, tab,
+                (const int*)tile_sums);
+  }
+  return launch_status();
+}

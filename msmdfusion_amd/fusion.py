@@ -185,14 +185,19 @@ class SparseFusionPath(nn.Module):
                 jobs.append((stages[i][0], v2[i].indices, shape))
             idx3_5, s3, s2, plans = [], [], [], []
             q = self.reference_quirks
-            for i, (mix3, mix2, pa, pb, stats) in enumerate(
-                    K.modality_split_many(jobs, B, float_keys=q, reference_offsets=q)):
+            splits = K.modality_split_many(jobs, B, float_keys=q, reference_offsets=q)
+            # the row lists of the unmatched voxels of both sets at all four scales: one scan
+            lists = K.rows_where_eq_many(
+                [(m, 0, sum(st[key])) for (m3, m2, _, _, st) in splits
+                 for m, key in ((m3, "c3_plain"), (m2, "c2_plain"))])
+            for i, (mix3, mix2, pa, pb, stats) in enumerate(splits):
                 idx3, idx2 = jobs[i][0], jobs[i][1]
                 i3 = torch.cat([idx3[:, :1], mix3[:, None], idx3[:, 1:]], 1).contiguous()
                 v2[i].indices = torch.cat([idx2[:, :1], mix2[:, None], idx2[:, 1:]], 1).contiguous()
                 idx3_5.append(i3); s3.append(pa.long()); s2.append(pb.long())
                 plans.append(mm.plan_stage_rows(i3, v2[i].indices, B, stats, bzyx3=idx3, bzyx2=idx2,
-                                                mix3=mix3, mix2=mix2))
+                                                mix3=mix3, mix2=mix2,
+                                                plain_rows=(lists[2 * i], lists[2 * i + 1])))
             # the fusion stack's own voxel sets and rulebooks, stage by stage (each needs
             # the previous stage's output set).  Before the neighbour search is enqueued:
             # these calls read counts back, and must not wait behind 9 ms of FPS

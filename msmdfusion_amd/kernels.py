@@ -1584,6 +1584,32 @@ def rows_where_eq(flags, value, count):
     return rows
 
 
+def rows_where_eq_many(jobs):
+    """rows_where_eq for several (flags, value, count) triples in ONE scan (two launches):
+    -> list of int64 row tensors.  flags: 1-D int32 CUDA tensors (any stride)."""
+    if not jobs:
+        return []
+    dev = jobs[0][0].device
+    n = len(jobs)
+    outs, ptr_f, ptr_r = [], (C.c_void_p * n)(), (C.c_void_p * n)()
+    strides, lens, values, caps = ((C.c_int * n)() for _ in range(4))
+    for i, (flags, value, count) in enumerate(jobs):
+        _need_cuda(flags)
+        if flags.dtype != torch.int32 or flags.dim() != 1:
+            raise ValueError("rows_where_eq_many: 1-D int32 flag vectors")
+        count = int(count)
+        out = torch.empty((count,), dtype=torch.long, device=dev)
+        outs.append(out)
+        ptr_f[i], ptr_r[i] = _p(flags), (_p(out) if count else None)
+        strides[i] = int(flags.stride(0)) if flags.shape[0] else 1
+        lens[i], values[i], caps[i] = flags.shape[0], int(value), count
+    nbytes = lib.msmd_rows_where_eq_many_workspace_bytes(lens, n)
+    ws = _ws(nbytes, dev)
+    check(lib.msmd_rows_where_eq_many(ptr_f, strides, lens, values, ptr_r, caps, n, _p(ws), nbytes,
+                                      _stream()), "msmd_rows_where_eq_many")
+    return outs
+
+
 def rows_where(mask, count):
     """Row numbers where a 1-D bool tensor is set, ascending, when their number is
     already known on the host: mask.nonzero() would wait for the device to size its

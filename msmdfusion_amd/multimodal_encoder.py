@@ -212,7 +212,7 @@ class SparseMultiModalEncoderPaint(nn.Module):
 
     # ---- index-only half of a GMA-Conv stage ------------------------------------
     def plan_stage_rows(self, idx3_5, idx2_5, batch_size, stats=None, bzyx3=None, bzyx2=None,
-                        mix3=None, mix2=None):
+                        mix3=None, mix2=None, plain_rows=None):
         """Everything grouped_sparse_conv derives from the two 5-column index
         tensors alone, up to the neighbour search: row lists of the only-3D /
         only-2D voxels, the padded only-2D indices, the per-sample counts.
@@ -222,18 +222,22 @@ class SparseMultiModalEncoderPaint(nn.Module):
         bzyx3 / bzyx2: the same voxel sets as 4-column (b,z,y,x) tensors when the caller
         still has them (it made the 5-column ones by inserting the mix flag): selections are
         taken from those instead of dropping the column again after every index_select.
-        mix3 / mix2: the flag columns as contiguous int32 vectors, likewise."""
+        mix3 / mix2: the flag columns as contiguous int32 vectors, likewise.
+        plain_rows: (only-3D rows, only-2D rows) when the caller made them already."""
         if stats is None:
             only_3D_rows = (idx3_5[:, 1] == 0).nonzero().flatten()
             only_2D_rows = (idx2_5[:, 1] == 0).nonzero().flatten()
             missing = None
         else:
-            # (the flag vectors themselves when the caller has them: a contiguous read
-            # instead of every fifth int of the index tensor)
-            only_3D_rows = K.rows_where_eq(mix3 if mix3 is not None else idx3_5[:, 1], 0,
-                                           sum(stats["c3_plain"]))
-            only_2D_rows = K.rows_where_eq(mix2 if mix2 is not None else idx2_5[:, 1], 0,
-                                           sum(stats["c2_plain"]))
+            if plain_rows is not None:      # (made for all stages at once: rows_where_eq_many)
+                only_3D_rows, only_2D_rows = plain_rows
+            else:
+                # (the flag vectors themselves when the caller has them: a contiguous read
+                # instead of every fifth int of the index tensor)
+                only_3D_rows = K.rows_where_eq(mix3 if mix3 is not None else idx3_5[:, 1], 0,
+                                               sum(stats["c3_plain"]))
+                only_2D_rows = K.rows_where_eq(mix2 if mix2 is not None else idx2_5[:, 1], 0,
+                                               sum(stats["c2_plain"]))
             missing = [b for b in range(batch_size) if stats["c2_plain"][b] == 0]
         idx3 = bzyx3 if bzyx3 is not None else drop_mix_column(idx3_5)
         idx2 = bzyx2 if bzyx2 is not None else drop_mix_column(idx2_5)

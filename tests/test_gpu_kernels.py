@@ -394,6 +394,31 @@ def test_rows_where_eq(dev):
         assert bool((got[real:] == -1).all())
 
 
+def test_rows_where_eq_many(dev):
+    """msmd_rows_where_eq_many == msmd_rows_where_eq list by list: contiguous and strided
+    flags, lists below / across scan tiles, an empty flag vector, a count of zero (skipped),
+    a capacity above the real count (-1 tail), 20 lists = two launch sets."""
+    from msmdfusion_amd import kernels as K
+    rng = np.random.RandomState(6)
+    jobs, want = [], []
+    for n in (1, 77, 2048, 2049, 50001, 0, 4100, 300, 9000, 12):
+        idx = t(rng.randint(0, 3, size=(max(n, 1), 5)).astype(np.int32), dev)[:n]
+        for flags in (idx[:, 1], idx[:, 1].contiguous()):
+            value = int(rng.randint(0, 3))
+            real = int((flags == value).sum()) if n else 0
+            extra = 3 if n == 300 else 0
+            jobs.append((flags, value, real + extra))
+            w = (flags == value).nonzero().flatten()
+            want.append(torch.cat([w, torch.full((extra,), -1, dtype=torch.long, device=dev)]))
+    got = K.rows_where_eq_many(jobs)
+    assert len(got) == len(jobs) == 20
+    for g, w, (f, v, c) in zip(got, want, jobs):
+        assert g.dtype == torch.long and g.shape[0] == c and torch.equal(g, w)
+        if c:
+            assert torch.equal(g, K.rows_where_eq(f, v, c))
+    assert K.rows_where_eq_many([]) == []
+
+
 def _plan_tables(dev):
     """Tables of an index pass in miniature: SubM 3x3x3 of three sizes (one below a block, one
     a single row), both sides of a stride-2 conv (ld > rows: the output side is the shorter
